@@ -1,0 +1,88 @@
+"""Pin the CPU oracle (oracle/titanet_oracle.py) against golden vectors produced by the real
+reference (tests/golden/make_golden.py).  CPU-only; runs in the build container and on the GPU box."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import titanet_oracle as O
+from tests.golden.cases import CASES
+from tests.util import LOSS_KW, case_inputs, case_state_dict, load_golden, oracle_cfg, rel_err
+
+FAST = ["tiny_k3", "tiny_k7", "tiny_k11_short", "mid_k3"]
+
+
+@pytest.mark.parametrize("name", FAST + ["s17_b8"])
+def test_eval_embeddings(name):
+    case, g = CASES[name], load_golden(name)
+    for dtype, tag, tol in ((torch.float64, "f64", 1e-10), (torch.float32, "f32", 2e-5)):
+        sd = case_state_dict(case, None, dtype)
+        x, _ = case_inputs(case, dtype)
+        with torch.no_grad():
+            out = O.titanet_forward(sd, x, oracle_cfg(case), training=False, keep_inter=(tag == "f64"))
+        assert rel_err(out.normalized.numpy(), g[f"eval.{tag}.embeddings"]) < tol
+        if tag == "f64" and case.get("inter"):
+            for k, v in g.items():
+                if not k.startswith("eval.f64.inter."):
+                    continue
+                key = k[len("eval.f64.inter."):]
+                key = key.replace(".excitation.gate", ".excitation.gate")
+                if key.endswith(".excitation.gate"):
+                    got = out.inter[key][:, :]
+                    assert rel_err(got.numpy(), v.reshape(got.shape)) < 1e-6, key
+                elif key in out.inter:
+                    assert rel_err(out.inter[key].numpy(), v) < 1e-6, key
+
+
+@pytest.mark.parametrize("name", FAST + ["s17_b8"])
+def test_train_forward_backward(name):
+    case, g = CASES[name], load_golden(name)
+    for loss in case["losses"]:
+        sd = case_state_dict(case, loss, torch.float64)
+        for k, v in sd.items():
+            if v.dtype.is_floating_point and "running_" not in k:
+                v.requires_grad_(True)
+        x, y = case_inputs(case)
+        x.requires_grad_(True)
+        kw = LOSS_KW[loss]
+        out = O.titanet_forward(sd, x, oracle_cfg(case), training=True, speakers=y,
+                                loss="ce" if loss == "ce" else "margin", loss_kwargs=kw)
+        p = f"train.{loss}"
+        assert abs(out.loss.item() - float(g[p + ".loss"])) < 1e-9 * max(1.0, abs(float(g[p + ".loss"])))
+        assert rel_err(out.normalized.detach().numpy(), g[p + ".embeddings"]) < 1e-9
+        assert np.array_equal(out.preds.numpy(), g[p + ".preds"])
+        assert rel_err(out.logits.detach().numpy().clip(-1e30, 1e30), np.clip(g[p + ".logits"], -1, 1) if loss != "ce" else g[p + ".logits"]) < 1e-9
+        if loss != "ce":
+            assert rel_err(out.new_fc_weight.numpy(), g[p + ".fc_weight_after"]) < 1e-12
+        out.loss.backward()
+        n_checked = 0
+        gscale = max([float(np.linalg.norm(v)) for k, v in g.items() if k.startswith(p + ".grad.")] + [1.0])
+        for k, v in g.items():
+            if not k.startswith(p + ".grad."):
+                continue
+            key = k[len(p + ".grad."):]
+            got = x.grad if key == "input" else sd[key].grad
+            assert got is not None, key
+            # goldens are stored as float32
+            # (a conv bias feeding a train-mode BN has an exactly-zero gradient: absolute floor)
+            err = float(np.linalg.norm(got.numpy() - v))
+            assert err < 2e-6 * float(np.linalg.norm(v)) + 1e-12 * gscale, (key, err)
+            n_checked += 1
+        assert n_checked > 0
+        for k, v in g.items():
+            if k.startswith(p + ".buffer."):
+                key = k[len(p + ".buffer."):]
+                assert rel_err(out.new_buffers[key].numpy(), v) < 1e-10, key
+
+
+def test_state_dict_layout_matches_reference_listing():
+    # 68 keys for N=1 + CE head; params 1.78 M (titanet.ipynb:961)
+    cfg = O.OracleConfig.titanet("s", n_mega_blocks=1)
+    shapes = O.state_dict_shapes(cfg, "ce", 251)
+    assert len(shapes) == 68
+    sizing = load_golden("sizing")
+    n = sum(int(np.prod(s)) for k, s in shapes.items() if "running_" not in k and "num_batches" not in k)
+    assert n == int(sizing["params.s1.ce251"]) == 1776379
+    for size, nb in (("s", 17), ("s", 18), ("m", 10), ("l", 5)):
+        shapes = O.state_dict_shapes(O.OracleConfig.titanet(size, n_mega_blocks=nb))
+        n = sum(int(np.prod(s)) for k, s in shapes.items() if "running_" not in k and "num_batches" not in k)
+        assert n == int(sizing[f"params.{size}{nb}"])
