@@ -1,0 +1,133 @@
+/* titanet_amd.h — C ABI of libtitanet_amd.so: the MI355X (gfx950 / CDNA4) hot path of
+ * Wadaboa/titanet — TitaNet encoder (prolog, depthwise-separable MegaBlocks with SE, epilog),
+ * attentive-statistics-pooling decoder and the CE / angular-margin loss heads, forward AND
+ * backward, as hand-written HIP kernels.
+ *
+ * The reference has no FFI: its boundary for this path is the nn.Module surface
+ *   TitaNet.forward(spectrograms, speakers=None)            reference src/models.py:318-339
+ *   TitaNet.get_titanet(...) / TitaNet.__init__(...)        reference src/models.py:175-219, :262-316
+ *   LOSSES[name](embedding_size, n_classes, ...).forward    reference src/losses.py:22-44, :47-132
+ *   model.state_dict() key names / shapes                   (SURVEY.md §8b listing)
+ * Every entry point below names the reference call it stands behind.  All pointers are plain
+ * device pointers (HIP), no framework types.  Every function returns 0 on success, a positive
+ * hipError_t, or a negative TN_E_* code; none of them synchronises the device or throws.
+ *
+ * Memory model: the caller owns four flat device buffers and binds them to a plan once:
+ *   params  float[tn_model_param_floats]   all learnable tensors, state_dict order
+ *   grads   float[tn_model_param_floats]   same layout (d loss / d param)
+ *   bnbuf   float[tn_model_buffer_floats]  BatchNorm running_mean / running_var
+ *   nbt     int64[tn_model_num_bn]         BatchNorm num_batches_tracked
+ *   workspace  char[tn_plan_workspace_bytes] activations saved for backward, statistics, scratch
+ * tn_model_tensor_info() maps every reference state_dict key to (buffer kind, offset, shape).
+ */
+#ifndef TITANET_AMD_H
+#define TITANET_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TN_E_BADARG (-1)
+#define TN_E_UNSUPPORTED (-2)
+#define TN_E_NOTBOUND (-3)
+#define TN_E_STATE (-4)
+
+#define TN_PREC_FP32 0 /* f32 storage, v_mfma_f32_32x32x2_f32: the 1e-3 parity path */
+#define TN_PREC_BF16 1 /* bf16 activations/weights, v_mfma_f32_32x32x16_bf16, f32 accumulate/statistics */
+
+#define TN_LOSS_NONE 0
+#define TN_LOSS_CE 1     /* reference src/losses.py:22-44  (fc has a bias)                     */
+#define TN_LOSS_MARGIN 2 /* reference src/losses.py:47-132 (ArcFace/CosFace/SphereFace; no bias) */
+
+/* Mirrors TitaNet.__init__ (reference src/models.py:175-192) + the loss constructor arguments
+ * (reference src/losses.py:56-75). */
+typedef struct tn_config {
+  int32_t n_mels;        /* 80 */
+  int32_t n_mega_blocks; /* 17 (parameters.yml:54) */
+  int32_t n_sub_blocks;  /* 3 */
+  int32_t hidden;        /* encoder_hidden_size: 256 / 512 / 1024 */
+  int32_t enc_out;       /* encoder_output_size: 1536 */
+  int32_t emb;           /* embedding_size: 192 */
+  int32_t kernel;        /* mega_block_kernel_size: 3 / 7 / 11 */
+  int32_t prolog_kernel; /* 3 */
+  int32_t epilog_kernel; /* 1 (only 1 is supported) */
+  int32_t attn_hidden;   /* attention_hidden_size: 128 */
+  int32_t se_reduction;  /* 16 */
+  int32_t loss_type;     /* TN_LOSS_* */
+  int32_t n_classes;     /* fc rows (0 when loss_type == TN_LOSS_NONE) */
+  int32_t has_scale;     /* margin loss: 0 => scale = ||x|| (reference scale=None) */
+  float dropout;         /* p of every Dropout / F.dropout in the mega blocks */
+  float scale, m1, m2, m3, loss_eps; /* margin loss: s, m1, m2, m3, eps (1e-6) */
+} tn_config;
+
+typedef struct tn_model tn_model; /* parameter layout for one architecture */
+typedef struct tn_plan tn_plan;   /* execution plan for one (batch, frames, precision) */
+
+/* kind of a state_dict tensor */
+#define TN_KIND_PARAM 0  /* offset in floats into params / grads */
+#define TN_KIND_BUFFER 1 /* offset in floats into bnbuf */
+#define TN_KIND_NBT 2    /* offset in int64 into nbt */
+
+/* ---- model layout (TitaNet.__init__ / state_dict; reference src/models.py:193-219) ---------- */
+int tn_model_create(const tn_config* cfg, tn_model** out);
+void tn_model_destroy(tn_model* m);
+int64_t tn_model_param_floats(const tn_model* m);
+int64_t tn_model_buffer_floats(const tn_model* m);
+int32_t tn_model_num_bn(const tn_model* m);
+int32_t tn_model_num_tensors(const tn_model* m);
+/* name: >=160 bytes; shape: 4 entries.  Tensors come in the reference's state_dict order. */
+int tn_model_tensor_info(const tn_model* m, int32_t index, char* name, int32_t* kind, int64_t* offset,
+                         int64_t* numel, int32_t* ndim, int64_t* shape);
+
+/* ---- plan ----------------------------------------------------------------------------------- */
+int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, int32_t precision, tn_plan** out);
+void tn_plan_destroy(tn_plan* p);
+size_t tn_plan_workspace_bytes(const tn_plan* p);
+/* Bind the caller-owned device buffers (grads may be NULL for inference-only use).  Uploads the
+ * small descriptor tables; call outside stream capture. */
+int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbuf, int64_t* nbt, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+/* ---- TitaNet.forward (reference src/models.py:318-339) --------------------------------------
+ * spectrograms: float32 [batch][n_mels][frames] (the reference's [B, M, T] layout).
+ * speakers:     int64 [batch] or NULL (inference: loss head skipped).
+ * training != 0: BatchNorm uses batch statistics and updates running stats, dropout active
+ *                (model.train()); activations are kept in the workspace for tn_backward.
+ * embeddings:   float32 [batch][emb]  L2-normalised embeddings (what the reference returns first).
+ * preds: int64 [batch], loss: float32 scalar (device) — written only when speakers != NULL.
+ * seed: dropout stream key for this step (counter-based, regenerated in backward). */
+int tn_forward(tn_plan* p, const float* spectrograms, const int64_t* speakers, int32_t training, uint64_t seed,
+               float* embeddings, int64_t* preds, float* loss, void* stream);
+
+/* ---- loss.backward() through the module (reference src/learn.py:117) -------------------------
+ * Must follow a tn_forward(training or eval) on the same plan.  Writes d loss / d params into
+ * the bound grads buffer (overwrite, not accumulate), scaled by grad_scale (d out / d loss, 1.0
+ * for loss.backward()) times *grad_scale_dev when that device scalar is given (autograd hands
+ * the upstream gradient over as a device tensor; reading it on the host would force a sync).
+ * grad_embeddings (float32 [batch][emb], may be NULL) is an additional
+ * upstream gradient on the returned normalised embeddings.  grad_input (float32
+ * [batch][n_mels][frames], may be NULL) receives d / d spectrograms (utils.chart_dependencies,
+ * reference src/utils.py:451-468). */
+int tn_backward(tn_plan* p, float grad_scale, const float* grad_scale_dev, const float* grad_embeddings,
+                float* grad_input, void* stream);
+
+/* ---- optim.Adam step on the flat buffers (reference src/train.py:131-135: Adam, lr 1e-3) -----
+ * grads are multiplied by grad_mult first (1/world_size after a sum all-reduce). */
+int tn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                 float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_mult,
+                 void* stream);
+
+/* ---- introspection for tests / roofline -------------------------------------------------------*/
+/* Copies a named internal tensor of the last forward as float32 in the REFERENCE layout.
+ * what: "logits" [B][n_classes]; "embeddings_raw" [B][emb]; "pooled" [B][2*enc_out];
+ *       "block_out:<i>" [B][hidden][T]; "prolog_out" [B][hidden][T]; "epilog_out" [B][enc_out][T];
+ *       "se_gate:<i>" [B][hidden].  dst: device float buffer of the right size. */
+int tn_debug_fetch(tn_plan* p, const char* what, float* dst, int64_t dst_floats, void* stream);
+const char* tn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TITANET_AMD_H */

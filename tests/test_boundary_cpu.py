@@ -1,0 +1,101 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol the
+header declares, and its parameter layout IS the reference state_dict (names, shapes, order)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import titanet_oracle as O
+from tests.util import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "titanet_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tn_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from titanet_amd import _lib
+    lib = _lib.load()
+    syms = _header_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert set(syms) == set(_lib.EXPORTS)
+    assert b"gfx950" in lib.tn_version()
+
+
+@pytest.mark.parametrize("loss", [None, "ce", "arc"])
+def test_layout_is_reference_state_dict(loss):
+    from titanet_amd import LOSSES, TitaNet
+    lf = None if loss is None else (LOSSES[loss](192, 251) if loss == "ce" else LOSSES[loss](192, 251, scale=30, margin=0.2))
+    m = TitaNet.get_titanet(n_mega_blocks=2, model_size="s", loss_function=lf)
+    sd = m.state_dict()
+    want = O.state_dict_shapes(O.OracleConfig.titanet("s", n_mega_blocks=2), loss=("ce" if loss == "ce" else ("m" if loss else None)),
+                               n_classes=251)
+    assert list(sd.keys()) == list(want.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(want[k]), k
+        assert v.dtype == (torch.int64 if k.endswith("num_batches_tracked") else torch.float32)
+    # every tensor is a view into the flat buffers
+    base = m.flat_parameters()
+    for n, p in m.named_parameters():
+        assert p.untyped_storage().data_ptr() == base.untyped_storage().data_ptr(), n
+
+
+def test_param_counts_match_reference_known_answers():
+    from titanet_amd import LOSSES, TitaNet
+    sizing = load_golden("sizing")
+    for size, n in (("s", 17), ("m", 10), ("l", 5)):
+        m = TitaNet.get_titanet(n_mega_blocks=n, model_size=size)
+        assert int(m.get_n_params()) == int(sizing[f"params.{size}{n}"])
+    m = TitaNet.get_titanet(n_mega_blocks=1, model_size="s", loss_function=LOSSES["ce"](192, 251))
+    assert int(m.get_n_params()) == 1776379            # titanet.ipynb:961 ("1.78M")
+    assert abs(m.get_n_params(div=1e6) - 1.78) < 0.01
+
+
+def test_find_n_mega_blocks_known_answers():
+    from titanet_amd import TitaNet
+    # titanet.ipynb:743,765,787
+    assert TitaNet.find_n_mega_blocks(192, 80, "s") == 18
+    assert TitaNet.find_n_mega_blocks(192, 80, "m") == 10
+    assert TitaNet.find_n_mega_blocks(192, 80, "l") == 5
+
+
+def test_state_dict_roundtrip_and_default_init():
+    from titanet_amd import LOSSES, TitaNet
+    torch.manual_seed(0)
+    m = TitaNet.get_titanet(n_mega_blocks=1, model_size="s", loss_function=LOSSES["ce"](192, 10))
+    sd = m.state_dict()
+    assert float(sd["encoder.prolog.conv_block.1.weight"].min()) == 1.0
+    assert float(sd["encoder.prolog.conv_block.1.running_var"].min()) == 1.0
+    w = sd["encoder.mega_blocks.0.sub_blocks.0.conv_block.0.conv.1.weight"]
+    assert abs(float(w.abs().max()) - 1 / 16) < 0.01          # kaiming_uniform(a=sqrt(5)): bound = 1/sqrt(fan_in)
+    m2 = TitaNet.get_titanet(n_mega_blocks=1, model_size="s", loss_function=LOSSES["ce"](192, 10))
+    m2.load_state_dict(sd)
+    assert torch.equal(m2.flat_parameters(), m.flat_parameters())
+
+
+def test_forward_without_gpu_fails_loudly():
+    from titanet_amd import TitaNet
+    m = TitaNet.get_titanet(n_mega_blocks=1, model_size="s").eval()
+    with pytest.raises(RuntimeError, match="no CPU execution path"):
+        m(torch.zeros(2, 80, 50))
+
+
+def test_reference_assertions():
+    from titanet_amd import LOSSES, TitaNet
+    with pytest.raises(AssertionError, match="Unsupported model size"):
+        TitaNet.get_titanet(n_mega_blocks=1, model_size="x")
+    with pytest.raises(AssertionError, match="Unsupported loss function"):
+        TitaNet.get_titanet(n_mega_blocks=1, loss_function=torch.nn.CrossEntropyLoss())
+    with pytest.raises(AssertionError, match="Margin out of bounds"):
+        LOSSES["arc"](192, 10, margin=1.5)
+    m = TitaNet.get_titanet(n_mega_blocks=1, model_size="s")
+    with pytest.raises(AssertionError, match="Loss function should not be None in training mode"):
+        m(torch.zeros(2, 80, 50), speakers=torch.zeros(2, dtype=torch.int64))

@@ -1,0 +1,86 @@
+"""ctypes binding of libtitanet_amd.so (the C ABI in include/titanet_amd.h).
+
+There is NO fallback: if the HIP library is missing the import fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtitanet_amd.so")
+
+TN_PREC_FP32, TN_PREC_BF16 = 0, 1
+TN_LOSS_NONE, TN_LOSS_CE, TN_LOSS_MARGIN = 0, 1, 2
+TN_KIND_PARAM, TN_KIND_BUFFER, TN_KIND_NBT = 0, 1, 2
+
+EXPORTS = [
+    "tn_model_create", "tn_model_destroy", "tn_model_param_floats", "tn_model_buffer_floats", "tn_model_num_bn",
+    "tn_model_num_tensors", "tn_model_tensor_info", "tn_plan_create", "tn_plan_destroy", "tn_plan_workspace_bytes",
+    "tn_plan_bind", "tn_forward", "tn_backward", "tn_adam_step", "tn_debug_fetch", "tn_version",
+]
+
+
+class TnConfig(C.Structure):
+    _fields_ = [
+        ("n_mels", C.c_int32), ("n_mega_blocks", C.c_int32), ("n_sub_blocks", C.c_int32), ("hidden", C.c_int32),
+        ("enc_out", C.c_int32), ("emb", C.c_int32), ("kernel", C.c_int32), ("prolog_kernel", C.c_int32),
+        ("epilog_kernel", C.c_int32), ("attn_hidden", C.c_int32), ("se_reduction", C.c_int32),
+        ("loss_type", C.c_int32), ("n_classes", C.c_int32), ("has_scale", C.c_int32),
+        ("dropout", C.c_float), ("scale", C.c_float), ("m1", C.c_float), ("m2", C.c_float), ("m3", C.c_float),
+        ("loss_eps", C.c_float),
+    ]
+
+
+class TitaNetLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TitaNetLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python titanet_amd/csrc/build.py` (hipcc --offload-arch=gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.tn_model_create.argtypes = [C.POINTER(TnConfig), C.POINTER(vp)]
+    lib.tn_model_destroy.argtypes = [vp]
+    lib.tn_model_destroy.restype = None
+    lib.tn_model_param_floats.argtypes = [vp]
+    lib.tn_model_param_floats.restype = i64
+    lib.tn_model_buffer_floats.argtypes = [vp]
+    lib.tn_model_buffer_floats.restype = i64
+    lib.tn_model_num_bn.argtypes = [vp]
+    lib.tn_model_num_bn.restype = i32
+    lib.tn_model_num_tensors.argtypes = [vp]
+    lib.tn_model_num_tensors.restype = i32
+    lib.tn_model_tensor_info.argtypes = [vp, i32, C.c_char_p, C.POINTER(i32), C.POINTER(i64), C.POINTER(i64),
+                                         C.POINTER(i32), C.POINTER(i64)]
+    lib.tn_plan_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    lib.tn_plan_destroy.argtypes = [vp]
+    lib.tn_plan_destroy.restype = None
+    lib.tn_plan_workspace_bytes.argtypes = [vp]
+    lib.tn_plan_workspace_bytes.restype = C.c_size_t
+    lib.tn_plan_bind.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.tn_forward.argtypes = [vp, vp, vp, i32, C.c_uint64, vp, vp, vp, vp]
+    lib.tn_backward.argtypes = [vp, f32, vp, vp, vp, vp]
+    lib.tn_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]
+    lib.tn_debug_fetch.argtypes = [vp, C.c_char_p, vp, i64, vp]
+    lib.tn_version.restype = C.c_char_p
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int:  # default restype; all status-returning entry points
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        names = {-1: "TN_E_BADARG", -2: "TN_E_UNSUPPORTED", -3: "TN_E_NOTBOUND", -4: "TN_E_STATE"}
+        raise TitaNetLibraryError(f"{what} failed: {names.get(rc, 'hipError_t ' + str(rc))}")

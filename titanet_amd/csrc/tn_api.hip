@@ -1,0 +1,575 @@
+// titanet_amd — C ABI, model layout, execution plan and the forward orchestration.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "tn_fwd_kernels.h"
+#include "tn_gemm.h"
+#include "tn_internal.h"
+
+// =============================================================================================
+// model layout == reference state_dict (reference src/models.py:370-384, :432-455, :504-513,
+// src/modules.py:65-78, :119-133, :166-171, src/losses.py:31, :68)
+// =============================================================================================
+namespace {
+
+struct LayoutBuilder {
+  tn_model* m;
+  int64_t add(const std::string& name, int kind, std::initializer_list<int64_t> shape) {
+    TensorInfo t;
+    t.name = name;
+    t.kind = kind;
+    t.ndim = (int)shape.size();
+    t.numel = 1;
+    int i = 0;
+    for (auto s : shape) { t.shape[i++] = s; t.numel *= s; }
+    for (; i < 4; ++i) t.shape[i] = 1;
+    int64_t* counter = (kind == TN_KIND_PARAM) ? &m->n_params : &m->n_buffers;
+    if (kind == TN_KIND_NBT) {
+      t.offset = m->n_bn;   // caller bumps n_bn
+    } else {
+      *counter = (*counter + 15) & ~(int64_t)15;   // 64-byte aligned tensors (float4 / 16-byte loads)
+      t.offset = *counter;
+      *counter += t.numel;
+    }
+    m->tensors.push_back(t);
+    return t.offset;
+  }
+  BnRef bn(const std::string& prefix, int C) {
+    BnRef r;
+    r.C = C;
+    r.gamma = add(prefix + ".weight", TN_KIND_PARAM, {C});
+    r.beta = add(prefix + ".bias", TN_KIND_PARAM, {C});
+    r.rmean = add(prefix + ".running_mean", TN_KIND_BUFFER, {C});
+    r.rvar = add(prefix + ".running_var", TN_KIND_BUFFER, {C});
+    add(prefix + ".num_batches_tracked", TN_KIND_NBT, {});
+    r.id = m->n_bn++;
+    m->all_bn.push_back(r);
+    return r;
+  }
+};
+
+int validate(const tn_config& c) {
+  if (c.n_mels <= 0 || c.n_mega_blocks < 0 || c.n_sub_blocks < 1) return TN_E_BADARG;
+  if (c.hidden % 8 || c.enc_out % 8 || c.emb % 8 || c.attn_hidden % 8 || c.hidden <= 0) return TN_E_UNSUPPORTED;
+  if ((c.n_mels * c.prolog_kernel) % 8) return TN_E_UNSUPPORTED;
+  if (c.kernel % 2 == 0 || c.prolog_kernel % 2 == 0 || c.epilog_kernel != 1) return TN_E_UNSUPPORTED;
+  if (c.se_reduction <= 0 || c.hidden / c.se_reduction < 1) return TN_E_BADARG;
+  if (c.hidden > 4096 || c.emb > 4096) return TN_E_UNSUPPORTED;
+  if (c.loss_type != TN_LOSS_NONE && c.n_classes <= 0) return TN_E_BADARG;
+  if (c.dropout < 0.f || c.dropout >= 1.f) return TN_E_BADARG;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int tn_model_create(const tn_config* cfg, tn_model** out) {
+  if (!cfg || !out) return TN_E_BADARG;
+  int rc = validate(*cfg);
+  if (rc) return rc;
+  tn_model* m = new tn_model();
+  m->cfg = *cfg;
+  LayoutBuilder L{m};
+  const int H = cfg->hidden, D = cfg->enc_out, Hr = cfg->hidden / cfg->se_reduction;
+  m->prolog_w = L.add("encoder.prolog.conv_block.0.weight", TN_KIND_PARAM, {H, cfg->n_mels, cfg->prolog_kernel});
+  m->prolog_b = L.add("encoder.prolog.conv_block.0.bias", TN_KIND_PARAM, {H});
+  m->prolog_bn = L.bn("encoder.prolog.conv_block.1", H);
+  for (int i = 0; i < cfg->n_mega_blocks; ++i) {
+    MegaBlockRef mb;
+    const std::string p = "encoder.mega_blocks." + std::to_string(i);
+    for (int j = 0; j < cfg->n_sub_blocks; ++j) {
+      const std::string q = p + ".sub_blocks." + std::to_string(j) + ".conv_block";
+      SubBlockRef s;
+      s.wdw = L.add(q + ".0.conv.0.weight", TN_KIND_PARAM, {H, 1, cfg->kernel});
+      s.bdw = L.add(q + ".0.conv.0.bias", TN_KIND_PARAM, {H});
+      s.wpw = L.add(q + ".0.conv.1.weight", TN_KIND_PARAM, {H, H, 1});
+      s.bpw = L.add(q + ".0.conv.1.bias", TN_KIND_PARAM, {H});
+      s.bn = L.bn(q + ".1", H);
+      mb.sub.push_back(s);
+    }
+    const std::string q = p + ".sub_blocks." + std::to_string(cfg->n_sub_blocks) + ".excitation";
+    mb.se_w1 = L.add(q + ".0.weight", TN_KIND_PARAM, {Hr, H});
+    mb.se_w2 = L.add(q + ".2.weight", TN_KIND_PARAM, {H, Hr});
+    mb.wskip = L.add(p + ".skip_connection.0.weight", TN_KIND_PARAM, {H, H, 1});
+    mb.bskip = L.add(p + ".skip_connection.0.bias", TN_KIND_PARAM, {H});
+    mb.bnskip = L.bn(p + ".skip_connection.1", H);
+    m->blocks.push_back(mb);
+  }
+  m->epi_w = L.add("encoder.epilog.conv_block.0.weight", TN_KIND_PARAM, {D, H, 1});
+  m->epi_b = L.add("encoder.epilog.conv_block.0.bias", TN_KIND_PARAM, {D});
+  m->epi_bn = L.bn("encoder.epilog.conv_block.1", D);
+  m->asp_win = L.add("decoder.pool.0.in_linear.weight", TN_KIND_PARAM, {cfg->attn_hidden, D});
+  m->asp_bin = L.add("decoder.pool.0.in_linear.bias", TN_KIND_PARAM, {cfg->attn_hidden});
+  m->asp_wout = L.add("decoder.pool.0.out_linear.weight", TN_KIND_PARAM, {D, cfg->attn_hidden});
+  m->asp_bout = L.add("decoder.pool.0.out_linear.bias", TN_KIND_PARAM, {D});
+  m->pool_bn = L.bn("decoder.pool.1", 2 * D);
+  m->lin_w = L.add("decoder.linear.0.weight", TN_KIND_PARAM, {cfg->emb, 2 * D});
+  m->lin_b = L.add("decoder.linear.0.bias", TN_KIND_PARAM, {cfg->emb});
+  m->lin_bn = L.bn("decoder.linear.1", cfg->emb);
+  if (cfg->loss_type != TN_LOSS_NONE) {
+    m->fc_w = L.add("loss_function.fc.weight", TN_KIND_PARAM, {cfg->n_classes, cfg->emb});
+    if (cfg->loss_type == TN_LOSS_CE) m->fc_b = L.add("loss_function.fc.bias", TN_KIND_PARAM, {cfg->n_classes});
+  }
+  m->n_params = (m->n_params + 15) & ~(int64_t)15;
+  m->n_buffers = (m->n_buffers + 15) & ~(int64_t)15;
+  *out = m;
+  return 0;
+}
+
+extern "C" void tn_model_destroy(tn_model* m) { delete m; }
+extern "C" int64_t tn_model_param_floats(const tn_model* m) { return m ? m->n_params : 0; }
+extern "C" int64_t tn_model_buffer_floats(const tn_model* m) { return m ? m->n_buffers : 0; }
+extern "C" int32_t tn_model_num_bn(const tn_model* m) { return m ? m->n_bn : 0; }
+extern "C" int32_t tn_model_num_tensors(const tn_model* m) { return m ? (int32_t)m->tensors.size() : 0; }
+extern "C" int tn_model_tensor_info(const tn_model* m, int32_t index, char* name, int32_t* kind, int64_t* offset,
+                                    int64_t* numel, int32_t* ndim, int64_t* shape) {
+  if (!m || index < 0 || index >= (int32_t)m->tensors.size()) return TN_E_BADARG;
+  const TensorInfo& t = m->tensors[index];
+  if (name) { strncpy(name, t.name.c_str(), 159); name[159] = 0; }
+  if (kind) *kind = t.kind;
+  if (offset) *offset = t.offset;
+  if (numel) *numel = t.numel;
+  if (ndim) *ndim = t.ndim;
+  if (shape) for (int i = 0; i < 4; ++i) shape[i] = t.shape[i];
+  return 0;
+}
+extern "C" const char* tn_version(void) { return "titanet_amd 0.1 (gfx950)"; }
+
+// =============================================================================================
+// plan
+// =============================================================================================
+namespace {
+struct Bump {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    size_t r = off;
+    off += bytes;
+    return r;
+  }
+};
+}  // namespace
+
+extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, int32_t precision, tn_plan** out) {
+  if (!m || !out || batch <= 0 || frames <= 0) return TN_E_BADARG;
+  if (precision != TN_PREC_FP32 && precision != TN_PREC_BF16) return TN_E_BADARG;
+  if ((int64_t)batch * frames * std::max(m->cfg.enc_out, m->cfg.hidden) >= ((int64_t)1 << 32)) return TN_E_UNSUPPORTED;
+  tn_plan* p = new tn_plan();
+  p->model = m;
+  p->B = batch; p->T = frames; p->M = batch * frames; p->prec = precision;
+  p->esz = precision == TN_PREC_BF16 ? 2 : 4;
+  const tn_config& c = m->cfg;
+  const size_t M = p->M, H = c.hidden, D = c.enc_out, A = c.attn_hidden, Hr = c.hidden / c.se_reduction;
+  const size_t e = p->esz;
+  Bump b;
+  // ---- zeroed-every-step region: statistics, backward sums, loss accumulator
+  p->zero_begin = b.take(0);
+  p->stats.resize(m->n_bn);
+  p->bsums.resize(m->n_bn);
+  for (int i = 0; i < m->n_bn; ++i) p->stats[i] = b.take((size_t)TN_NREP * 2 * m->all_bn[i].C * sizeof(float));
+  for (int i = 0; i < m->n_bn; ++i) p->bsums[i] = b.take((size_t)TN_NREP * 2 * m->all_bn[i].C * sizeof(float));
+  p->loss_acc = b.take(256);
+  p->zero_bytes = ((b.off + 255) & ~(size_t)255) - p->zero_begin;
+  // ---- compute-precision weights
+  auto wc = [&](size_t n, size_t k) { WcRef r; r.w = b.take(n * k * e); r.wt = b.take(n * k * e); return r; };
+  p->wprolog = wc(H, (size_t)c.n_mels * c.prolog_kernel);
+  p->wepi = wc(D, H);
+  p->wwin = wc(A, D);
+  p->wwout = wc(D, A);
+  // ---- activations
+  p->Y0 = b.take(M * H * e);
+  p->blk.resize(c.n_mega_blocks);
+  for (auto& bw : p->blk) {
+    for (int j = 0; j < c.n_sub_blocks; ++j) { bw.Y.push_back(b.take(M * H * e)); bw.wpw.push_back(wc(H, H)); }
+    bw.wskip = wc(H, H);
+    bw.S = b.take(M * H * e);
+    bw.OUT = b.take(M * H * e);
+    bw.m = b.take((size_t)batch * H * 4);
+    bw.h = b.take((size_t)batch * Hr * 4);
+    bw.g = b.take((size_t)batch * H * 4);
+    bw.dpre2 = b.take((size_t)batch * H * 4);
+    bw.dpre1 = b.take((size_t)batch * Hr * 4);
+  }
+  p->E = b.take(M * D * e);
+  p->HID = b.take(M * A * e);
+  p->EN = b.take(M * D * e);
+  p->pooled = b.take((size_t)batch * 2 * D * 4);
+  p->smax = b.take((size_t)batch * D * 4);
+  p->sinv = b.take((size_t)batch * D * 4);
+  p->qv = b.take((size_t)batch * D * 4);
+  p->lin = b.take((size_t)batch * c.emb * 4);
+  p->emb = b.take((size_t)batch * c.emb * 4);
+  p->emb_norm = b.take((size_t)batch * c.emb * 4);
+  const size_t nc = std::max(c.n_classes, 1);
+  p->dlogits = b.take((size_t)batch * nc * 4);
+  p->logits = b.take((size_t)batch * nc * 4);
+  p->dscale = b.take((size_t)batch * 4);
+  p->preds = b.take((size_t)batch * 8);
+  // ---- backward scratch
+  p->dA[0] = b.take(M * H * e);
+  p->dA[1] = b.take(M * H * e);
+  p->dYbn = b.take(M * H * e);
+  p->dD = b.take(M * H * e);
+  p->dZ = b.take(M * H * e);
+  p->dXs = b.take(M * H * e);
+  p->dE = b.take(M * D * e);
+  p->dEbn = b.take(M * D * e);
+  p->dHP = b.take(M * A * e);
+  p->dpooled = b.take((size_t)batch * 2 * D * 4);
+  p->dlin = b.take((size_t)batch * c.emb * 4);
+  p->demb = b.take((size_t)batch * c.emb * 4);
+  // split-K slabs for weight gradients: sized for the largest weight (see tn_bwd.hip)
+  {
+    size_t biggest = std::max({H * H, D * H, D * A, H * (size_t)c.n_mels * c.prolog_kernel});
+    p->slab_bytes = biggest * sizeof(float) * 64;   // up to 64 K-splits
+    p->slabs = b.take(p->slab_bytes);
+  }
+  p->cast_table = b.take(sizeof(CastDesc) * (8 + (size_t)c.n_mega_blocks * (c.n_sub_blocks + 1)));
+  p->bn_table = b.take(sizeof(BnUpdateDesc) * m->n_bn);
+  p->bwd_table = b.take(4096);
+  p->ws_bytes = (b.off + 255) & ~(size_t)255;
+  *out = p;
+  return 0;
+}
+
+extern "C" void tn_plan_destroy(tn_plan* p) { delete p; }
+extern "C" size_t tn_plan_workspace_bytes(const tn_plan* p) { return p ? p->ws_bytes : 0; }
+
+extern "C" int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbuf, int64_t* nbt, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  if (!p || !params || !bnbuf || !nbt || !workspace) return TN_E_BADARG;
+  if (workspace_bytes < p->ws_bytes) return TN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  p->params = params; p->grads = grads; p->bnbuf = bnbuf; p->nbt = nbt; p->ws = (char*)workspace;
+  const tn_model* m = p->model;
+  const tn_config& c = m->cfg;
+  // cast table: bf16 needs the straight copy + the transpose; fp32 reads the masters directly and
+  // only needs the transposes (for the data-gradient GEMMs)
+  std::vector<CastDesc> cd;
+  const bool bf = p->prec == TN_PREC_BF16;
+  auto add = [&](int64_t off, const WcRef& r, int R, int C, bool need_t) {
+    CastDesc d;
+    d.src = params + off;
+    d.dst = bf ? (void*)(p->ws + r.w) : nullptr;
+    d.dstT = need_t ? (void*)(p->ws + r.wt) : nullptr;
+    d.R = R; d.C = C;
+    if (d.dst || d.dstT) cd.push_back(d);
+  };
+  add(m->prolog_w, p->wprolog, c.hidden, c.n_mels * c.prolog_kernel, false);
+  add(m->epi_w, p->wepi, c.enc_out, c.hidden, true);
+  add(m->asp_win, p->wwin, c.attn_hidden, c.enc_out, true);
+  add(m->asp_wout, p->wwout, c.enc_out, c.attn_hidden, true);
+  for (int i = 0; i < c.n_mega_blocks; ++i) {
+    for (int j = 0; j < c.n_sub_blocks; ++j) add(m->blocks[i].sub[j].wpw, p->blk[i].wpw[j], c.hidden, c.hidden, true);
+    add(m->blocks[i].wskip, p->blk[i].wskip, c.hidden, c.hidden, true);
+  }
+  p->n_cast = (int)cd.size();
+  TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->cast_table, cd.data(), cd.size() * sizeof(CastDesc), hipMemcpyHostToDevice, st));
+  std::vector<BnUpdateDesc> bd(m->n_bn);
+  for (int i = 0; i < m->n_bn; ++i) {
+    const BnRef& r = m->all_bn[i];
+    bd[i].stats = (const float*)(p->ws + p->stats[i]);
+    bd[i].rmean = bnbuf + r.rmean;
+    bd[i].rvar = bnbuf + r.rvar;
+    bd[i].C = r.C;
+    bd[i].n = (i == m->pool_bn.id || i == m->lin_bn.id) ? p->B : p->M;
+  }
+  TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->bn_table, bd.data(), bd.size() * sizeof(BnUpdateDesc), hipMemcpyHostToDevice, st));
+  TN_CHECK_HIP(hipStreamSynchronize(st));   // host vectors go out of scope
+  p->bound = true;
+  return 0;
+}
+
+// =============================================================================================
+// forward
+// =============================================================================================
+BnAct identity_act() {
+  BnAct a;
+  memset(&a, 0, sizeof(a));
+  return a;
+}
+
+BnAct make_act(const tn_plan* p, const BnRef& bn, int rows, int training, int relu, float drop_p, uint64_t seed,
+               int layer) {
+  BnAct a;
+  memset(&a, 0, sizeof(a));
+  a.stats = (const float*)(p->ws + p->stats[bn.id]);
+  a.gamma = p->params + bn.gamma;
+  a.beta = p->params + bn.beta;
+  a.rmean = p->bnbuf + bn.rmean;
+  a.rvar = p->bnbuf + bn.rvar;
+  a.inv_n = 1.f / (float)rows;
+  a.eps = 1e-5f;
+  a.mode = training ? 1 : 2;
+  a.relu = relu;
+  if (training && drop_p > 0.f) {
+    a.drop_thr = (uint32_t)lrintf(drop_p * 65536.f);
+    a.drop_key = tn_layer_key(seed, (uint32_t)layer);
+    a.inv_keep = 1.f / (1.f - drop_p);
+  }
+  return a;
+}
+
+namespace {
+
+template <typename AT, typename Prod, typename Epi = EpiStore>
+int gemm_store(const GemmShape& g, const typename Prod::Args& pa, const EpiStoreArgs& ea, int KD, hipStream_t st) {
+  if (g.N > 128) return launch_gemm<AT, 2, 4, Prod, Epi>(g, pa, ea, KD, st);
+  return launch_gemm<AT, 2, 2, Prod, Epi>(g, pa, ea, KD, st);
+}
+
+template <typename AT>
+const void* wsel(const tn_plan* p, int64_t master_off, const WcRef& r) {
+  if (sizeof(AT) == 4) return p->params + master_off;
+  return p->ws + r.w;
+}
+
+template <typename AT>
+int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int training, uint64_t seed, float* emb_out,
+                 int64_t* preds, float* loss, hipStream_t st) {
+  const tn_model* m = p->model;
+  const tn_config& c = m->cfg;
+  const int M = p->M, H = c.hidden, D = c.enc_out, A = c.attn_hidden, Hr = c.hidden / c.se_reduction, T = p->T, B = p->B;
+  char* ws = p->ws;
+  float* params = p->params;
+  const float pd = c.dropout;
+  auto statp = [&](const BnRef& bn) -> float* { return training ? (float*)(ws + p->stats[bn.id]) : nullptr; };
+
+  TN_CHECK_HIP(hipMemsetAsync(ws + p->zero_begin, 0, p->zero_bytes, st));
+  if (p->n_cast > 0) {
+    hipLaunchKernelGGL(cast_params_kernel<AT>, dim3(64, p->n_cast), dim3(256), 0, st, (const CastDesc*)(ws + p->cast_table));
+  }
+  // ---- prolog: dense k=3 conv as an im2col GEMM (reference src/models.py:370, :398)
+  {
+    GemmShape g{M, H, c.n_mels * c.prolog_kernel, wsel<AT>(p, m->prolog_w, p->wprolog)};
+    ProdIm2col::Args pa{spec, c.n_mels, c.prolog_kernel, T};
+    EpiStoreArgs ea{ws + p->Y0, H, params + m->prolog_b, statp(m->prolog_bn)};
+    int rc = gemm_store<AT, ProdIm2col>(g, pa, ea, 0, st);
+    if (rc) return rc;
+  }
+  const void* xin = ws + p->Y0;
+  BnAct actx = make_act(p, m->prolog_bn, M, training, 1, 0.f, seed, 0);
+  for (int i = 0; i < c.n_mega_blocks; ++i) {
+    const MegaBlockRef& mb = m->blocks[i];
+    BlockWs& bw = p->blk[i];
+    // skip connection: 1x1 conv (reference src/models.py:452-455)
+    {
+      GemmShape g{M, H, H, wsel<AT>(p, mb.wskip, bw.wskip)};
+      ProdPlain::Args pa{xin, H, actx};
+      EpiStoreArgs ea{ws + bw.S, H, params + mb.bskip, statp(mb.bnskip)};
+      int rc = gemm_store<AT, ProdPlain>(g, pa, ea, 0, st);
+      if (rc) return rc;
+    }
+    const void* cur = xin;
+    BnAct acur = actx;
+    for (int j = 0; j < c.n_sub_blocks; ++j) {
+      const SubBlockRef& sb = mb.sub[j];
+      GemmShape g{M, H, H, wsel<AT>(p, sb.wpw, bw.wpw[j])};
+      ProdDw::Args pa{cur, H, acur, params + sb.wdw, params + sb.bdw, c.kernel, T};
+      EpiStoreArgs ea{ws + bw.Y[j], H, params + sb.bpw, statp(sb.bn)};
+      int rc = gemm_store<AT, ProdDw>(g, pa, ea, c.kernel, st);
+      if (rc) return rc;
+      cur = ws + bw.Y[j];
+      acur = make_act(p, sb.bn, M, training, 1, pd, seed, i * (c.n_sub_blocks + 1) + j);
+    }
+    // SE gate + residual combine (reference src/modules.py:173-189, src/models.py:467-472)
+    {
+      const int CV = H / 8, TG = 512 / CV;
+      size_t smem = (size_t)(3 * H + ((Hr + 3) & ~3) + TG * H) * sizeof(float);
+      hipLaunchKernelGGL(se_squeeze_fc_kernel<AT>, dim3(B), dim3(512), smem, st, (const AT*)cur, acur, T, H, Hr,
+                         params + mb.se_w1, params + mb.se_w2, (float*)(ws + bw.m), (float*)(ws + bw.h), (float*)(ws + bw.g));
+      BnAct acts = make_act(p, mb.bnskip, M, training, 0, 0.f, seed, 0);
+      uint32_t thr = 0, key = 0;
+      float ik = 1.f;
+      if (training && pd > 0.f) {
+        thr = (uint32_t)lrintf(pd * 65536.f);
+        key = tn_layer_key(seed, (uint32_t)(i * (c.n_sub_blocks + 1) + c.n_sub_blocks));
+        ik = 1.f / (1.f - pd);
+      }
+      const int rpb = 64;
+      hipLaunchKernelGGL(combine_fwd_kernel<AT>, dim3((M + rpb - 1) / rpb), dim3(256), (size_t)4 * H * sizeof(float), st,
+                         (const AT*)(ws + bw.S), acts, (const AT*)cur, acur, (const float*)(ws + bw.g), (AT*)(ws + bw.OUT), M,
+                         T, H, rpb, thr, key, ik);
+    }
+    xin = ws + bw.OUT;
+    actx = identity_act();
+  }
+  // ---- epilog 1x1 conv (reference src/models.py:384, :404)
+  {
+    GemmShape g{M, D, H, wsel<AT>(p, m->epi_w, p->wepi)};
+    ProdPlain::Args pa{xin, H, actx};
+    EpiStoreArgs ea{ws + p->E, D, params + m->epi_b, statp(m->epi_bn)};
+    int rc = gemm_store<AT, ProdPlain>(g, pa, ea, 0, st);
+    if (rc) return rc;
+  }
+  BnAct acte = make_act(p, m->epi_bn, M, training, 1, 0.f, seed, 0);
+  // ---- attentive statistics pooling (reference src/models.py:553-584)
+  {
+    GemmShape g1{M, A, D, wsel<AT>(p, m->asp_win, p->wwin)};
+    ProdPlain::Args pa1{ws + p->E, D, acte};
+    EpiStoreArgs ea1{ws + p->HID, A, params + m->asp_bin, nullptr};
+    int rc = gemm_store<AT, ProdPlain, EpiStoreTanh>(g1, pa1, ea1, 0, st);
+    if (rc) return rc;
+    GemmShape g2{M, D, A, wsel<AT>(p, m->asp_wout, p->wwout)};
+    ProdPlain::Args pa2{ws + p->HID, A, identity_act()};
+    EpiStoreArgs ea2{ws + p->EN, D, params + m->asp_bout, nullptr};
+    rc = gemm_store<AT, ProdPlain>(g2, pa2, ea2, 0, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(asp_pool_fwd_kernel<AT>, dim3(B, (D + 511) / 512), dim3(256), 0, st, (const AT*)(ws + p->E), acte,
+                       (const AT*)(ws + p->EN), T, D, 1e-6f, (float*)(ws + p->pooled), (float*)(ws + p->smax),
+                       (float*)(ws + p->sinv), (float*)(ws + p->qv), statp(m->pool_bn));
+  }
+  // ---- decoder tail + loss head (reference src/models.py:504-513, src/losses.py)
+  {
+    BnAct actp = make_act(p, m->pool_bn, B, training, 0, 0.f, seed, 0);
+    hipLaunchKernelGGL(tail_linear_fwd_kernel, dim3(B), dim3(256), (size_t)2 * D * sizeof(float), st,
+                       (const float*)(ws + p->pooled), actp, 2 * D, c.emb, params + m->lin_w, params + m->lin_b,
+                       (float*)(ws + p->lin), statp(m->lin_bn));
+    HeadArgs ha;
+    memset(&ha, 0, sizeof(ha));
+    ha.lin = (const float*)(ws + p->lin);
+    ha.actL = make_act(p, m->lin_bn, B, training, 0, 0.f, seed, 0);
+    ha.B = B; ha.E = c.emb; ha.NC = c.n_classes;
+    ha.loss_type = speakers ? c.loss_type : TN_LOSS_NONE;
+    if (speakers && c.loss_type == TN_LOSS_NONE) return TN_E_STATE;   // "Loss function should not be None in training mode"
+    ha.W = m->fc_w >= 0 ? params + m->fc_w : nullptr;
+    ha.bias = m->fc_b >= 0 ? params + m->fc_b : nullptr;
+    ha.targets = speakers;
+    ha.scale = c.scale; ha.has_scale = c.has_scale; ha.m1 = c.m1; ha.m2 = c.m2; ha.m3 = c.m3; ha.eps = c.loss_eps;
+    ha.emb = (float*)(ws + p->emb);
+    ha.emb_norm = emb_out ? emb_out : (float*)(ws + p->emb_norm);
+    ha.preds = preds ? preds : (int64_t*)(ws + p->preds);
+    ha.loss = (float*)(ws + p->loss_acc);
+    ha.dlogits = (float*)(ws + p->dlogits);
+    ha.dscale = (float*)(ws + p->dscale);
+    ha.logits = (float*)(ws + p->logits);
+    if (ha.loss_type == TN_LOSS_MARGIN) {
+      hipLaunchKernelGGL(row_normalize_kernel, dim3((c.n_classes + 3) / 4), dim3(256), 0, st, params + m->fc_w, c.n_classes, c.emb);
+    }
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (size_t)(c.emb + std::max(c.n_classes, 1)) * sizeof(float), st, ha);
+    if (speakers && loss) TN_CHECK_HIP(hipMemcpyAsync(loss, ws + p->loss_acc, sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  if (training) {
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(2, m->n_bn), dim3(256), 0, st, (const BnUpdateDesc*)(ws + p->bn_table),
+                       0.1f, p->nbt, m->n_bn);
+  }
+  p->last_training = training;
+  p->last_has_loss = speakers != nullptr;
+  p->last_seed = seed;
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int plan_forward(tn_plan* p, const float* spec, const int64_t* speakers, int training, uint64_t seed, float* emb_out,
+                 int64_t* preds, float* loss, hipStream_t st) {
+  if (p->prec == TN_PREC_BF16) return forward_impl<bf16_t>(p, spec, speakers, training, seed, emb_out, preds, loss, st);
+  return forward_impl<float>(p, spec, speakers, training, seed, emb_out, preds, loss, st);
+}
+
+extern "C" int tn_forward(tn_plan* p, const float* spectrograms, const int64_t* speakers, int32_t training,
+                          uint64_t seed, float* embeddings, int64_t* preds, float* loss, void* stream) {
+  if (!p || !spectrograms) return TN_E_BADARG;
+  if (!p->bound) return TN_E_NOTBOUND;
+  if (training && p->B < 2) return TN_E_BADARG;   // BatchNorm1d raises on a batch of 1 in train mode
+  return plan_forward(p, spectrograms, speakers, training, seed, embeddings, preds, loss, (hipStream_t)stream);
+}
+
+extern "C" int tn_backward(tn_plan* p, float grad_scale, const float* grad_scale_dev, const float* grad_embeddings,
+                           float* grad_input, void* stream) {
+  if (!p) return TN_E_BADARG;
+  if (!p->bound || !p->grads) return TN_E_NOTBOUND;
+  if (p->last_training < 0) return TN_E_STATE;
+  return plan_backward(p, grad_scale, grad_scale_dev, grad_embeddings, grad_input, (hipStream_t)stream);
+}
+
+// =============================================================================================
+// Adam (torch.optim.Adam semantics, reference src/train.py:131-135)
+// =============================================================================================
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                            float bc1, float bc2_sqrt, float gmult) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gmult;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+
+extern "C" int tn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_mult,
+                            void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) return TN_E_BADARG;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
+  int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr,
+                     beta1, beta2, eps, weight_decay, bc1, bc2, grad_mult);
+  return (int)hipGetLastError();
+}
+
+// =============================================================================================
+// debug fetch (tests): internal rows-x-channels tensors -> float32 reference layout
+// =============================================================================================
+template <typename AT>
+__global__ void fetch_bct_kernel(const AT* __restrict__ src, BnAct act, int M, int T, int C, float* __restrict__ dst) {
+  const size_t n = (size_t)M * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / C), c = (int)(i % C);
+    float v = Elem<AT>::to_f(src[i]);
+    if (act.mode != 0) { float sc, sh; bn_scale_shift(act, C, c, sc, sh); v = v * sc + sh; }
+    if (act.relu) v = fmaxf(v, 0.f);
+    if (act.drop_thr) {
+      const uint32_t e = (uint32_t)i;
+      const uint32_t k = tn_keep_pair(e >> 1, act.drop_key, act.drop_thr);
+      v = ((k >> (e & 1u)) & 1u) ? v * act.inv_keep : 0.f;
+    }
+    const int b = row / T, t = row % T;
+    dst[((size_t)b * C + c) * T + t] = v;
+  }
+}
+
+extern "C" int tn_debug_fetch(tn_plan* p, const char* what, float* dst, int64_t dst_floats, void* stream) {
+  if (!p || !what || !dst || !p->bound || p->last_training < 0) return TN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const tn_model* m = p->model;
+  const tn_config& c = m->cfg;
+  std::string w(what);
+  auto copyf = [&](size_t off, int64_t n) -> int {
+    if (dst_floats < n) return TN_E_BADARG;
+    TN_CHECK_HIP(hipMemcpyAsync(dst, p->ws + off, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+  };
+  auto fetch = [&](size_t off, const BnAct& act, int C) -> int {
+    if (dst_floats < (int64_t)p->M * C) return TN_E_BADARG;
+    if (p->prec == TN_PREC_BF16)
+      hipLaunchKernelGGL(fetch_bct_kernel<bf16_t>, dim3(1024), dim3(256), 0, st, (const bf16_t*)(p->ws + off), act, p->M, p->T, C, dst);
+    else
+      hipLaunchKernelGGL(fetch_bct_kernel<float>, dim3(1024), dim3(256), 0, st, (const float*)(p->ws + off), act, p->M, p->T, C, dst);
+    return (int)hipGetLastError();
+  };
+  if (w == "logits") return copyf(p->logits, (int64_t)p->B * c.n_classes);
+  if (w == "embeddings_raw") return copyf(p->emb, (int64_t)p->B * c.emb);
+  if (w == "pooled") return copyf(p->pooled, (int64_t)p->B * 2 * c.enc_out);
+  if (w == "prolog_out") return fetch(p->Y0, make_act(p, m->prolog_bn, p->M, p->last_training, 1, 0.f, 0, 0), c.hidden);
+  if (w == "epilog_out") return fetch(p->E, make_act(p, m->epi_bn, p->M, p->last_training, 1, 0.f, 0, 0), c.enc_out);
+  if (w.rfind("block_out:", 0) == 0) {
+    int i = atoi(w.c_str() + 10);
+    if (i < 0 || i >= c.n_mega_blocks) return TN_E_BADARG;
+    return fetch(p->blk[i].OUT, identity_act(), c.hidden);
+  }
+  if (w.rfind("se_gate:", 0) == 0) {
+    int i = atoi(w.c_str() + 8);
+    if (i < 0 || i >= c.n_mega_blocks) return TN_E_BADARG;
+    return copyf(p->blk[i].g, (int64_t)p->B * c.hidden);
+  }
+  return TN_E_BADARG;
+}

@@ -1,0 +1,215 @@
+// titanet_amd — common device helpers for the gfx950 (MI355X / CDNA4) kernels.
+//
+// Layout convention used by every kernel in this library ("rows x channels"):
+//   an activation tensor of the reference shape [B, C, T] (reference src/models.py:386-404)
+//   is stored as a row-major matrix [M = B*T rows][C channels], row = b*T + t, channels
+//   contiguous.  Pointwise (1x1) convs are then NT GEMMs with both operands K-contiguous
+//   (what the MFMA fragment loads want), depthwise convs are whole-row shifts, and every
+//   per-channel reduction (BatchNorm statistics, SE mean, attentive softmax over time)
+//   is a lane-local loop with fully coalesced 16-byte accesses.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TN_NREP 8          // replicated atomic accumulators per statistic (spreads same-address atomics)
+#define TN_WAVE 64
+
+typedef unsigned short bf16_t;   // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// ------------------------------------------------------------------------------------------
+// bf16 <-> f32
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  const uint32_t u = __float_as_uint(f);
+  // round-to-nearest-even; NaN stays NaN (quiet bit forced); branch-free
+  const uint32_t r = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+  const uint32_t n = (u >> 16) | 0x40u;
+  return (bf16_t)(((u & 0x7fffffffu) > 0x7f800000u) ? n : r);
+}
+
+template <typename AT> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int BK = 32;     // K elements staged per chunk
+  static constexpr int PAD = 1;     // LDS row padding (elements)
+  static constexpr int KM = 2;      // K per MFMA (v_mfma_f32_32x32x2_f32)
+  __device__ static __forceinline__ float to_f(float v) { return v; }
+  __device__ static __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int BK = 64;
+  static constexpr int PAD = 8;
+  static constexpr int KM = 16;     // v_mfma_f32_32x32x16_bf16
+  __device__ static __forceinline__ float to_f(bf16_t v) { return bf2f(v); }
+  __device__ static __forceinline__ bf16_t from_f(float v) { return f2bf(v); }
+};
+
+// 8 consecutive elements <-> 8 floats (global or LDS; p must be 16-byte aligned for bf16,
+// 16-byte aligned for float as two float4).
+__device__ __forceinline__ void load8(const float* p, float v[8]) {
+  float4 a = *reinterpret_cast<const float4*>(p);
+  float4 b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float v[8]) {
+  uint4 a = *reinterpret_cast<const uint4*>(p);
+  v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+  v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+  v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+  v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+__device__ __forceinline__ void store8(float* p, const float v[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float v[8]) {
+  uint4 a;
+  a.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  a.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  a.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+  a.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = a;
+}
+// LDS row writes: the float tiles use an odd row stride (bank-conflict-free ds_read_b32 for the
+// f32 MFMA fragments), so they are written element-wise; bf16 rows are 16-byte aligned.
+__device__ __forceinline__ void store8_lds(float* p, const float v[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = v[i];
+}
+__device__ __forceinline__ void store8_lds(bf16_t* p, const float v[8]) { store8(p, v); }
+__device__ __forceinline__ void load8_lds(const float* p, float v[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = p[i];
+}
+__device__ __forceinline__ void load8_lds(const bf16_t* p, float v[8]) { load8(p, v); }
+
+// ------------------------------------------------------------------------------------------
+// counter-based dropout (restated in numpy by oracle/rng.py for the parity tests)
+// ------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t tn_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t tn_layer_key(uint64_t seed, uint32_t layer) {
+  uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+  return tn_mix32(lo ^ tn_mix32(hi + layer * 0x9E3779B9u + 1u));
+}
+// keep bits for the element pair (e, e+1), e even: bit0 -> element e, bit1 -> element e+1
+__device__ __forceinline__ uint32_t tn_keep_pair(uint32_t pair_index, uint32_t key, uint32_t thr) {
+  uint32_t h = tn_mix32(pair_index + key);
+  return ((h & 0xffffu) >= thr ? 1u : 0u) | ((h >> 16) >= thr ? 2u : 0u);
+}
+
+// ------------------------------------------------------------------------------------------
+// "activation on load": how a consumer turns a stored RAW conv output into the tensor the
+// reference would have materialised: BatchNorm (batch or running statistics) -> ReLU ->
+// Dropout (reference src/modules.py:119-133).  Raw outputs are stored once; normalisation,
+// activation and the dropout mask are recomputed by every consumer (never materialised).
+// ------------------------------------------------------------------------------------------
+struct BnAct {
+  const float* stats;   // [TN_NREP][2][C]: sum, sum of squares over the M rows (train mode)
+  const float* gamma;   // [C]
+  const float* beta;    // [C]
+  const float* rmean;   // [C] running mean (eval mode)
+  const float* rvar;    // [C] running var  (eval mode)
+  float inv_n;          // 1 / rows
+  float eps;
+  int mode;             // 0 identity, 1 batch statistics, 2 running statistics
+  int relu;             // apply max(.,0)
+  uint32_t drop_thr;    // 0 = no dropout; else round(p * 65536)
+  uint32_t drop_key;    // tn_layer_key(seed, layer)
+  float inv_keep;       // 1 / (1 - p)
+};
+
+// per-channel (mean, rstd) from the replicated batch sums
+__device__ __forceinline__ void bn_mean_rstd(const BnAct& a, int C, int c, float& mean, float& rstd) {
+  if (a.mode == 1) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int r = 0; r < TN_NREP; ++r) { s += a.stats[(r * 2 + 0) * C + c]; q += a.stats[(r * 2 + 1) * C + c]; }
+    mean = s * a.inv_n;
+    float var = fmaxf(q * a.inv_n - mean * mean, 0.f);
+    rstd = rsqrtf(var + a.eps);
+  } else {
+    mean = a.rmean[c];
+    rstd = rsqrtf(a.rvar[c] + a.eps);
+  }
+}
+// scale/shift so that bn(x) = x*scale + shift
+__device__ __forceinline__ void bn_scale_shift(const BnAct& a, int C, int c, float& sc, float& sh) {
+  if (a.mode == 0) { sc = 1.f; sh = 0.f; return; }
+  float mean, rstd;
+  bn_mean_rstd(a, C, c, mean, rstd);
+  sc = a.gamma[c] * rstd;
+  sh = a.beta[c] - mean * sc;
+}
+
+// apply act to 8 consecutive channels of row `row` (element index = row*C + c0 + i)
+__device__ __forceinline__ void act8(float v[8], const float* sc, const float* sh, const BnAct& a,
+                                     uint32_t row, int C, int c0) {
+  if (a.mode != 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[i] + sh[i];
+  }
+  if (a.relu) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+  }
+  if (a.drop_thr) {
+    uint32_t pair = (row * (uint32_t)C + (uint32_t)c0) >> 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t k = tn_keep_pair(pair + i, a.drop_key, a.drop_thr);
+      v[2 * i] = (k & 1u) ? v[2 * i] * a.inv_keep : 0.f;
+      v[2 * i + 1] = (k & 2u) ? v[2 * i + 1] * a.inv_keep : 0.f;
+    }
+  }
+}
+// mask-only variant for the backward pass: given the raw value's post-BN sign and the keep
+// bits, returns the multiplier d(act)/d(bn output) for each of the 8 channels.
+__device__ __forceinline__ void act8_grad_mask(const float raw[8], float m[8], const float* sc, const float* sh,
+                                               const BnAct& a, uint32_t row, int C, int c0) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float z = (a.mode != 0) ? raw[i] * sc[i] + sh[i] : raw[i];
+    m[i] = (!a.relu || z > 0.f) ? 1.f : 0.f;
+  }
+  if (a.drop_thr) {
+    uint32_t pair = (row * (uint32_t)C + (uint32_t)c0) >> 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t k = tn_keep_pair(pair + i, a.drop_key, a.drop_thr);
+      m[2 * i] = (k & 1u) ? m[2 * i] * a.inv_keep : 0.f;
+      m[2 * i + 1] = (k & 2u) ? m[2 * i + 1] * a.inv_keep : 0.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// wave / block reductions
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+  // hardware global_atomic_add_f32 (built with -munsafe-fp-atomics), no return value
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#define TN_CHECK_HIP(expr)                          \
+  do {                                              \
+    hipError_t _e = (expr);                         \
+    if (_e != hipSuccess) return (int)_e;           \
+  } while (0)

@@ -1,0 +1,434 @@
+// titanet_amd — forward-pass kernels that are not GEMMs: SE squeeze + gate, residual combine,
+// attentive-statistics pooling, decoder tail, loss heads, BatchNorm running-statistics update and the
+// per-step weight cast/transposition.  All tensors are "rows x channels" (see tn_common.h).
+#pragma once
+#include "tn_common.h"
+
+// ------------------------------------------------------------------------------------------
+// per-step weight preparation: fp32 master -> compute-precision copy and its transpose
+// ------------------------------------------------------------------------------------------
+struct CastDesc {
+  const float* src;   // [R][C] fp32 master
+  void* dst;          // [R][C] AT or null
+  void* dstT;         // [C][R] AT or null
+  int R, C;
+};
+
+template <typename AT>
+__global__ void cast_params_kernel(const CastDesc* descs) {
+  const CastDesc d = descs[blockIdx.y];
+  const int n = d.R * d.C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float v = d.src[i];
+    if (d.dst) reinterpret_cast<AT*>(d.dst)[i] = Elem<AT>::from_f(v);
+    if (d.dstT) {
+      const int r = i / d.C, c = i % d.C;
+      reinterpret_cast<AT*>(d.dstT)[(size_t)c * d.R + r] = Elem<AT>::from_f(v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Squeeze-and-Excitation: m = mean_T act(Y3); h = relu(W1 m); g = sigmoid(W2 h)
+// (reference src/modules.py:173-189).  One workgroup per utterance.
+// ------------------------------------------------------------------------------------------
+template <typename AT>
+__global__ __launch_bounds__(512) void se_squeeze_fc_kernel(const AT* __restrict__ Y, BnAct act, int T, int C, int Hr,
+                                                            const float* __restrict__ W1, const float* __restrict__ W2,
+                                                            float* __restrict__ m_out, float* __restrict__ h_out,
+                                                            float* __restrict__ g_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sc = reinterpret_cast<float*>(smem);
+  float* sh = sc + C;
+  float* mean = sh + C;
+  float* hbuf = mean + C;          // [Hr]
+  float* part = hbuf + ((Hr + 3) & ~3);   // [TG][C]
+  const int tid = threadIdx.x, NT = blockDim.x, b = blockIdx.x;
+  const int CV = C / 8, TG = NT / CV;
+  if (act.mode != 0)
+    for (int c = tid; c < C; c += NT) bn_scale_shift(act, C, c, sc[c], sh[c]);
+  __syncthreads();
+  const int vc = tid % CV, tg = tid / CV;
+  if (tg < TG) {
+    float s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = 0.f;
+    for (int t = tg; t < T; t += TG) {
+      const uint32_t row = (uint32_t)b * T + t;
+      float v[8];
+      load8(Y + (size_t)row * C + vc * 8, v);
+      act8(v, sc + vc * 8, sh + vc * 8, act, row, C, vc * 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] += v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part[tg * C + vc * 8 + i] = s[i];
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += NT) {
+    float s = 0.f;
+    for (int k = 0; k < TG; ++k) s += part[k * C + c];
+    s *= (1.f / (float)T);
+    mean[c] = s;
+    m_out[(size_t)b * C + c] = s;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, NW = NT >> 6;
+  for (int j = wave; j < Hr; j += NW) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += W1[(size_t)j * C + c] * mean[c];
+    s = wave_sum(s);
+    if (lane == 0) {
+      s = fmaxf(s, 0.f);
+      hbuf[j] = s;
+      h_out[(size_t)b * Hr + j] = s;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += NT) {
+    float s = 0.f;
+    for (int j = 0; j < Hr; ++j) s += W2[(size_t)c * Hr + j] * hbuf[j];
+    g_out[(size_t)b * C + c] = 1.f / (1.f + __expf(-s));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Mega-block tail: OUT = dropout(relu(BN(S) + g * act3(Y3)))   (reference src/models.py:467-472)
+// ------------------------------------------------------------------------------------------
+template <typename AT>
+__global__ __launch_bounds__(256) void combine_fwd_kernel(const AT* __restrict__ S, BnAct actS,
+                                                          const AT* __restrict__ Y3, BnAct act3,
+                                                          const float* __restrict__ gate, AT* __restrict__ OUT, int M,
+                                                          int T, int C, int rows_per_block, uint32_t drop_thr,
+                                                          uint32_t drop_key, float inv_keep) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* scS = reinterpret_cast<float*>(smem);
+  float* shS = scS + C;
+  float* sc3 = shS + C;
+  float* sh3 = sc3 + C;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  for (int c = tid; c < C; c += NT) {
+    bn_scale_shift(actS, C, c, scS[c], shS[c]);
+    bn_scale_shift(act3, C, c, sc3[c], sh3[c]);
+  }
+  __syncthreads();
+  const int CV = C / 8;
+  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_end = min(M, r_begin + rows_per_block);
+  for (int i = tid; i < (r_end - r_begin) * CV; i += NT) {
+    const int row = r_begin + i / CV, c0 = (i % CV) * 8;
+    const int b = row / T;
+    float s[8], y[8], g[8], o[8];
+    load8(S + (size_t)row * C + c0, s);
+    load8(Y3 + (size_t)row * C + c0, y);
+    load8(gate + (size_t)b * C + c0, g);
+    act8(y, sc3 + c0, sh3 + c0, act3, (uint32_t)row, C, c0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = fmaxf(s[q] * scS[c0 + q] + shS[c0 + q] + g[q] * y[q], 0.f);
+    if (drop_thr) {
+      const uint32_t pair = ((uint32_t)row * (uint32_t)C + (uint32_t)c0) >> 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t k = tn_keep_pair(pair + q, drop_key, drop_thr);
+        o[2 * q] = (k & 1u) ? o[2 * q] * inv_keep : 0.f;
+        o[2 * q + 1] = (k & 2u) ? o[2 * q + 1] * inv_keep : 0.f;
+      }
+    }
+    store8(OUT + (size_t)row * C + c0, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Attentive statistics pooling, second half (reference src/models.py:569-584): per (utterance,
+// channel) online softmax over time of the energies, weighted mean and std of x = act(E).
+// Lane-local over time (channels-last layout): no cross-lane reduction inside the loop.
+//   pooled[b][c] = mean, pooled[b][D + c] = std; saves softmax max / 1/sum and q = sum alpha x^2.
+// Also accumulates the BatchNorm1d(2D) batch statistics (reference src/models.py:506).
+// ------------------------------------------------------------------------------------------
+template <typename AT>
+__global__ __launch_bounds__(256) void asp_pool_fwd_kernel(const AT* __restrict__ E, BnAct actE,
+                                                           const AT* __restrict__ EN, int T, int D, float eps,
+                                                           float* __restrict__ pooled, float* __restrict__ smax,
+                                                           float* __restrict__ sinv, float* __restrict__ qout,
+                                                           float* __restrict__ stats) {
+  constexpr int CVB = 64, TG = 4;   // 64 channel-vectors (512 channels) x 4 time groups per block
+  __shared__ float red[TG][4][CVB * 8];
+  __shared__ float scs[CVB * 8], shs[CVB * 8];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int cbase = blockIdx.y * CVB * 8;
+  for (int c = tid; c < CVB * 8; c += 256) {
+    float sc = 1.f, sh = 0.f;
+    if (cbase + c < D) bn_scale_shift(actE, D, cbase + c, sc, sh);
+    scs[c] = sc; shs[c] = sh;
+  }
+  __syncthreads();
+  const int vc = tid % CVB, tg = tid / CVB;
+  const int c0 = cbase + vc * 8;
+  float m[8], l[8], s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { m[i] = -INFINITY; l[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
+  if (c0 < D) {
+    for (int t = tg; t < T; t += TG) {
+      const uint32_t row = (uint32_t)b * T + t;
+      float x[8], e[8];
+      load8(E + (size_t)row * D + c0, x);
+      load8(EN + (size_t)row * D + c0, e);
+      act8(x, scs + vc * 8, shs + vc * 8, actE, row, D, c0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float mn = fmaxf(m[i], e[i]);
+        const float r = __expf(m[i] - mn);      // exp(-inf) = 0 on the first step
+        const float p = __expf(e[i] - mn);
+        l[i] = l[i] * r + p;
+        s1[i] = s1[i] * r + p * x[i];
+        s2[i] = s2[i] * r + p * x[i] * x[i];
+        m[i] = mn;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    red[tg][0][vc * 8 + i] = m[i];
+    red[tg][1][vc * 8 + i] = l[i];
+    red[tg][2][vc * 8 + i] = s1[i];
+    red[tg][3][vc * 8 + i] = s2[i];
+  }
+  __syncthreads();
+  for (int c = tid; c < CVB * 8; c += 256) {
+    const int cg = cbase + c;
+    if (cg >= D) continue;
+    float M = -INFINITY;
+    for (int k = 0; k < TG; ++k) M = fmaxf(M, red[k][0][c]);
+    float L = 0.f, S1 = 0.f, S2 = 0.f;
+    for (int k = 0; k < TG; ++k) {
+      const float r = __expf(red[k][0][c] - M);
+      L += red[k][1][c] * r; S1 += red[k][2][c] * r; S2 += red[k][3][c] * r;
+    }
+    const float inv = 1.f / L;
+    const float mu = S1 * inv, q = S2 * inv;
+    const float sd = sqrtf(fmaxf(q - mu * mu, eps));
+    pooled[(size_t)b * 2 * D + cg] = mu;
+    pooled[(size_t)b * 2 * D + D + cg] = sd;
+    smax[(size_t)b * D + cg] = M;
+    sinv[(size_t)b * D + cg] = inv;
+    qout[(size_t)b * D + cg] = q;
+    if (stats) {
+      const int rep = b % TN_NREP;
+      atomic_add_f32(&stats[(size_t)(rep * 2 + 0) * 2 * D + cg], mu);
+      atomic_add_f32(&stats[(size_t)(rep * 2 + 1) * 2 * D + cg], mu * mu);
+      atomic_add_f32(&stats[(size_t)(rep * 2 + 0) * 2 * D + D + cg], sd);
+      atomic_add_f32(&stats[(size_t)(rep * 2 + 1) * 2 * D + D + cg], sd * sd);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Decoder tail: lin = Linear(BN(pooled))  (reference src/models.py:506-511).  One workgroup per
+// utterance; the K = 2D reduction is split over lanes with coalesced float4 weight reads.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tail_linear_fwd_kernel(const float* __restrict__ pooled, BnAct actP, int K, int E,
+                                                              const float* __restrict__ W, const float* __restrict__ bias,
+                                                              float* __restrict__ lin, float* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* p = reinterpret_cast<float*>(smem);   // [K]
+  const int tid = threadIdx.x, b = blockIdx.x;
+  for (int k = tid; k < K; k += 256) {
+    float sc, sh;
+    bn_scale_shift(actP, K, k, sc, sh);
+    p[k] = pooled[(size_t)b * K + k] * sc + sh;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int e = wave; e < E; e += 4) {
+    const float* w = W + (size_t)e * K;
+    float s = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+      const float4 wv = *reinterpret_cast<const float4*>(w + k);
+      s += wv.x * p[k] + wv.y * p[k + 1] + wv.z * p[k + 2] + wv.w * p[k + 3];
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+      s += bias[e];
+      lin[(size_t)b * E + e] = s;
+      if (stats) {
+        const int rep = b % TN_NREP;
+        atomic_add_f32(&stats[(size_t)(rep * 2 + 0) * E + e], s);
+        atomic_add_f32(&stats[(size_t)(rep * 2 + 1) * E + e], s * s);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Loss heads.  emb = BN(lin) (reference src/models.py:512-513); then
+//   loss_type 0: inference, out = F.normalize(emb)                       (src/models.py:333)
+//   loss_type 1: CELoss                                                  (src/losses.py:32-44)
+//   loss_type 2: AngularMarginLoss (ArcFace/CosFace/SphereFace by m1,m2,m3) (src/losses.py:77-132)
+// One workgroup per utterance.  Writes d(loss)/d(fc output) (already divided by B) for the
+// backward pass, and for margin losses d(loss)/d(scale) when scale = ||x||.
+// ------------------------------------------------------------------------------------------
+struct HeadArgs {
+  const float* lin;      // [B][E]
+  BnAct actL;
+  int B, E, NC;
+  int loss_type;
+  const float* W;        // [NC][E]
+  const float* bias;     // [NC] (CE) or null
+  const int64_t* targets;
+  float scale; int has_scale; float m1, m2, m3, eps;
+  float* emb;            // [B][E] pre-normalisation embeddings
+  float* emb_norm;       // [B][E] output: normalised embeddings
+  int64_t* preds;        // [B]
+  float* loss;           // scalar, pre-zeroed; accumulates mean
+  float* dlogits;        // [B][NC]
+  float* dscale;         // [B]
+  float* logits;         // [B][NC] or null (CE logits / clamped cosines, for tests)
+};
+
+__global__ __launch_bounds__(256) void row_normalize_kernel(float* W, int R, int C) {
+  // fc.weight.data = F.normalize(fc.weight.data, p=2, dim=1)  (reference src/losses.py:86) — in place
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) { const float v = W[(size_t)r * C + c]; s += v * v; }
+  s = wave_sum(s);
+  const float inv = 1.f / fmaxf(sqrtf(s), 1e-12f);
+  for (int c = lane; c < C; c += 64) W[(size_t)r * C + c] *= inv;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* x = reinterpret_cast<float*>(smem);   // [E] embedding (CE) or normalised embedding (margin)
+  float* lg = x + a.E;                           // [NC]
+  __shared__ float red[4];
+  __shared__ float redv[4];
+  __shared__ int redi[4];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  float ss = 0.f;
+  for (int e = tid; e < a.E; e += 256) {
+    float sc, sh;
+    bn_scale_shift(a.actL, a.E, e, sc, sh);
+    const float v = a.lin[(size_t)b * a.E + e] * sc + sh;
+    x[e] = v;
+    a.emb[(size_t)b * a.E + e] = v;
+    ss += v * v;
+  }
+  ss = block_sum_256(ss, red);
+  const float norm = sqrtf(ss);
+  if (a.loss_type == 2) {
+    // normalized_inputs = inputs / ||inputs||  (no epsilon: src/losses.py:89-92)
+    const float inv = 1.f / norm;
+    for (int e = tid; e < a.E; e += 256) { const float v = x[e] * inv; x[e] = v; a.emb_norm[(size_t)b * a.E + e] = v; }
+  } else {
+    const float inv = 1.f / fmaxf(norm, 1e-12f);
+    for (int e = tid; e < a.E; e += 256) a.emb_norm[(size_t)b * a.E + e] = x[e] * inv;
+  }
+  if (a.loss_type == 0) return;
+  __syncthreads();
+  const int y = (int)a.targets[b];
+  // logits / cosines
+  float vmax = -INFINITY; int imax = 0x7fffffff;
+  for (int c = tid; c < a.NC; c += 256) {
+    const float* w = a.W + (size_t)c * a.E;
+    float s = 0.f;
+    for (int e = 0; e < a.E; ++e) s = fmaf(w[e], x[e], s);
+    if (a.loss_type == 1) s += a.bias[c];
+    else s = fminf(fmaxf(s, -1.f), 1.f);
+    lg[c] = s;
+    if (a.logits) a.logits[(size_t)b * a.NC + c] = s;
+    if (s > vmax) { vmax = s; imax = c; }
+  }
+  // block argmax (first index wins ties) and max
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(vmax, o, 64);
+    const int oi = __shfl_xor(imax, o, 64);
+    if (ov > vmax || (ov == vmax && oi < imax)) { vmax = ov; imax = oi; }
+  }
+  if ((tid & 63) == 0) { redv[tid >> 6] = vmax; redi[tid >> 6] = imax; }
+  __syncthreads();
+  vmax = redv[0]; imax = redi[0];
+  for (int w = 1; w < 4; ++w)
+    if (redv[w] > vmax || (redv[w] == vmax && redi[w] < imax)) { vmax = redv[w]; imax = redi[w]; }
+  if (tid == 0) a.preds[b] = imax;
+  const float invB = 1.f / (float)a.B;
+  if (a.loss_type == 1) {
+    float se = 0.f;
+    for (int c = tid; c < a.NC; c += 256) se += __expf(lg[c] - vmax);
+    se = block_sum_256(se, red);
+    const float lse = vmax + logf(se);
+    for (int c = tid; c < a.NC; c += 256) {
+      const float p = __expf(lg[c] - lse);
+      a.dlogits[(size_t)b * a.NC + c] = (p - (c == y ? 1.f : 0.f)) * invB;
+    }
+    if (tid == 0) atomic_add_f32(a.loss, (lse - lg[y]) * invB);
+  } else {
+    const float s = a.has_scale ? a.scale : norm;
+    const float cy = lg[y];
+    const float theta = acosf(cy);
+    const float ang = a.m1 * theta + a.m2;
+    const float num = s * (cosf(ang) - a.m3);
+    float others = 0.f;
+    for (int c = tid; c < a.NC; c += 256)
+      if (c != y) others += expf(s * lg[c]);     // unstabilised exp, as the reference (src/losses.py:127)
+    others = block_sum_256(others, red);
+    const float den = expf(num) + others;
+    const float dene = den + a.eps;
+    const float dnum = -1.f + expf(num) / dene;
+    float dsc = dnum * (cosf(ang) - a.m3);        // d loss / d scale (used only when scale = ||x||)
+    float dsacc = 0.f;
+    for (int c = tid; c < a.NC; c += 256) {
+      float d;
+      if (c == y) {
+        const float sq = sqrtf(fmaxf(1.f - cy * cy, 0.f));
+        d = dnum * s * a.m1 * sinf(ang) / sq;
+      } else {
+        const float p = expf(s * lg[c]) / dene;
+        d = p * s;
+        dsacc += p * lg[c];
+      }
+      a.dlogits[(size_t)b * a.NC + c] = d * invB;
+    }
+    dsacc = block_sum_256(dsacc, red);
+    if (tid == 0) {
+      a.dscale[b] = a.has_scale ? 0.f : (dsc + dsacc) * invB;
+      atomic_add_f32(a.loss, -(num - logf(dene)) * invB);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm running statistics (train mode): running = (1-m) running + m batch, unbiased var
+// (nn.BatchNorm1d; reference src/modules.py:128).  One launch for every BN layer of the model.
+// ------------------------------------------------------------------------------------------
+struct BnUpdateDesc {
+  const float* stats;   // [TN_NREP][2][C]
+  float* rmean;
+  float* rvar;
+  int C;
+  int n;                // rows reduced
+};
+
+__global__ void bn_running_update_kernel(const BnUpdateDesc* descs, float momentum, int64_t* nbt, int n_layers) {
+  const BnUpdateDesc d = descs[blockIdx.y];
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < d.C; c += gridDim.x * blockDim.x) {
+    float s = 0.f, q = 0.f;
+    for (int r = 0; r < TN_NREP; ++r) { s += d.stats[(r * 2 + 0) * d.C + c]; q += d.stats[(r * 2 + 1) * d.C + c]; }
+    const float inv = 1.f / (float)d.n;
+    const float mean = s * inv;
+    const float var = fmaxf(q * inv - mean * mean, 0.f);
+    const float unb = var * ((float)d.n / (float)max(d.n - 1, 1));
+    d.rmean[c] = (1.f - momentum) * d.rmean[c] + momentum * mean;
+    d.rvar[c] = (1.f - momentum) * d.rvar[c] + momentum * unb;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) nbt[blockIdx.y] += 1;
+}

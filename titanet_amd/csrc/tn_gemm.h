@@ -1,0 +1,391 @@
+// titanet_amd — generic "rows x channels" NT GEMM on MFMA with pluggable A-tile producers and
+// epilogues.  C[M x N] = A[M x K] * W[N x K]^T, where the A tile is *produced* into LDS by a functor
+// (activation-on-load, depthwise stencil, im2col, BatchNorm-backward-on-load ...) and never exists in
+// HBM, and the epilogue functor consumes the accumulators (bias, BN statistics, tanh, stores ...).
+//
+// One workgroup = WM x WN waves, each wave owns a 64 x 64 output sub-tile as 2 x 2 MFMA 32x32 tiles:
+//   bf16 path : v_mfma_f32_32x32x16_bf16   (8 K-elements per lane, ds_read_b128 fragments)
+//   fp32 path : v_mfma_f32_32x32x2_f32     (exact f32 == fmaf chain; the parity path)
+// Both share the C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#pragma once
+#include "tn_common.h"
+
+struct GemmShape {
+  int M, N, K;
+  const void* W;   // [N][K], element type AT, K contiguous
+};
+
+template <typename AT> struct Mma;
+template <> struct Mma<bf16_t> {
+  using Frag = bf16x8_t;
+  __device__ static __forceinline__ Frag load(const bf16_t* row, int ks, int half) {
+    return *reinterpret_cast<const bf16x8_t*>(row + ks * 16 + half * 8);
+  }
+  __device__ static __forceinline__ f32x16_t mma(Frag a, Frag b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  using Frag = float;
+  __device__ static __forceinline__ Frag load(const float* row, int ks, int half) { return row[ks * 2 + half]; }
+  __device__ static __forceinline__ f32x16_t mma(Frag a, Frag b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ int cd_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// Fill a [ROWS][BK] tile (row stride BKP) from a row-major global matrix src[nrows][ld], rows
+// row0.., columns kc..kc+BK, zero outside [0,nrows) x [0,kmax).  NT threads, 8-element vectors.
+template <typename AT, int ROWS, int NT>
+__device__ __forceinline__ void fill_tile_plain(AT* dst, const AT* __restrict__ src, int nrows, int ld, int kmax,
+                                                int row0, int kc, int tid) {
+  constexpr int BK = Elem<AT>::BK, BKP = BK + Elem<AT>::PAD, VC = BK / 8, RL = NT / VC;
+  const int vc = tid % VC, rl = tid / VC;
+  const int k = kc + vc * 8;
+  for (int r = rl; r < ROWS; r += RL) {
+    float v[8];
+    const int gr = row0 + r;
+    if (gr < nrows && gr >= 0 && k < kmax) load8(src + (size_t)gr * ld + k, v);
+    else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    }
+    store8_lds(dst + r * BKP + vc * 8, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------
+template <typename AT, int WM, int WN, typename Prod, typename Epi>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 4 : 3)) void gemm_nt_kernel(GemmShape g, typename Prod::Args pa,
+                                                               typename Epi::Args ea) {
+  constexpr int BM = WM * 64, BN = WN * 64, BK = Elem<AT>::BK, BKP = BK + Elem<AT>::PAD, NT = WM * WN * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  AT* As = reinterpret_cast<AT*>(smem);
+  AT* Bs = As + BM * BKP;
+  char* scratch = reinterpret_cast<char*>(Bs + BN * BKP);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+  Prod prod;
+  prod.template init<AT, BM, NT>(pa, g, scratch, tid, r0);   // ends with __syncthreads()
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const AT* W = reinterpret_cast<const AT*>(g.W);
+  for (int kc = 0; kc < g.K; kc += BK) {
+    fill_tile_plain<AT, BN, NT>(Bs, W, g.N, g.K, g.K, n0, kc, tid);
+    prod.template fill<AT, BM, NT>(As, pa, g, tid, r0, kc);   // result in As; may sync internally
+    __syncthreads();
+    const AT* arow0 = As + (wm * 64 + (lane & 31)) * BKP;
+    const AT* brow0 = Bs + (wn * 64 + (lane & 31)) * BKP;
+    const int half = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < BK / Elem<AT>::KM; ++ks) {
+      typename Mma<AT>::Frag a0 = Mma<AT>::load(arow0, ks, half);
+      typename Mma<AT>::Frag a1 = Mma<AT>::load(arow0 + 32 * BKP, ks, half);
+      typename Mma<AT>::Frag b0 = Mma<AT>::load(brow0, ks, half);
+      typename Mma<AT>::Frag b1 = Mma<AT>::load(brow0 + 32 * BKP, ks, half);
+      acc[0][0] = Mma<AT>::mma(a0, b0, acc[0][0]);
+      acc[0][1] = Mma<AT>::mma(a0, b1, acc[0][1]);
+      acc[1][0] = Mma<AT>::mma(a1, b0, acc[1][0]);
+      acc[1][1] = Mma<AT>::mma(a1, b1, acc[1][1]);
+    }
+    __syncthreads();
+  }
+  Epi::template run<AT, WM, WN>(acc, ea, g, smem, tid, r0, n0);
+}
+
+// LDS bytes needed by the main loop (without producer scratch)
+template <typename AT, int WM, int WN>
+constexpr size_t gemm_tile_bytes() {
+  return (size_t)(WM * 64 + WN * 64) * (Elem<AT>::BK + Elem<AT>::PAD) * sizeof(AT);
+}
+
+// ------------------------------------------------------------------------------------------
+// producers
+// ------------------------------------------------------------------------------------------
+// P_PLAIN: A[r][c] = act(X[r][c])
+struct ProdPlain {
+  struct Args {
+    const void* X;   // [M][ldx]
+    int ldx;
+    BnAct act;
+  };
+  float* sc;
+  float* sh;
+  static size_t scratch_bytes(int K, int /*KD*/, int /*BM*/, size_t /*elem*/) { return (size_t)2 * K * sizeof(float); }
+  template <typename AT, int BM, int NT>
+  __device__ __forceinline__ void init(const Args& a, const GemmShape& g, char* scratch, int tid, int /*r0*/) {
+    sc = reinterpret_cast<float*>(scratch);
+    sh = sc + g.K;
+    if (a.act.mode != 0) {
+      for (int c = tid; c < g.K; c += NT) bn_scale_shift(a.act, g.K, c, sc[c], sh[c]);
+    }
+    __syncthreads();
+  }
+  template <typename AT, int BM, int NT>
+  __device__ __forceinline__ void fill(AT* As, const Args& a, const GemmShape& g, int tid, int r0, int kc) {
+    constexpr int BK = Elem<AT>::BK, BKP = BK + Elem<AT>::PAD, VC = BK / 8, RL = NT / VC;
+    const int vc = tid % VC, rl = tid / VC;
+    const int k = kc + vc * 8;
+    const AT* X = reinterpret_cast<const AT*>(a.X);
+    for (int r = rl; r < BM; r += RL) {
+      float v[8];
+      const int gr = r0 + r;
+      if (gr < g.M && k < g.K) {
+        load8(X + (size_t)gr * a.ldx + k, v);
+        act8(v, sc + k, sh + k, a.act, (uint32_t)gr, g.K, k);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+      }
+      store8_lds(As + r * BKP + vc * 8, v);
+    }
+  }
+};
+
+// P_DW: A[r][c] = b_dw[c] + sum_j w_dw[c][j] * act(X)[r + j - pad][c]   (zero outside the utterance)
+// — the depthwise conv of reference src/modules.py:65-75 fused as the prologue of its pointwise GEMM.
+struct ProdDw {
+  struct Args {
+    const void* X;
+    int ldx;
+    BnAct act;
+    const float* wdw;   // [C][KD]  (reference weight [C,1,KD])
+    const float* bdw;   // [C]
+    int KD;
+    int T;              // frames per utterance
+  };
+  float* sc;
+  float* sh;
+  float* wd;    // [KD][BK]
+  float* bd;    // [BK]
+  char* xs;     // [(BM + KD - 1)][BK] AT
+  static size_t scratch_bytes(int K, int KD, int BM, size_t elem) {
+    size_t bk = (elem == 2) ? 64 : 32;
+    return (size_t)2 * K * sizeof(float) + (size_t)(KD + 1) * bk * sizeof(float) + (size_t)(BM + KD - 1) * bk * elem + 16;
+  }
+  template <typename AT, int BM, int NT>
+  __device__ __forceinline__ void init(const Args& a, const GemmShape& g, char* scratch, int tid, int /*r0*/) {
+    constexpr int BK = Elem<AT>::BK;
+    sc = reinterpret_cast<float*>(scratch);
+    sh = sc + g.K;
+    wd = sh + g.K;
+    bd = wd + a.KD * BK;
+    size_t off = (size_t)(2 * g.K + (a.KD + 1) * BK) * sizeof(float);
+    off = (off + 15) & ~(size_t)15;
+    xs = scratch + off;
+    if (a.act.mode != 0) {
+      for (int c = tid; c < g.K; c += NT) bn_scale_shift(a.act, g.K, c, sc[c], sh[c]);
+    }
+    __syncthreads();
+  }
+  template <typename AT, int BM, int NT>
+  __device__ __forceinline__ void fill(AT* As, const Args& a, const GemmShape& g, int tid, int r0, int kc) {
+    constexpr int BK = Elem<AT>::BK, BKP = BK + Elem<AT>::PAD, VC = BK / 8, RL = NT / VC;
+    const int vc = tid % VC, rl = tid / VC;
+    const int k = kc + vc * 8;
+    const int KD = a.KD, pad = (KD - 1) / 2;
+    const AT* X = reinterpret_cast<const AT*>(a.X);
+    AT* Xs = reinterpret_cast<AT*>(xs);
+    // stage the activated input rows (with halo) once
+    for (int i = rl; i < BM + KD - 1; i += RL) {
+      float v[8];
+      const int gr = r0 - pad + i;
+      if (gr >= 0 && gr < g.M && k < g.K) {
+        load8(X + (size_t)gr * a.ldx + k, v);
+        act8(v, sc + k, sh + k, a.act, (uint32_t)gr, g.K, k);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = 0.f;
+      }
+      store8(Xs + i * BK + vc * 8, v);
+    }
+    for (int i = tid; i < (KD + 1) * BK; i += NT) {
+      const int j = i / BK, c = i % BK;
+      float w = 0.f;
+      if (kc + c < g.K) w = (j < KD) ? a.wdw[(size_t)(kc + c) * KD + j] : a.bdw[kc + c];
+      wd[i] = w;   // row KD of wd == bd
+    }
+    __syncthreads();
+    // stencil over time
+    for (int r = rl; r < BM; r += RL) {
+      const int gr = r0 + r;
+      const int t = gr % a.T;
+      float o[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = bd[vc * 8 + q];
+      for (int j = 0; j < KD; ++j) {
+        const int tt = t + j - pad;
+        if (tt >= 0 && tt < a.T) {
+          float v[8];
+          load8(Xs + (r + j) * BK + vc * 8, v);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] = fmaf(wd[j * BK + vc * 8 + q], v[q], o[q]);
+        }
+      }
+      store8_lds(As + r * BKP + vc * 8, o);
+    }
+  }
+};
+
+// P_IM2COL (prolog): A[r][ci*KP + j] = x[b][ci][t + j - pad]; x is the float [B, n_mels, T] input of
+// TitaNet.forward (reference src/models.py:318-331, prolog conv :370).  K = n_mels * KP.
+struct ProdIm2col {
+  struct Args {
+    const float* x;   // [B][n_mels][T] float32, T contiguous (reference layout)
+    int n_mels, KP, T;
+  };
+  static size_t scratch_bytes(int, int, int, size_t) { return 16; }
+  template <typename AT, int BM, int NT>
+  __device__ __forceinline__ void init(const Args&, const GemmShape&, char*, int, int) { __syncthreads(); }
+  template <typename AT, int BM, int NT>
+  __device__ __forceinline__ void fill(AT* As, const Args& a, const GemmShape& g, int tid, int r0, int kc) {
+    constexpr int BK = Elem<AT>::BK, BKP = BK + Elem<AT>::PAD;
+    const int pad = (a.KP - 1) / 2;
+    // consecutive threads -> consecutive rows (t) for coalesced reads of the T-contiguous input
+    for (int i = tid; i < BM * BK; i += NT) {
+      const int r = i % BM, kk = i / BM;
+      const int gr = r0 + r, k = kc + kk;
+      float v = 0.f;
+      if (gr < g.M && k < g.K) {
+        const int b = gr / a.T, t = gr % a.T;
+        const int ci = k / a.KP, j = k % a.KP;
+        const int tt = t + j - pad;
+        if (tt >= 0 && tt < a.T) v = a.x[((size_t)b * a.n_mels + ci) * a.T + tt];
+      }
+      As[r * BKP + kk] = Elem<AT>::from_f(v);
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// epilogues
+// ------------------------------------------------------------------------------------------
+// y = acc + bias [-> tanh]; store as AT through LDS (coalesced 16-byte rows); optional per-column
+// sum / sum-of-squares of y over the valid rows -> replicated global atomics (BatchNorm statistics
+// accumulated in the producing kernel's epilogue, SURVEY.md §2 "native_batch_norm" row).
+struct EpiStoreArgs {
+  void* Y;             // [M][ldy] AT
+  int ldy;
+  const float* bias;   // [N] or null
+  float* stats;        // [TN_NREP][2][N] or null
+};
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __expf(2.f * x);       // inf for large x -> 1, 0 for very negative x -> -1
+  return 1.f - 2.f / (e + 1.f);
+}
+template <bool TANH>
+struct EpiStoreT {
+  using Args = EpiStoreArgs;
+  template <typename AT, int WM, int WN>
+  static constexpr size_t lds_bytes() {
+    return (size_t)64 * (WN * 64 + 8) * sizeof(AT) + (size_t)2 * WN * 64 * sizeof(float);
+  }
+  template <typename AT, int WM, int WN>
+  __device__ static __forceinline__ void run(f32x16_t (&acc)[2][2], const Args& e, const GemmShape& g, char* smem,
+                                             int tid, int r0, int n0) {
+    constexpr int BN = WN * 64, NT = WM * WN * 64, CSP = BN + 8;
+    AT* Cs = reinterpret_cast<AT*>(smem);
+    float* colsum = reinterpret_cast<float*>(smem + (size_t)64 * CSP * sizeof(AT));
+    const int lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
+    if (e.stats) {
+      for (int i = tid; i < 2 * BN; i += NT) colsum[i] = 0.f;
+    }
+    __syncthreads();
+    // bias (+tanh) and statistics in registers
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n = wn * 64 + nt * 32 + (lane & 31);
+      const float b = (e.bias && n0 + n < g.N) ? e.bias[n0 + n] : 0.f;
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float y = acc[mt][nt][r] + b;
+          if (TANH) y = fast_tanh(y);
+          acc[mt][nt][r] = y;
+          const int row = r0 + wm * 64 + mt * 32 + cd_row(r, lane);
+          if (row < g.M) { s += y; q += y * y; }
+        }
+      }
+      if (e.stats) {
+        s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (lane < 32) {
+          atomicAdd(&colsum[n], s);
+          atomicAdd(&colsum[BN + n], q);
+        }
+      }
+    }
+    AT* Y = reinterpret_cast<AT*>(e.Y);
+    for (int pass = 0; pass < WM; ++pass) {
+      __syncthreads();
+      if (wm == pass) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              Cs[(mt * 32 + cd_row(r, lane)) * CSP + wn * 64 + nt * 32 + (lane & 31)] = Elem<AT>::from_f(acc[mt][nt][r]);
+      }
+      __syncthreads();
+      constexpr int VCN = BN / 8, RL = NT / VCN;
+      const int vc = tid % VCN, rl = tid / VCN;
+      for (int r = rl; r < 64; r += RL) {
+        const int row = r0 + pass * 64 + r, n = n0 + vc * 8;
+        if (row < g.M && n < g.N) {
+          const uint4* src = reinterpret_cast<const uint4*>(Cs + r * CSP + vc * 8);
+          uint4* dst = reinterpret_cast<uint4*>(Y + (size_t)row * e.ldy + n);
+          dst[0] = src[0];
+          if (sizeof(AT) == 4) dst[1] = src[1];
+        }
+      }
+    }
+    if (e.stats) {
+      // colsum complete: all LDS atomics happened before the first pass barrier
+      const int rep = blockIdx.x % TN_NREP;
+      for (int i = tid; i < 2 * BN; i += NT) {
+        const int which = i / BN, n = i % BN;
+        if (n0 + n < g.N) atomic_add_f32(&e.stats[(size_t)(rep * 2 + which) * g.N + n0 + n], colsum[i]);
+      }
+    }
+  }
+};
+
+using EpiStore = EpiStoreT<false>;
+using EpiStoreTanh = EpiStoreT<true>;
+
+// ------------------------------------------------------------------------------------------
+// host-side launcher
+// ------------------------------------------------------------------------------------------
+template <typename AT, int WM, int WN, typename Prod, typename Epi>
+inline int launch_gemm(const GemmShape& g, const typename Prod::Args& pa, const typename Epi::Args& ea, int KD,
+                       hipStream_t stream) {
+  constexpr int BM = WM * 64, BN = WN * 64;
+  size_t main_bytes = gemm_tile_bytes<AT, WM, WN>() + Prod::scratch_bytes(g.K, KD, BM, sizeof(AT));
+  size_t epi_bytes = Epi::template lds_bytes<AT, WM, WN>();
+  size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+  smem = (smem + 15) & ~(size_t)15;
+  auto kern = gemm_nt_kernel<AT, WM, WN, Prod, Epi>;
+  if (smem > 64 * 1024) {
+    TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)smem));
+  }
+  dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN);
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, g, pa, ea);
+  return (int)hipGetLastError();
+}

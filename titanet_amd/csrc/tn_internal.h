@@ -1,0 +1,121 @@
+// titanet_amd — host-side model layout and execution plan (internal).
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/titanet_amd.h"
+#include "tn_common.h"
+
+struct TensorInfo {
+  std::string name;
+  int kind;
+  int64_t offset, numel;
+  int ndim;
+  int64_t shape[4];
+};
+
+struct BnRef {
+  int id = -1;      // index into the BN tables (statistics, nbt)
+  int C = 0;
+  int64_t gamma = 0, beta = 0;    // offsets into params
+  int64_t rmean = 0, rvar = 0;    // offsets into bnbuf
+};
+
+struct SubBlockRef {
+  int64_t wdw, bdw, wpw, bpw;
+  BnRef bn;
+};
+
+struct MegaBlockRef {
+  std::vector<SubBlockRef> sub;
+  int64_t se_w1, se_w2;
+  int64_t wskip, bskip;
+  BnRef bnskip;
+};
+
+struct tn_model {
+  tn_config cfg;
+  std::vector<TensorInfo> tensors;
+  int64_t n_params = 0, n_buffers = 0;
+  int n_bn = 0;
+  int64_t prolog_w, prolog_b;
+  BnRef prolog_bn;
+  std::vector<MegaBlockRef> blocks;
+  int64_t epi_w, epi_b;
+  BnRef epi_bn;
+  int64_t asp_win, asp_bin, asp_wout, asp_bout;
+  BnRef pool_bn;
+  int64_t lin_w, lin_b;
+  BnRef lin_bn;
+  int64_t fc_w = -1, fc_b = -1;
+  std::vector<BnRef> all_bn;   // by id
+};
+
+// compute-precision weight copies (offsets in BYTES into the workspace)
+struct WcRef {
+  size_t w = 0;    // [N][K]
+  size_t wt = 0;   // [K][N]
+};
+
+struct BlockWs {
+  std::vector<size_t> Y;   // raw sub-block outputs
+  size_t S, OUT;
+  size_t m, h, g;          // SE: mean [B][C], hidden [B][Hr], gate [B][C]  (float)
+  std::vector<WcRef> wpw;
+  WcRef wskip;
+  // backward (float): SE pre-activation grads
+  size_t dpre2, dpre1;
+};
+
+struct tn_plan {
+  const tn_model* model;
+  int B, T, M, prec;
+  size_t esz;               // activation element size
+  size_t ws_bytes = 0;
+  // bound buffers
+  float* params = nullptr;
+  float* grads = nullptr;
+  float* bnbuf = nullptr;
+  int64_t* nbt = nullptr;
+  char* ws = nullptr;
+  bool bound = false;
+  // workspace layout (byte offsets)
+  size_t zero_begin, zero_bytes;        // region cleared at the start of every step
+  std::vector<size_t> stats;            // per BN id: forward sums  float[NREP][2][C]
+  std::vector<size_t> bsums;            // per BN id: backward sums float[NREP][2][C]
+  size_t loss_acc;
+  size_t Y0;
+  std::vector<BlockWs> blk;
+  size_t E, HID, EN, pooled, smax, sinv, qv, lin, emb, emb_norm, dlogits, dscale, logits, preds;
+  WcRef wprolog, wepi, wwin, wwout;
+  size_t cast_table, bn_table;
+  int n_cast = 0;
+  // backward scratch
+  size_t dA[2];        // ping-pong grad wrt block outputs (rows x hidden, AT)
+  size_t dYbn;         // rows x hidden AT
+  size_t dD;           // rows x hidden AT
+  size_t dZ;           // rows x hidden AT
+  size_t dXs;          // rows x hidden AT (skip dgrad)
+  size_t dE;           // rows x enc_out AT  (d energies)
+  size_t dEbn;         // rows x enc_out AT
+  size_t dHP;          // rows x attn AT
+  size_t dpooled, dlin, demb;   // float
+  size_t slabs;        // split-K partial weight gradients
+  size_t slab_bytes = 0;
+  size_t bwd_table;
+  // state
+  int last_training = -1;
+  int last_has_loss = 0;
+  uint64_t last_seed = 0;
+};
+
+int plan_forward(tn_plan* p, const float* spec, const int64_t* speakers, int training, uint64_t seed, float* emb_out,
+                 int64_t* preds, float* loss, hipStream_t st);
+int plan_backward(tn_plan* p, float grad_scale, const float* grad_scale_dev, const float* grad_emb, float* grad_input,
+                  hipStream_t st);
+
+// helpers shared by forward / backward orchestration
+BnAct make_act(const tn_plan* p, const BnRef& bn, int rows, int training, int relu, float drop_p, uint64_t seed,
+               int layer);
+BnAct identity_act();
