@@ -228,7 +228,10 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   }
   p->cast_table = b.take(sizeof(CastDesc) * (8 + (size_t)c.n_mega_blocks * (c.n_sub_blocks + 1)));
   p->bn_table = b.take(sizeof(BnUpdateDesc) * m->n_bn);
-  p->bwd_table = b.take(4096);
+  p->bwd_table_bytes = (size_t)m->n_bn * 128;   // >= sizeof(BnGradDesc) each (checked at upload)
+  p->bwd_table = b.take(p->bwd_table_bytes);
+  p->bwd_table_eval = b.take(p->bwd_table_bytes);
+  p->se_table = b.take((size_t)(c.n_mega_blocks + 1) * 64);
   p->ws_bytes = (b.off + 255) & ~(size_t)255;
   *out = p;
   return 0;
@@ -278,6 +281,8 @@ extern "C" int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbu
   }
   TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->bn_table, bd.data(), bd.size() * sizeof(BnUpdateDesc), hipMemcpyHostToDevice, st));
   TN_CHECK_HIP(hipStreamSynchronize(st));   // host vectors go out of scope
+  int rc = plan_upload_bwd_tables(p, st);
+  if (rc) return rc;
   p->bound = true;
   return 0;
 }
@@ -456,6 +461,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
                        0.1f, p->nbt, m->n_bn);
   }
   p->last_training = training;
+  p->last_input = spec;
   p->last_has_loss = speakers != nullptr;
   p->last_seed = seed;
   return (int)hipGetLastError();

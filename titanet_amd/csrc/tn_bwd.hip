@@ -1,3 +1,318 @@
-// placeholder until the backward kernels land
+// titanet_amd — backward orchestration: loss.backward() through the whole network as one call.
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "tn_bwd_kernels.h"
 #include "tn_internal.h"
-int plan_backward(tn_plan*, float, const float*, const float*, float*, hipStream_t) { return TN_E_UNSUPPORTED; }
+
+namespace {
+
+BnBwd make_bnbwd(const tn_plan* p, const BnRef& bn, int rows, int training) {
+  BnBwd b;
+  memset(&b, 0, sizeof(b));
+  b.fstats = (const float*)(p->ws + p->stats[bn.id]);
+  b.bsums = (const float*)(p->ws + p->bsums[bn.id]);
+  b.gamma = p->params + bn.gamma;
+  b.rmean = p->bnbuf + bn.rmean;
+  b.rvar = p->bnbuf + bn.rvar;
+  b.inv_n = 1.f / (float)rows;
+  b.eps = 1e-5f;
+  b.mode = training ? 1 : 2;
+  return b;
+}
+
+template <typename AT, typename Prod, typename Epi>
+int gemm_any(const GemmShape& g, const typename Prod::Args& pa, const typename Epi::Args& ea, hipStream_t st) {
+  if (g.N > 128) return launch_gemm<AT, 2, 4, Prod, Epi>(g, pa, ea, 0, st);
+  return launch_gemm<AT, 2, 2, Prod, Epi>(g, pa, ea, 0, st);
+}
+
+template <typename AT>
+int launch_dw_bwd(const DwBwdArgs& a, int KD, hipStream_t st) {
+  DwBwdArgs args = a;
+  const int row_tiles = (a.M + 63) / 64;
+  args.tiles_per_wg = std::max(1, std::min(8, row_tiles / 128));
+  dim3 grid((row_tiles + args.tiles_per_wg - 1) / args.tiles_per_wg, (a.C + 63) / 64);
+  switch (KD) {
+#define TN_DW_CASE(K) \
+  case K: hipLaunchKernelGGL((dw_bwd_kernel<AT, K>), grid, dim3(256), 0, st, args); break;
+    TN_DW_CASE(1) TN_DW_CASE(3) TN_DW_CASE(5) TN_DW_CASE(7) TN_DW_CASE(9) TN_DW_CASE(11) TN_DW_CASE(13) TN_DW_CASE(15)
+#undef TN_DW_CASE
+    default: return TN_E_UNSUPPORTED;
+  }
+  return (int)hipGetLastError();
+}
+
+template <typename AT>
+int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb, float* grad_input, hipStream_t st) {
+  const tn_model* m = p->model;
+  const tn_config& c = m->cfg;
+  const int M = p->M, H = c.hidden, D = c.enc_out, A = c.attn_hidden, Hr = c.hidden / c.se_reduction, T = p->T, B = p->B;
+  const int training = p->last_training;
+  const uint64_t seed = p->last_seed;
+  const float pd = c.dropout;
+  char* ws = p->ws;
+  float* params = p->params;
+  float* grads = p->grads;
+  float* slabs = (float*)(ws + p->slabs);
+  const int nsub = c.n_sub_blocks;
+  auto bsum = [&](const BnRef& bn) -> float* { return (float*)(ws + p->bsums[bn.id]); };
+  auto wt = [&](const WcRef& r) -> const void* { return ws + r.wt; };
+
+  TN_CHECK_HIP(hipMemsetAsync(grads, 0, (size_t)m->n_params * sizeof(float), st));
+
+  // ================= loss head -> d emb =================
+  {
+    HeadBwdArgs ha;
+    memset(&ha, 0, sizeof(ha));
+    ha.B = B; ha.E = c.emb; ha.NC = c.n_classes;
+    ha.loss_type = p->last_has_loss ? c.loss_type : TN_LOSS_NONE;
+    ha.dlogits = (const float*)(ws + p->dlogits);
+    ha.dscale = (const float*)(ws + p->dscale);
+    ha.emb = (const float*)(ws + p->emb);
+    ha.emb_norm = (const float*)(ws + p->emb_norm);
+    ha.W = m->fc_w >= 0 ? params + m->fc_w : nullptr;
+    ha.gs = gs; ha.gs_dev = gs_dev; ha.g_embnorm = g_emb;
+    ha.g_W = m->fc_w >= 0 ? grads + m->fc_w : nullptr;
+    ha.g_bias = m->fc_b >= 0 ? grads + m->fc_b : nullptr;
+    ha.demb = (float*)(ws + p->demb);
+    if (ha.loss_type != TN_LOSS_NONE) {
+      const int n = c.n_classes * c.emb;
+      hipLaunchKernelGGL(head_bwd_w_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ha);
+    }
+    hipLaunchKernelGGL(head_bwd_x_kernel, dim3(B), dim3(256), (size_t)c.emb * sizeof(float), st, ha);
+  }
+  // ================= decoder tail =================
+  {
+    BnAct actL = make_act(p, m->lin_bn, B, training, 0, 0.f, seed, 0);
+    BnAct actP = make_act(p, m->pool_bn, B, training, 0, 0.f, seed, 0);
+    const float* demb = (const float*)(ws + p->demb);
+    float* dlin = (float*)(ws + p->dlin);
+    float* dpool = (float*)(ws + p->dpooled);
+    const float* lin = (const float*)(ws + p->lin);
+    const float* pooled = (const float*)(ws + p->pooled);
+    const int K2 = 2 * D;
+    hipLaunchKernelGGL(rows_bn_bwd_sums_kernel, dim3((c.emb + 255) / 256), dim3(256), 0, st, demb, lin, actL, B, c.emb, bsum(m->lin_bn));
+    hipLaunchKernelGGL(rows_bn_bwd_apply_kernel, dim3((B * c.emb + 255) / 256), dim3(256), 0, st, demb, lin,
+                       make_bnbwd(p, m->lin_bn, B, training), B, c.emb, dlin);
+    hipLaunchKernelGGL(tail_bwd_dw_kernel, dim3((K2 + 255) / 256, c.emb), dim3(256), 0, st, (const float*)dlin, pooled, actP, B, K2,
+                       c.emb, grads + m->lin_w);
+    // d pbn -> (in place) d pooled
+    hipLaunchKernelGGL(tail_bwd_dp_kernel, dim3((K2 + 255) / 256, B), dim3(256), 0, st, (const float*)dlin, params + m->lin_w, B, K2,
+                       c.emb, dpool);
+    hipLaunchKernelGGL(rows_bn_bwd_sums_kernel, dim3((K2 + 255) / 256), dim3(256), 0, st, (const float*)dpool, pooled, actP, B, K2,
+                       bsum(m->pool_bn));
+    hipLaunchKernelGGL(rows_bn_bwd_apply_kernel, dim3((B * K2 + 255) / 256), dim3(256), 0, st, (const float*)dpool, pooled,
+                       make_bnbwd(p, m->pool_bn, B, training), B, K2, dpool);
+  }
+  // ================= attentive statistics pooling =================
+  BnAct acte = make_act(p, m->epi_bn, M, training, 1, 0.f, seed, 0);
+  {
+    hipLaunchKernelGGL(asp_bwd_de_kernel<AT>, dim3(B, (D + 511) / 512), dim3(256), 0, st, (const AT*)(ws + p->E), acte,
+                       (const AT*)(ws + p->EN), T, D, 1e-6f, (const float*)(ws + p->pooled), (const float*)(ws + p->qv),
+                       (const float*)(ws + p->smax), (const float*)(ws + p->sinv), (const float*)(ws + p->dpooled),
+                       (AT*)(ws + p->dE), (AT*)(ws + p->dEbn), grads + m->asp_bout);
+    // d W_out[c][a] = sum_r dEN[r][c] * hid[r][a]
+    {
+      ProdPlain::Args pa{ws + p->dE, D, identity_act()};
+      ProdPlain::Args qa{ws + p->HID, A, identity_act()};
+      int rc = launch_wgrad<AT, ProdPlain, ProdPlain>(M, D, A, pa, qa, 0, slabs, p->slab_bytes, grads + m->asp_wout, st);
+      if (rc) return rc;
+    }
+    // d hid_pre = (dEN * W_out) .* (1 - hid^2)
+    {
+      GemmShape g{M, A, D, wt(p->wwout)};
+      ProdPlain::Args pa{ws + p->dE, D, identity_act()};
+      EpiTanhBwd::Args ea{ws + p->dHP, A, ws + p->HID, grads + m->asp_bin};
+      int rc = gemm_any<AT, ProdPlain, EpiTanhBwd>(g, pa, ea, st);
+      if (rc) return rc;
+    }
+    // d W_in[a][c] = sum_r dHP[r][a] * x[r][c],  x = act(E)
+    {
+      ProdPlain::Args pa{ws + p->dHP, A, identity_act()};
+      ProdPlain::Args qa{ws + p->E, D, acte};
+      int rc = launch_wgrad<AT, ProdPlain, ProdPlain>(M, A, D, pa, qa, 0, slabs, p->slab_bytes, grads + m->asp_win, st);
+      if (rc) return rc;
+    }
+    // d x = dHP * W_in + direct term; through the epilog relu -> dEbn (+ BN backward sums)
+    {
+      GemmShape g{M, D, A, wt(p->wwin)};
+      ProdPlain::Args pa{ws + p->dHP, A, identity_act()};
+      EpiAddMaskStore::Args ea{ws + p->dEbn, D, ws + p->E, acte, bsum(m->epi_bn)};
+      int rc = gemm_any<AT, ProdPlain, EpiAddMaskStore>(g, pa, ea, st);
+      if (rc) return rc;
+    }
+  }
+  // ================= epilog 1x1 conv =================
+  const int nb = c.n_mega_blocks;
+  const void* x_last = nb > 0 ? (const void*)(ws + p->blk[nb - 1].OUT) : (const void*)(ws + p->Y0);
+  BnAct act0 = make_act(p, m->prolog_bn, M, training, 1, 0.f, seed, 0);
+  BnAct act_last = nb > 0 ? identity_act() : act0;
+  int cur = 0;   // dA[cur] holds the gradient wrt the current block output
+  {
+    ProdDy::Args pa{ws + p->dEbn, ws + p->E, D, make_bnbwd(p, m->epi_bn, M, training)};
+    {
+      ProdPlain::Args qa{x_last, H, act_last};
+      int rc = launch_wgrad<AT, ProdDy, ProdPlain>(M, D, H, pa, qa, 0, slabs, p->slab_bytes, grads + m->epi_w, st);
+      if (rc) return rc;
+    }
+    GemmShape g{M, H, D, wt(p->wepi)};
+    EpiStoreArgs ea{ws + p->dA[cur], H, nullptr, nullptr};
+    int rc = gemm_any<AT, ProdDy, EpiStore>(g, pa, ea, st);
+    if (rc) return rc;
+  }
+  // ================= mega blocks, last to first =================
+  for (int i = nb - 1; i >= 0; --i) {
+    const MegaBlockRef& mb = m->blocks[i];
+    BlockWs& bw = p->blk[i];
+    const void* xin = i > 0 ? (const void*)(ws + p->blk[i - 1].OUT) : (const void*)(ws + p->Y0);
+    BnAct actx = i > 0 ? identity_act() : act0;
+    BnAct act3 = make_act(p, mb.sub[nsub - 1].bn, M, training, 1, pd, seed, i * (nsub + 1) + nsub - 1);
+    BnAct acts = make_act(p, mb.bnskip, M, training, 0, 0.f, seed, 0);
+    const float inv_keep = (training && pd > 0.f) ? 1.f / (1.f - pd) : 1.f;
+    const int CV = H / 8, TG = 512 / CV;
+    {
+      size_t smem = (size_t)(4 * H + TG * 3 * H) * sizeof(float);
+      auto k1 = combine_bwd1_kernel<AT>;
+      if (smem > 64 * 1024) TN_CHECK_HIP(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL(k1, dim3(B), dim3(512), smem, st, (const AT*)(ws + p->dA[cur]), (const AT*)(ws + bw.OUT),
+                         (const AT*)(ws + bw.Y[nsub - 1]), act3, (const AT*)(ws + bw.S), acts, T, H, inv_keep, (AT*)(ws + p->dZ),
+                         (float*)(ws + bw.dpre2), bsum(mb.bnskip));
+      smem = (size_t)(7 * H + ((Hr + 3) & ~3) + TG * 2 * H) * sizeof(float);
+      auto k2 = combine_bwd2_kernel<AT>;
+      if (smem > 64 * 1024) TN_CHECK_HIP(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL(k2, dim3(B), dim3(512), smem, st, (const AT*)(ws + p->dZ), (const AT*)(ws + bw.Y[nsub - 1]), act3,
+                         (const float*)(ws + bw.g), (const float*)(ws + bw.h), (float*)(ws + bw.dpre2), (float*)(ws + bw.dpre1),
+                         params + mb.se_w1, params + mb.se_w2, T, H, Hr, (AT*)(ws + p->dYbn), bsum(mb.sub[nsub - 1].bn));
+    }
+    // ---- skip connection: d S = BN-backward(dZ); dXs = dS * W_skip; d W_skip = dS^T X
+    {
+      ProdDy::Args pa{ws + p->dZ, ws + bw.S, H, make_bnbwd(p, mb.bnskip, M, training)};
+      ProdPlain::Args qa{xin, H, actx};
+      int rc = launch_wgrad<AT, ProdDy, ProdPlain>(M, H, H, pa, qa, 0, slabs, p->slab_bytes, grads + mb.wskip, st);
+      if (rc) return rc;
+      GemmShape g{M, H, H, wt(bw.wskip)};
+      EpiStoreArgs ea{ws + p->dXs, H, nullptr, nullptr};
+      rc = gemm_any<AT, ProdDy, EpiStore>(g, pa, ea, st);
+      if (rc) return rc;
+    }
+    // ---- sub-blocks, last to first
+    for (int j = nsub - 1; j >= 0; --j) {
+      const SubBlockRef& sb = mb.sub[j];
+      const void* sin = j > 0 ? (const void*)(ws + bw.Y[j - 1]) : xin;
+      BnAct asin = j > 0 ? make_act(p, mb.sub[j - 1].bn, M, training, 1, pd, seed, i * (nsub + 1) + j - 1) : actx;
+      ProdDy::Args pa{ws + p->dYbn, ws + bw.Y[j], H, make_bnbwd(p, sb.bn, M, training)};
+      {
+        ProdDw::Args qa{sin, H, asin, params + sb.wdw, params + sb.bdw, c.kernel, T};
+        int rc = launch_wgrad<AT, ProdDy, ProdDw>(M, H, H, pa, qa, c.kernel, slabs, p->slab_bytes, grads + sb.wpw, st);
+        if (rc) return rc;
+      }
+      {
+        GemmShape g{M, H, H, wt(bw.wpw[j])};
+        EpiStoreArgs ea{ws + p->dD, H, nullptr, nullptr};
+        int rc = gemm_any<AT, ProdDy, EpiStore>(g, pa, ea, st);
+        if (rc) return rc;
+      }
+      DwBwdArgs da;
+      memset(&da, 0, sizeof(da));
+      da.dD = ws + p->dD;
+      da.XRAW = sin;
+      da.actX = asin;
+      da.wdw = params + sb.wdw;
+      da.g_wdw = grads + sb.wdw;
+      da.g_bdw = grads + sb.bdw;
+      da.M = M; da.T = T; da.C = H;
+      if (j > 0) {
+        da.ADD = nullptr;
+        da.OUT = ws + p->dYbn;
+        da.bsumsX = bsum(mb.sub[j - 1].bn);
+      } else {
+        da.ADD = ws + p->dXs;
+        da.OUT = ws + p->dA[cur ^ 1];
+        da.bsumsX = (i == 0) ? bsum(m->prolog_bn) : nullptr;
+      }
+      int rc = launch_dw_bwd<AT>(da, c.kernel, st);
+      if (rc) return rc;
+    }
+    cur ^= 1;
+  }
+  // ================= prolog conv =================
+  {
+    if (nb == 0) {
+      // no mega blocks: dA[cur] holds d act0(Y0); push it through the prolog relu/BN mask
+      return TN_E_UNSUPPORTED;
+    }
+    ProdDy::Args pa{ws + p->dA[cur], ws + p->Y0, H, make_bnbwd(p, m->prolog_bn, M, training)};
+    const float* spec = p->last_input;
+    ProdIm2col::Args qa{spec, c.n_mels, c.prolog_kernel, T};
+    int rc = launch_wgrad<AT, ProdDy, ProdIm2col>(M, H, c.n_mels * c.prolog_kernel, pa, qa, 0, slabs, p->slab_bytes,
+                                                 grads + m->prolog_w, st);
+    if (rc) return rc;
+    if (grad_input) {
+      const int n = B * c.n_mels * T;
+      hipLaunchKernelGGL(prolog_input_grad_kernel<AT>, dim3((n + 255) / 256), dim3(256), 0, st, (const AT*)(ws + p->dA[cur]),
+                         (const AT*)(ws + p->Y0), pa.bn, params + m->prolog_w, B, c.n_mels, T, H, c.prolog_kernel, grad_input);
+    }
+  }
+  // ================= gradients that are functions of the accumulated sums =================
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3(2, m->n_bn), dim3(256), 0, st,
+                     (const BnGradDesc*)(ws + (training ? p->bwd_table : p->bwd_table_eval)));
+  if (nb > 0) {
+    hipLaunchKernelGGL(se_wgrad_kernel, dim3((2 * H * Hr + 255) / 256, nb), dim3(256), 0, st,
+                       (const SeGradDesc*)(ws + p->se_table), B, H, Hr);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// descriptor tables for the two "all layers at once" kernels; uploaded at bind time
+int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
+  const tn_model* m = p->model;
+  if (!p->grads) return 0;
+  std::vector<BnGradDesc> bd(m->n_bn);
+  std::vector<int64_t> bias_of(m->n_bn, -1);
+  bias_of[m->prolog_bn.id] = m->prolog_b;
+  for (auto& mb : m->blocks) {
+    for (auto& sb : mb.sub) bias_of[sb.bn.id] = sb.bpw;
+    bias_of[mb.bnskip.id] = mb.bskip;
+  }
+  bias_of[m->epi_bn.id] = m->epi_b;
+  bias_of[m->lin_bn.id] = m->lin_b;
+  for (int i = 0; i < m->n_bn; ++i) {
+    const BnRef& r = m->all_bn[i];
+    const int rows = (i == m->pool_bn.id || i == m->lin_bn.id) ? p->B : p->M;
+    bd[i].bn = make_bnbwd(p, r, rows, 1);   // mode patched per call (see below): tables hold train mode
+    bd[i].g_gamma = p->grads + r.gamma;
+    bd[i].g_beta = p->grads + r.beta;
+    bd[i].g_bias = bias_of[i] >= 0 ? p->grads + bias_of[i] : nullptr;
+    bd[i].C = r.C;
+    bd[i].n = rows;
+  }
+  if (sizeof(BnGradDesc) * bd.size() > p->bwd_table_bytes) return TN_E_STATE;
+  TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->bwd_table, bd.data(), bd.size() * sizeof(BnGradDesc), hipMemcpyHostToDevice, st));
+  // eval-mode copy (mode 2) right behind it
+  for (auto& d : bd) d.bn.mode = 2;
+  TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->bwd_table_eval, bd.data(), bd.size() * sizeof(BnGradDesc), hipMemcpyHostToDevice, st));
+  std::vector<SeGradDesc> sd(m->blocks.size());
+  for (size_t i = 0; i < m->blocks.size(); ++i) {
+    sd[i].dpre2 = (const float*)(p->ws + p->blk[i].dpre2);
+    sd[i].hid = (const float*)(p->ws + p->blk[i].h);
+    sd[i].dpre1 = (const float*)(p->ws + p->blk[i].dpre1);
+    sd[i].mean = (const float*)(p->ws + p->blk[i].m);
+    sd[i].g_w1 = p->grads + m->blocks[i].se_w1;
+    sd[i].g_w2 = p->grads + m->blocks[i].se_w2;
+  }
+  if (!sd.empty())
+    TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->se_table, sd.data(), sd.size() * sizeof(SeGradDesc), hipMemcpyHostToDevice, st));
+  TN_CHECK_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+int plan_backward(tn_plan* p, float grad_scale, const float* grad_scale_dev, const float* grad_emb, float* grad_input,
+                  hipStream_t st) {
+  if (p->prec == TN_PREC_BF16) return backward_impl<bf16_t>(p, grad_scale, grad_scale_dev, grad_emb, grad_input, st);
+  return backward_impl<float>(p, grad_scale, grad_scale_dev, grad_emb, grad_input, st);
+}

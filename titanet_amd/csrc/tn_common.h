@@ -203,6 +203,16 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// sum over a 256-thread block (4 waves); red = 4 floats of LDS
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
   // hardware global_atomic_add_f32 (built with -munsafe-fp-atomics), no return value
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

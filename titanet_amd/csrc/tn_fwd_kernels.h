@@ -297,15 +297,6 @@ __global__ __launch_bounds__(256) void row_normalize_kernel(float* W, int R, int
   for (int c = lane; c < C; c += 64) W[(size_t)r * C + c] *= inv;
 }
 
-__device__ __forceinline__ float block_sum_256(float v, float* red) {
-  v = wave_sum(v);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) red[wave] = v;
-  __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
-}
-
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* x = reinterpret_cast<float*>(smem);   // [E] embedding (CE) or normalised embedding (margin)

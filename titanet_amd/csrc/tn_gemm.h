@@ -72,7 +72,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 4 : 3)) void gemm_nt_k
   const int r0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
   Prod prod;
-  prod.template init<AT, BM, NT>(pa, g, scratch, tid, r0);   // ends with __syncthreads()
+  prod.template init<AT, NT, BK>(pa, g.M, g.K, scratch, tid);   // ends with __syncthreads()
 
   f32x16_t acc[2][2];
 #pragma unroll
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 4 : 3)) void gemm_nt_k
   const AT* W = reinterpret_cast<const AT*>(g.W);
   for (int kc = 0; kc < g.K; kc += BK) {
     fill_tile_plain<AT, BN, NT>(Bs, W, g.N, g.K, g.K, n0, kc, tid);
-    prod.template fill<AT, BM, NT>(As, pa, g, tid, r0, kc);   // result in As; may sync internally
+    prod.template fill<AT, BM, NT, BK, BKP>(As, pa, g.M, g.K, tid, r0, kc);   // result in As; may sync internally
     __syncthreads();
     const AT* arow0 = As + (wm * 64 + (lane & 31)) * BKP;
     const AT* brow0 = Bs + (wn * 64 + (lane & 31)) * BKP;
@@ -124,28 +124,30 @@ struct ProdPlain {
   };
   float* sc;
   float* sh;
-  static size_t scratch_bytes(int K, int /*KD*/, int /*BM*/, size_t /*elem*/) { return (size_t)2 * K * sizeof(float); }
-  template <typename AT, int BM, int NT>
-  __device__ __forceinline__ void init(const Args& a, const GemmShape& g, char* scratch, int tid, int /*r0*/) {
+  __host__ __device__ static size_t scratch_bytes(int K, int /*KD*/, int /*ROWS*/, int /*CW*/, size_t /*elem*/) {
+    return (size_t)2 * K * sizeof(float);
+  }
+  template <typename AT, int NT, int CW>
+  __device__ __forceinline__ void init(const Args& a, int M, int K, char* scratch, int tid) {
     sc = reinterpret_cast<float*>(scratch);
-    sh = sc + g.K;
+    sh = sc + K;
     if (a.act.mode != 0) {
-      for (int c = tid; c < g.K; c += NT) bn_scale_shift(a.act, g.K, c, sc[c], sh[c]);
+      for (int c = tid; c < K; c += NT) bn_scale_shift(a.act, K, c, sc[c], sh[c]);
     }
     __syncthreads();
   }
-  template <typename AT, int BM, int NT>
-  __device__ __forceinline__ void fill(AT* As, const Args& a, const GemmShape& g, int tid, int r0, int kc) {
-    constexpr int BK = Elem<AT>::BK, BKP = BK + Elem<AT>::PAD, VC = BK / 8, RL = NT / VC;
+  template <typename AT, int ROWS, int NT, int CW, int PITCH>
+  __device__ __forceinline__ void fill(AT* As, const Args& a, int M, int K, int tid, int r0, int kc) {
+    constexpr int BKP = PITCH, VC = CW / 8, RL = NT / VC, BM = ROWS;
     const int vc = tid % VC, rl = tid / VC;
     const int k = kc + vc * 8;
     const AT* X = reinterpret_cast<const AT*>(a.X);
     for (int r = rl; r < BM; r += RL) {
       float v[8];
       const int gr = r0 + r;
-      if (gr < g.M && k < g.K) {
+      if (gr < M && k < K) {
         load8(X + (size_t)gr * a.ldx + k, v);
-        act8(v, sc + k, sh + k, a.act, (uint32_t)gr, g.K, k);
+        act8(v, sc + k, sh + k, a.act, (uint32_t)gr, K, k);
       } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = 0.f;
@@ -172,28 +174,27 @@ struct ProdDw {
   float* wd;    // [KD][BK]
   float* bd;    // [BK]
   char* xs;     // [(BM + KD - 1)][BK] AT
-  static size_t scratch_bytes(int K, int KD, int BM, size_t elem) {
-    size_t bk = (elem == 2) ? 64 : 32;
-    return (size_t)2 * K * sizeof(float) + (size_t)(KD + 1) * bk * sizeof(float) + (size_t)(BM + KD - 1) * bk * elem + 16;
+  __host__ __device__ static size_t scratch_bytes(int K, int KD, int ROWS, int CW, size_t elem) {
+    return (size_t)2 * K * sizeof(float) + (size_t)(KD + 1) * CW * sizeof(float) + (size_t)(ROWS + KD - 1) * CW * elem + 32;
   }
-  template <typename AT, int BM, int NT>
-  __device__ __forceinline__ void init(const Args& a, const GemmShape& g, char* scratch, int tid, int /*r0*/) {
-    constexpr int BK = Elem<AT>::BK;
+  template <typename AT, int NT, int CW>
+  __device__ __forceinline__ void init(const Args& a, int M, int K, char* scratch, int tid) {
     sc = reinterpret_cast<float*>(scratch);
-    sh = sc + g.K;
-    wd = sh + g.K;
-    bd = wd + a.KD * BK;
-    size_t off = (size_t)(2 * g.K + (a.KD + 1) * BK) * sizeof(float);
+    sh = sc + K;
+    wd = sh + K;
+    bd = wd + a.KD * CW;
+    size_t off = (size_t)(2 * K + (a.KD + 1) * CW) * sizeof(float);
     off = (off + 15) & ~(size_t)15;
     xs = scratch + off;
     if (a.act.mode != 0) {
-      for (int c = tid; c < g.K; c += NT) bn_scale_shift(a.act, g.K, c, sc[c], sh[c]);
+      for (int c = tid; c < K; c += NT) bn_scale_shift(a.act, K, c, sc[c], sh[c]);
     }
     __syncthreads();
   }
-  template <typename AT, int BM, int NT>
-  __device__ __forceinline__ void fill(AT* As, const Args& a, const GemmShape& g, int tid, int r0, int kc) {
-    constexpr int BK = Elem<AT>::BK, BKP = BK + Elem<AT>::PAD, VC = BK / 8, RL = NT / VC;
+  template <typename AT, int ROWS, int NT, int CW, int PITCH>
+  __device__ __forceinline__ void fill(AT* As, const Args& a, int M, int K, int tid, int r0, int kc) {
+    constexpr int BK = CW, BKP = PITCH, VC = BK / 8, RL = NT / VC, BM = ROWS;
+    struct { int M, K; } g{M, K};
     const int vc = tid % VC, rl = tid / VC;
     const int k = kc + vc * 8;
     const int KD = a.KD, pad = (KD - 1) / 2;
@@ -247,12 +248,13 @@ struct ProdIm2col {
     const float* x;   // [B][n_mels][T] float32, T contiguous (reference layout)
     int n_mels, KP, T;
   };
-  static size_t scratch_bytes(int, int, int, size_t) { return 16; }
-  template <typename AT, int BM, int NT>
-  __device__ __forceinline__ void init(const Args&, const GemmShape&, char*, int, int) { __syncthreads(); }
-  template <typename AT, int BM, int NT>
-  __device__ __forceinline__ void fill(AT* As, const Args& a, const GemmShape& g, int tid, int r0, int kc) {
-    constexpr int BK = Elem<AT>::BK, BKP = BK + Elem<AT>::PAD;
+  __host__ __device__ static size_t scratch_bytes(int, int, int, int, size_t) { return 16; }
+  template <typename AT, int NT, int CW>
+  __device__ __forceinline__ void init(const Args&, int, int, char*, int) { __syncthreads(); }
+  template <typename AT, int ROWS, int NT, int CW, int PITCH>
+  __device__ __forceinline__ void fill(AT* As, const Args& a, int M, int K, int tid, int r0, int kc) {
+    constexpr int BK = CW, BKP = PITCH, BM = ROWS;
+    struct { int M, K; } g{M, K};
     const int pad = (a.KP - 1) / 2;
     // consecutive threads -> consecutive rows (t) for coalesced reads of the T-contiguous input
     for (int i = tid; i < BM * BK; i += NT) {
@@ -376,7 +378,7 @@ template <typename AT, int WM, int WN, typename Prod, typename Epi>
 inline int launch_gemm(const GemmShape& g, const typename Prod::Args& pa, const typename Epi::Args& ea, int KD,
                        hipStream_t stream) {
   constexpr int BM = WM * 64, BN = WN * 64;
-  size_t main_bytes = gemm_tile_bytes<AT, WM, WN>() + Prod::scratch_bytes(g.K, KD, BM, sizeof(AT));
+  size_t main_bytes = gemm_tile_bytes<AT, WM, WN>() + Prod::scratch_bytes(g.K, KD, BM, Elem<AT>::BK, sizeof(AT));
   size_t epi_bytes = Epi::template lds_bytes<AT, WM, WN>();
   size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   smem = (smem + 15) & ~(size_t)15;

@@ -103,8 +103,10 @@ struct tn_plan {
   size_t dpooled, dlin, demb;   // float
   size_t slabs;        // split-K partial weight gradients
   size_t slab_bytes = 0;
-  size_t bwd_table;
+  size_t bwd_table, bwd_table_eval, se_table;
+  size_t bwd_table_bytes = 0;
   // state
+  const float* last_input = nullptr;
   int last_training = -1;
   int last_has_loss = 0;
   uint64_t last_seed = 0;
@@ -114,6 +116,8 @@ int plan_forward(tn_plan* p, const float* spec, const int64_t* speakers, int tra
                  int64_t* preds, float* loss, hipStream_t st);
 int plan_backward(tn_plan* p, float grad_scale, const float* grad_scale_dev, const float* grad_emb, float* grad_input,
                   hipStream_t st);
+
+int plan_upload_bwd_tables(tn_plan* p, hipStream_t st);
 
 // helpers shared by forward / backward orchestration
 BnAct make_act(const tn_plan* p, const BnRef& bn, int rows, int training, int relu, float drop_p, uint64_t seed,
