@@ -444,7 +444,8 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
     ha.targets = speakers;
     ha.scale = c.scale; ha.has_scale = c.has_scale; ha.m1 = c.m1; ha.m2 = c.m2; ha.m3 = c.m3; ha.eps = c.loss_eps;
     ha.emb = (float*)(ws + p->emb);
-    ha.emb_norm = emb_out ? emb_out : (float*)(ws + p->emb_norm);
+    ha.emb_norm = (float*)(ws + p->emb_norm);
+    ha.emb_user = emb_out;
     ha.preds = preds ? preds : (int64_t*)(ws + p->preds);
     ha.loss = (float*)(ws + p->loss_acc);
     ha.dlogits = (float*)(ws + p->dlogits);

@@ -945,9 +945,11 @@ __global__ void bn_param_grad_kernel(const BnGradDesc* descs) {
     d.g_gamma[c] = s2;
     d.g_beta[c] = s1;
     if (d.g_bias) {
+      // train mode: sum_r dy = k0 s1 + k1 sum_y + k2 n == 0 identically (BatchNorm removes the mean, so
+      // the bias of the layer in front of it has no effect on the loss); eval mode: k0 * sum dz.
       float k0, k1, k2;
       bn_bwd_coefs(d.bn, d.C, c, k0, k1, k2);
-      d.g_bias[c] = (d.bn.mode == 1) ? k0 * s1 + k1 * sy + k2 * (float)d.n : k0 * s1;
+      d.g_bias[c] = (d.bn.mode == 1) ? 0.f : k0 * s1;
     }
   }
 }

@@ -277,7 +277,8 @@ struct HeadArgs {
   const int64_t* targets;
   float scale; int has_scale; float m1, m2, m3, eps;
   float* emb;            // [B][E] pre-normalisation embeddings
-  float* emb_norm;       // [B][E] output: normalised embeddings
+  float* emb_norm;       // [B][E] normalised embeddings (workspace copy, used by backward)
+  float* emb_user;       // [B][E] caller's output buffer or null
   int64_t* preds;        // [B]
   float* loss;           // scalar, pre-zeroed; accumulates mean
   float* dlogits;        // [B][NC]
@@ -319,10 +320,18 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
   if (a.loss_type == 2) {
     // normalized_inputs = inputs / ||inputs||  (no epsilon: src/losses.py:89-92)
     const float inv = 1.f / norm;
-    for (int e = tid; e < a.E; e += 256) { const float v = x[e] * inv; x[e] = v; a.emb_norm[(size_t)b * a.E + e] = v; }
+    for (int e = tid; e < a.E; e += 256) {
+      const float v = x[e] * inv;
+      x[e] = v;
+      a.emb_norm[(size_t)b * a.E + e] = v;
+      if (a.emb_user) a.emb_user[(size_t)b * a.E + e] = v;
+    }
   } else {
     const float inv = 1.f / fmaxf(norm, 1e-12f);
-    for (int e = tid; e < a.E; e += 256) a.emb_norm[(size_t)b * a.E + e] = x[e] * inv;
+    for (int e = tid; e < a.E; e += 256) {
+      a.emb_norm[(size_t)b * a.E + e] = x[e] * inv;
+      if (a.emb_user) a.emb_user[(size_t)b * a.E + e] = x[e] * inv;
+    }
   }
   if (a.loss_type == 0) return;
   __syncthreads();
