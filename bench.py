@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): utterances/sec of TitaNet-S fwd+bwd on 80-mel x 300-frame
+synthetic batches on N MI355X GPUs.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic batch per GPU: forward + backward of
+TitaNet-S (17 mega blocks, parameters.yml:54) with the CE-251 head, bf16 compute, batch 256 per GPU
+(BASELINE.json configs[1]) + gradient all-reduce (N > 1) + fused Adam.  Inputs are resident in HBM
+before the timed region.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+ALG_BYTES_PER_UTT_BF16 = 70.66e6   # 7,065,600 elements x 5 passes x 2 B (S/17, T=300, fwd+bwd)
+
+PROF_CLASSES = {1: "fwd_subblock_gemm", 2: "bwd_pointwise_wgrad", 3: "bwd_pointwise_dgrad", 4: "bwd_depthwise"}
+
+
+def kernel_algorithmic_bytes(cls, rows, hidden, esz):
+    """Minimal HBM bytes one launch of the kernel class must move."""
+    t = rows * hidden * esz
+    return {
+        1: 2 * t,                          # read input rows once, write raw output once
+        2: 3 * t + hidden * hidden * 4,    # read dYbn, Y (BN backward on load), previous raw output; write dW
+        3: 3 * t,                          # read dYbn, Y; write dD
+        4: 3 * t,                          # read dD, previous raw output; write dYbn(prev)
+    }[cls]
+
+
+def cpu_baseline(seconds=12.0, threads=None):
+    """The CPU restatement of the reference path (oracle/, 'port') timed on this box's host cores:
+    TitaNet-S/17 train-mode fwd+bwd with CE, float32, batch 8 (the reference's parameters.yml batch)."""
+    from oracle import detgen
+    from oracle import titanet_oracle as O
+    # intra-op threads: all host cores up to 8 (beyond that the small per-layer ops of a batch-8 step
+    # lose to synchronisation overhead: 8 thr 18.0, 32 thr 16.0, 128 thr 1.7 utt/s on the 256-core GPU box)
+    torch.set_num_threads(threads or min(os.cpu_count() or 1, 8))
+    cfg = O.OracleConfig.titanet("s", n_mega_blocks=17, dropout=0.0)
+    shapes = O.state_dict_shapes(cfg, "ce", 251)
+    sd = {}
+    for k, v in detgen.fill_state_dict(shapes, seed=42).items():
+        t = torch.from_numpy(v)
+        sd[k] = t if t.dtype == torch.int64 else t.float()
+        if sd[k].dtype.is_floating_point and "running_" not in k:
+            sd[k].requires_grad_(True)
+    B = 8
+    x = torch.from_numpy(detgen.spectrograms(B, 80, 300, seed=42)).float()
+    y = torch.from_numpy(detgen.speakers(B, 251, seed=42))
+
+    def step():
+        out = O.titanet_forward(sd, x, cfg, training=True, speakers=y, loss="ce")
+        out.loss.backward()
+        for v in sd.values():
+            if v.grad is not None:
+                v.grad = None
+
+    step()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        if time.perf_counter() - t0 > seconds or n >= 20:
+            break
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(B / dt, 2), "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} iterations of TitaNet-S/17 fwd+bwd (CE), fp32, batch {B}, 80x300, oracle/titanet_oracle.py"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--loss", default="ce", choices=["ce", "arc"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU execution path for the product)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+
+    from titanet_amd import LOSSES, TitaNet
+    from titanet_amd.trainer import Trainer
+
+    torch.manual_seed(42)
+    n_classes, T = 251, 300
+    if args.loss == "ce":
+        loss = LOSSES["ce"](192, n_classes, device=dev)
+    else:
+        loss = LOSSES["arc"](192, n_classes, device=dev, scale=30, margin=0.2)      # parameters.yml:42-44
+    model = TitaNet.get_titanet(embedding_size=192, n_mels=80, n_mega_blocks=17, model_size="s", attention_hidden_size=128,
+                                loss_function=loss, dropout=0.1, device=dev, precision=args.precision).train()
+    trainer = Trainer(model, lr=1e-3)
+    g = torch.Generator(device="cpu").manual_seed(42 + rank)       # per-rank shard of the synthetic global batch
+    x = (torch.randn(args.batch, 80, T, generator=g) * 0.11 - 0.10).to(dev)
+    y = torch.randint(0, n_classes, (args.batch,), generator=g).to(dev)
+
+    lib = model._lib
+    for _ in range(max(args.warmup, 1)):
+        trainer.step(x, y)
+    torch.cuda.synchronize()
+
+    # pick the dominant kernel class with one profiled step each (outside the timed region)
+    plan = model._active_plan
+    cls_ms = {}
+    for cls in PROF_CLASSES:
+        lib.tn_profile_begin(plan.handle, cls)
+        trainer.step(x, y)
+        ms, cnt = C.c_double(), C.c_int64()
+        lib.tn_profile_read(plan.handle, C.byref(ms), C.byref(cnt))
+        cls_ms[cls] = (ms.value, cnt.value)
+    dom = max(cls_ms, key=lambda k: cls_ms[k][0])
+    lib.tn_profile_begin(plan.handle, dom)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        emb, preds, lv = trainer.step(x, y)
+    barrier()
+    dt = time.perf_counter() - t0
+    ms, cnt = C.c_double(), C.c_int64()
+    lib.tn_profile_read(plan.handle, C.byref(ms), C.byref(cnt))
+    lib.tn_profile_begin(plan.handle, 0)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss_value = float(lv.item())
+
+    if rank == 0:
+        esz = 2 if args.precision == "bf16" else 4
+        rows = args.batch * T
+        kbytes = kernel_algorithmic_bytes(dom, rows, 256, esz)
+        avg_s = (ms.value / 1e3) / max(cnt.value, 1)
+        achieved = kbytes / avg_s / 1e9
+        value = args.batch * world * args.steps / dt
+        step_alg = ALG_BYTES_PER_UTT_BF16 * (esz / 2) * args.batch
+        out = {
+            "metric": "utterances/sec TitaNet-S fwd+bwd (80-mel x 300f)",
+            "value": round(value, 1),
+            "unit": "utterances/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": f"TitaNet-S/17 fwd+bwd+Adam, {args.loss.upper()}-251 head, batch {args.batch}/GPU, 80x300 (BASELINE configs[1])",
+                       "global_batch": args.batch * world, "frames": T, "parallelism": f"dp{world}", "dropout": 0.1,
+                       "loss": loss_value},
+            "roofline": {"bound": "hbm", "kernel": PROF_CLASSES[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt.value,
+                         "algorithmic_bytes_per_launch": kbytes,
+                         "step_frac_of_hbm_roofline": round(step_alg * world / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
+                         "class_ms_per_step": {PROF_CLASSES[k]: round(v[0], 3) for k, v in cls_ms.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -119,6 +119,19 @@ int tn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
                  float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_mult,
                  void* stream);
 
+/* ---- per-kernel timing with HIP events on the launch stream (roofline measurement) ----------------
+ * Kernel classes: the heavy kernels of one mega-block sub-block (there are n_mega_blocks*n_sub_blocks
+ * launches of each per step). */
+#define TN_PROF_NONE 0
+#define TN_PROF_FWD_SUBBLOCK 1 /* act-on-load + depthwise stencil + pointwise MFMA GEMM + BN statistics */
+#define TN_PROF_BWD_WGRAD 2    /* pointwise weight gradient (TN MFMA GEMM, recomputes the depthwise output) */
+#define TN_PROF_BWD_DGRAD 3    /* BN-backward-on-load + pointwise data-gradient MFMA GEMM */
+#define TN_PROF_BWD_DW 4       /* depthwise backward stencil + activation backward + BN backward sums */
+/* Start bracketing every launch of `kernel_class` with hipEvents (TN_PROF_NONE stops). */
+int tn_profile_begin(tn_plan* p, int32_t kernel_class);
+/* Waits for the recorded events; returns the summed kernel time and launch count since begin. */
+int tn_profile_read(tn_plan* p, double* total_ms, int64_t* launches);
+
 /* ---- introspection for tests / roofline -------------------------------------------------------*/
 /* Copies a named internal tensor of the last forward as float32 in the REFERENCE layout.
  * what: "logits" [B][n_classes]; "embeddings_raw" [B][emb]; "pooled" [B][2*enc_out];

@@ -237,7 +237,32 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   return 0;
 }
 
-extern "C" void tn_plan_destroy(tn_plan* p) { delete p; }
+extern "C" void tn_plan_destroy(tn_plan* p) {
+  if (!p) return;
+  for (auto e : p->prof_events) (void)hipEventDestroy(e);
+  delete p;
+}
+
+extern "C" int tn_profile_begin(tn_plan* p, int32_t kernel_class) {
+  if (!p || kernel_class < 0 || kernel_class > 4) return TN_E_BADARG;
+  p->prof_class = kernel_class;
+  p->prof_used = 0;
+  return 0;
+}
+
+extern "C" int tn_profile_read(tn_plan* p, double* total_ms, int64_t* launches) {
+  if (!p || !total_ms || !launches) return TN_E_BADARG;
+  double t = 0.0;
+  for (size_t i = 0; i + 1 < p->prof_used; i += 2) {
+    TN_CHECK_HIP(hipEventSynchronize(p->prof_events[i + 1]));
+    float ms = 0.f;
+    TN_CHECK_HIP(hipEventElapsedTime(&ms, p->prof_events[i], p->prof_events[i + 1]));
+    t += ms;
+  }
+  *total_ms = t;
+  *launches = (int64_t)(p->prof_used / 2);
+  return 0;
+}
 extern "C" size_t tn_plan_workspace_bytes(const tn_plan* p) { return p ? p->ws_bytes : 0; }
 
 extern "C" int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbuf, int64_t* nbt, void* workspace,
@@ -374,7 +399,11 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       GemmShape g{M, H, H, wsel<AT>(p, sb.wpw, bw.wpw[j])};
       ProdDw::Args pa{cur, H, acur, params + sb.wdw, params + sb.bdw, c.kernel, T};
       EpiStoreArgs ea{ws + bw.Y[j], H, params + sb.bpw, statp(sb.bn)};
-      int rc = gemm_store<AT, ProdDw>(g, pa, ea, c.kernel, st);
+      int rc;
+      {
+        ProfScope ps(p, TN_PROF_FWD_SUBBLOCK, st);
+        rc = gemm_store<AT, ProdDw>(g, pa, ea, c.kernel, st);
+      }
       if (rc) return rc;
       cur = ws + bw.Y[j];
       acur = make_act(p, sb.bn, M, training, 1, pd, seed, i * (c.n_sub_blocks + 1) + j);

@@ -206,13 +206,18 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       ProdDy::Args pa{ws + p->dYbn, ws + bw.Y[j], H, make_bnbwd(p, sb.bn, M, training)};
       {
         ProdDw::Args qa{sin, H, asin, params + sb.wdw, params + sb.bdw, c.kernel, T};
-        int rc = launch_wgrad<AT, ProdDy, ProdDw>(M, H, H, pa, qa, c.kernel, slabs, p->slab_bytes, grads + sb.wpw, st);
+        int rc = launch_wgrad<AT, ProdDy, ProdDw>(M, H, H, pa, qa, c.kernel, slabs, p->slab_bytes, grads + sb.wpw, st, p,
+                                                  TN_PROF_BWD_WGRAD);
         if (rc) return rc;
       }
       {
         GemmShape g{M, H, H, wt(bw.wpw[j])};
         EpiStoreArgs ea{ws + p->dD, H, nullptr, nullptr};
-        int rc = gemm_any<AT, ProdDy, EpiStore>(g, pa, ea, st);
+        int rc;
+        {
+          ProfScope ps(p, TN_PROF_BWD_DGRAD, st);
+          rc = gemm_any<AT, ProdDy, EpiStore>(g, pa, ea, st);
+        }
         if (rc) return rc;
       }
       DwBwdArgs da;
@@ -233,7 +238,11 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         da.OUT = ws + p->dA[cur ^ 1];
         da.bsumsX = (i == 0) ? bsum(m->prolog_bn) : nullptr;
       }
-      int rc = launch_dw_bwd<AT>(da, c.kernel, st);
+      int rc;
+      {
+        ProfScope ps(p, TN_PROF_BWD_DW, st);
+        rc = launch_dw_bwd<AT>(da, c.kernel, st);
+      }
       if (rc) return rc;
     }
     cur ^= 1;

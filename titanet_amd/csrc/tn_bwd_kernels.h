@@ -7,6 +7,7 @@
 #include "../../include/titanet_amd.h"
 #include "tn_common.h"
 #include "tn_gemm.h"
+#include "tn_internal.h"
 
 // ------------------------------------------------------------------------------------------
 // BatchNorm backward "on load": a stored tensor dz = d loss / d BN-output becomes
@@ -371,7 +372,8 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int splits, 
 
 template <typename AT, typename ProdP, typename ProdQ>
 inline int launch_wgrad(int M, int CA, int CB, const typename ProdP::Args& pa, const typename ProdQ::Args& qa, int KD,
-                        float* slabs, size_t slab_bytes, float* out, hipStream_t st) {
+                        float* slabs, size_t slab_bytes, float* out, hipStream_t st, tn_plan* prof_plan = nullptr,
+                        int prof_cls = 0) {
   constexpr int RK = WgTile<AT>::RK, PITCH = 128 + WgTile<AT>::PAD;
   const int tiles = ((CA + 127) / 128) * ((CB + 127) / 128);
   int splits = (256 + tiles - 1) / tiles;
@@ -391,7 +393,10 @@ inline int launch_wgrad(int M, int CA, int CB, const typename ProdP::Args& pa, c
   if (smem > 64 * 1024) {
     TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   }
-  hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), smem, st, g, pa, qa);
+  {
+    ProfScope ps(prof_plan, prof_cls, st);
+    hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), smem, st, g, pa, qa);
+  }
   const int64_t n = (int64_t)CA * CB;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256), 0, st, slabs, splits, n, out);
   return (int)hipGetLastError();

@@ -105,6 +105,10 @@ struct tn_plan {
   size_t slab_bytes = 0;
   size_t bwd_table, bwd_table_eval, se_table;
   size_t bwd_table_bytes = 0;
+  // per-kernel event timing (tn_profile_*)
+  int prof_class = 0;
+  std::vector<hipEvent_t> prof_events;
+  size_t prof_used = 0;
   // state
   const float* last_input = nullptr;
   int last_training = -1;
@@ -118,6 +122,24 @@ int plan_backward(tn_plan* p, float grad_scale, const float* grad_scale_dev, con
                   hipStream_t st);
 
 int plan_upload_bwd_tables(tn_plan* p, hipStream_t st);
+
+// bracket a launch with events when its class is being profiled
+struct ProfScope {
+  tn_plan* p;
+  hipStream_t st;
+  bool on;
+  ProfScope(tn_plan* plan, int cls, hipStream_t s) : p(plan), st(s), on(plan && cls != 0 && plan->prof_class == cls) {
+    if (on) {
+      if (p->prof_used + 2 > p->prof_events.size()) {
+        for (int i = 0; i < 256; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } p->prof_events.push_back(e); }
+      }
+      (void)hipEventRecord(p->prof_events[p->prof_used], st);
+    }
+  }
+  ~ProfScope() {
+    if (on) { (void)hipEventRecord(p->prof_events[p->prof_used + 1], st); p->prof_used += 2; }
+  }
+};
 
 // helpers shared by forward / backward orchestration
 BnAct make_act(const tn_plan* p, const BnRef& bn, int rows, int training, int relu, float drop_p, uint64_t seed,
