@@ -8,6 +8,7 @@
 #include "tn_fwd_kernels.h"
 #include "tn_gemm.h"
 #include "tn_internal.h"
+#include "tn_v2_kernels.h"
 
 // =============================================================================================
 // model layout == reference state_dict (reference src/models.py:370-384, :432-455, :504-513,
@@ -160,6 +161,12 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   p->model = m;
   p->B = batch; p->T = frames; p->M = batch * frames; p->prec = precision;
   p->esz = precision == TN_PREC_BF16 ? 2 : 4;
+  {
+    const char* e = getenv("TN_V2");
+    // TN_V2 = bit mask (debug / A-B): 1 forward sub-block, 2 forward skip conv, 4 backward kernels; default all
+    const int mask = e ? atoi(e) : 7;
+    p->use_v2 = (precision == TN_PREC_BF16 && m->cfg.hidden == 256 && m->cfg.kernel == 3) ? mask : 0;
+  }
   const tn_config& c = m->cfg;
   const size_t M = p->M, H = c.hidden, D = c.enc_out, A = c.attn_hidden, Hr = c.hidden / c.se_reduction;
   const size_t e = p->esz;
@@ -228,6 +235,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   }
   p->cast_table = b.take(sizeof(CastDesc) * (8 + (size_t)c.n_mega_blocks * (c.n_sub_blocks + 1)));
   p->bn_table = b.take(sizeof(BnUpdateDesc) * m->n_bn);
+  p->stats_ptr_table = b.take(sizeof(float*) * m->n_bn);
   p->bwd_table_bytes = (size_t)m->n_bn * 128;   // >= sizeof(BnGradDesc) each (checked at upload)
   p->bwd_table = b.take(p->bwd_table_bytes);
   p->bwd_table_eval = b.take(p->bwd_table_bytes);
@@ -305,6 +313,9 @@ extern "C" int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbu
     bd[i].n = (i == m->pool_bn.id || i == m->lin_bn.id) ? p->B : p->M;
   }
   TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->bn_table, bd.data(), bd.size() * sizeof(BnUpdateDesc), hipMemcpyHostToDevice, st));
+  std::vector<float*> sp(m->n_bn);
+  for (int i = 0; i < m->n_bn; ++i) sp[i] = (float*)(p->ws + p->stats[i]);
+  TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->stats_ptr_table, sp.data(), sp.size() * sizeof(float*), hipMemcpyHostToDevice, st));
   TN_CHECK_HIP(hipStreamSynchronize(st));   // host vectors go out of scope
   int rc = plan_upload_bwd_tables(p, st);
   if (rc) return rc;
@@ -328,11 +339,9 @@ BnAct make_act(const tn_plan* p, const BnRef& bn, int rows, int training, int re
   a.stats = (const float*)(p->ws + p->stats[bn.id]);
   a.gamma = p->params + bn.gamma;
   a.beta = p->params + bn.beta;
-  a.rmean = p->bnbuf + bn.rmean;
-  a.rvar = p->bnbuf + bn.rvar;
   a.inv_n = 1.f / (float)rows;
   a.eps = 1e-5f;
-  a.mode = training ? 1 : 2;
+  a.mode = 1;
   a.relu = relu;
   if (training && drop_p > 0.f) {
     a.drop_thr = (uint32_t)lrintf(drop_p * 65536.f);
@@ -371,6 +380,11 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   if (p->n_cast > 0) {
     hipLaunchKernelGGL(cast_params_kernel<AT>, dim3(64, p->n_cast), dim3(256), 0, st, (const CastDesc*)(ws + p->cast_table));
   }
+  if (!training) {
+    // eval: BatchNorm uses the running statistics -> write the equivalent sums once for all layers
+    hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(2, m->n_bn), dim3(256), 0, st, (const BnUpdateDesc*)(ws + p->bn_table),
+                       (float* const*)(ws + p->stats_ptr_table));
+  }
   // ---- prolog: dense k=3 conv as an im2col GEMM (reference src/models.py:370, :398)
   {
     GemmShape g{M, H, c.n_mels * c.prolog_kernel, wsel<AT>(p, m->prolog_w, p->wprolog)};
@@ -386,10 +400,17 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
     BlockWs& bw = p->blk[i];
     // skip connection: 1x1 conv (reference src/models.py:452-455)
     {
-      GemmShape g{M, H, H, wsel<AT>(p, mb.wskip, bw.wskip)};
-      ProdPlain::Args pa{xin, H, actx};
-      EpiStoreArgs ea{ws + bw.S, H, params + mb.bskip, statp(mb.bnskip)};
-      int rc = gemm_store<AT, ProdPlain>(g, pa, ea, 0, st);
+      int rc;
+      if (p->use_v2 & 2) {
+        SubFwdV2Args va{(const bf16_t*)xin, actx, nullptr, nullptr, (const bf16_t*)(ws + bw.wskip.w), params + mb.bskip,
+                        (bf16_t*)(ws + bw.S), statp(mb.bnskip), M, T, 0};
+        rc = launch_sub_fwd_v2<1, false>(va, 256, st);
+      } else {
+        GemmShape g{M, H, H, wsel<AT>(p, mb.wskip, bw.wskip)};
+        ProdPlain::Args pa{xin, H, actx};
+        EpiStoreArgs ea{ws + bw.S, H, params + mb.bskip, statp(mb.bnskip)};
+        rc = gemm_store<AT, ProdPlain>(g, pa, ea, 0, st);
+      }
       if (rc) return rc;
     }
     const void* cur = xin;
@@ -402,7 +423,13 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       int rc;
       {
         ProfScope ps(p, TN_PROF_FWD_SUBBLOCK, st);
-        rc = gemm_store<AT, ProdDw>(g, pa, ea, c.kernel, st);
+        if (p->use_v2 & 1) {
+          SubFwdV2Args va{(const bf16_t*)cur, acur, params + sb.wdw, params + sb.bdw, (const bf16_t*)(ws + bw.wpw[j].w),
+                          params + sb.bpw, (bf16_t*)(ws + bw.Y[j]), statp(sb.bn), M, T, 0};
+          rc = launch_sub_fwd_v2<3, true>(va, 256, st);
+        } else {
+          rc = gemm_store<AT, ProdDw>(g, pa, ea, c.kernel, st);
+        }
       }
       if (rc) return rc;
       cur = ws + bw.Y[j];

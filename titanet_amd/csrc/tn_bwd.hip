@@ -15,11 +15,9 @@ BnBwd make_bnbwd(const tn_plan* p, const BnRef& bn, int rows, int training) {
   b.fstats = (const float*)(p->ws + p->stats[bn.id]);
   b.bsums = (const float*)(p->ws + p->bsums[bn.id]);
   b.gamma = p->params + bn.gamma;
-  b.rmean = p->bnbuf + bn.rmean;
-  b.rvar = p->bnbuf + bn.rvar;
   b.inv_n = 1.f / (float)rows;
   b.eps = 1e-5f;
-  b.mode = training ? 1 : 2;
+  b.batch = training ? 1.f : 0.f;
   return b;
 }
 
@@ -303,7 +301,7 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
   if (sizeof(BnGradDesc) * bd.size() > p->bwd_table_bytes) return TN_E_STATE;
   TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->bwd_table, bd.data(), bd.size() * sizeof(BnGradDesc), hipMemcpyHostToDevice, st));
   // eval-mode copy (mode 2) right behind it
-  for (auto& d : bd) d.bn.mode = 2;
+  for (auto& d : bd) d.bn.batch = 0.f;
   TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->bwd_table_eval, bd.data(), bd.size() * sizeof(BnGradDesc), hipMemcpyHostToDevice, st));
   std::vector<SeGradDesc> sd(m->blocks.size());
   for (size_t i = 0; i < m->blocks.size(); ++i) {

@@ -17,41 +17,30 @@
 // kernel PRODUCING dz accumulated.  d gamma = sum dz*yhat, d beta = sum dz.
 // ------------------------------------------------------------------------------------------
 struct BnBwd {
-  const float* fstats;   // forward  [TN_NREP][2][C]
+  const float* fstats;   // forward  [TN_NREP][2][C] (eval: equivalent sums of the running statistics)
   const float* bsums;    // backward [TN_NREP][2][C]
   const float* gamma;
-  const float* rmean;
-  const float* rvar;
   float inv_n, eps;
-  int mode;              // 1 batch statistics, 2 running statistics
+  float batch;           // 1.f: batch statistics (train) -> mean/variance terms; 0.f: fixed statistics (eval)
 };
 
 __device__ __forceinline__ void bn_fwd_mean_rstd(const BnBwd& b, int C, int c, float& mean, float& rstd) {
-  if (b.mode == 1) {
-    float s = 0.f, q = 0.f;
+  float s = 0.f, q = 0.f;
 #pragma unroll
-    for (int r = 0; r < TN_NREP; ++r) { s += b.fstats[(r * 2 + 0) * C + c]; q += b.fstats[(r * 2 + 1) * C + c]; }
-    mean = s * b.inv_n;
-    rstd = rsqrtf(fmaxf(q * b.inv_n - mean * mean, 0.f) + b.eps);
-  } else {
-    mean = b.rmean[c];
-    rstd = rsqrtf(b.rvar[c] + b.eps);
-  }
+  for (int r = 0; r < TN_NREP; ++r) { s += b.fstats[(r * 2 + 0) * C + c]; q += b.fstats[(r * 2 + 1) * C + c]; }
+  mean = s * b.inv_n;
+  rstd = rsqrtf(fmaxf(q * b.inv_n - mean * mean, 0.f) + b.eps);
 }
 __device__ __forceinline__ void bn_bwd_coefs(const BnBwd& b, int C, int c, float& k0, float& k1, float& k2) {
   float mean, rstd;
   bn_fwd_mean_rstd(b, C, c, mean, rstd);
   k0 = b.gamma[c] * rstd;
-  if (b.mode == 1) {
-    float s1 = 0.f, s2 = 0.f;
+  float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int r = 0; r < TN_NREP; ++r) { s1 += b.bsums[(r * 2 + 0) * C + c]; s2 += b.bsums[(r * 2 + 1) * C + c]; }
-    const float c1 = s1 * b.inv_n, c2 = s2 * b.inv_n;
-    k1 = -k0 * c2 * rstd;
-    k2 = k0 * (c2 * rstd * mean - c1);
-  } else {
-    k1 = 0.f; k2 = 0.f;
-  }
+  for (int r = 0; r < TN_NREP; ++r) { s1 += b.bsums[(r * 2 + 0) * C + c]; s2 += b.bsums[(r * 2 + 1) * C + c]; }
+  const float c1 = s1 * b.inv_n * b.batch, c2 = s2 * b.inv_n * b.batch;   // branch-free: zero in eval mode
+  k1 = -k0 * c2 * rstd;
+  k2 = k0 * (c2 * rstd * mean - c1);
 }
 
 // P_DY: A[r][c] = k0[c]*dZ[r][c] + k1[c]*Y[r][c] + k2[c]
@@ -954,7 +943,7 @@ __global__ void bn_param_grad_kernel(const BnGradDesc* descs) {
       // the bias of the layer in front of it has no effect on the loss); eval mode: k0 * sum dz.
       float k0, k1, k2;
       bn_bwd_coefs(d.bn, d.C, c, k0, k1, k2);
-      d.g_bias[c] = (d.bn.mode == 1) ? 0.f : k0 * s1;
+      d.g_bias[c] = (d.bn.batch != 0.f) ? 0.f : k0 * s1;
     }
   }
 }

@@ -24,13 +24,17 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // bf16 <-> f32
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  const uint32_t u = __float_as_uint(f);
-  // round-to-nearest-even; NaN stays NaN (quiet bit forced); branch-free
-  const uint32_t r = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-  const uint32_t n = (u >> 16) | 0x40u;
-  return (bf16_t)(((u & 0x7fffffffu) > 0x7f800000u) ? n : r);
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+// f32 -> bf16, round-to-nearest-even in hardware: v_cvt_pk_bf16_f32 converts TWO values per
+// instruction (the bit-twiddled software rounding costs ~5 VALU ops per value, and these kernels are
+// VALU-bound on exactly this kind of per-element work).
+__device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {
+  f32x2_t v;
+  v[0] = lo; v[1] = hi;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
 template <typename AT> struct Elem;
 template <> struct Elem<float> {
@@ -68,10 +72,10 @@ __device__ __forceinline__ void store8(float* p, const float v[8]) {
 }
 __device__ __forceinline__ void store8(bf16_t* p, const float v[8]) {
   uint4 a;
-  a.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-  a.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-  a.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-  a.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  a.x = f2bf_pk(v[0], v[1]);
+  a.y = f2bf_pk(v[2], v[3]);
+  a.z = f2bf_pk(v[4], v[5]);
+  a.w = f2bf_pk(v[6], v[7]);
   *reinterpret_cast<uint4*>(p) = a;
 }
 // LDS row writes: the float tiles use an odd row stride (bank-conflict-free ds_read_b32 for the
@@ -111,14 +115,17 @@ __device__ __forceinline__ uint32_t tn_keep_pair(uint32_t pair_index, uint32_t k
 // activation and the dropout mask are recomputed by every consumer (never materialised).
 // ------------------------------------------------------------------------------------------
 struct BnAct {
-  const float* stats;   // [TN_NREP][2][C]: sum, sum of squares over the M rows (train mode)
+  // [TN_NREP][2][C]: sum, sum of squares over the M rows.  Train mode: accumulated by the producing
+  // kernel's epilogue.  Eval mode: bn_eval_prepare_kernel writes the sums that reproduce the running
+  // statistics (sum = mean*n, sumsq = (var + mean^2)*n), so device code has ONE normalisation path
+  // (a second, running-stats path in these kernels was miscompiled by hipcc 7.2: the channel index
+  // register was left undefined on that branch).
+  const float* stats;
   const float* gamma;   // [C]
   const float* beta;    // [C]
-  const float* rmean;   // [C] running mean (eval mode)
-  const float* rvar;    // [C] running var  (eval mode)
   float inv_n;          // 1 / rows
   float eps;
-  int mode;             // 0 identity, 1 batch statistics, 2 running statistics
+  int mode;             // 0 identity, 1 BatchNorm from `stats`
   int relu;             // apply max(.,0)
   uint32_t drop_thr;    // 0 = no dropout; else round(p * 65536)
   uint32_t drop_key;    // tn_layer_key(seed, layer)
@@ -127,17 +134,12 @@ struct BnAct {
 
 // per-channel (mean, rstd) from the replicated batch sums
 __device__ __forceinline__ void bn_mean_rstd(const BnAct& a, int C, int c, float& mean, float& rstd) {
-  if (a.mode == 1) {
-    float s = 0.f, q = 0.f;
+  float s = 0.f, q = 0.f;
 #pragma unroll
-    for (int r = 0; r < TN_NREP; ++r) { s += a.stats[(r * 2 + 0) * C + c]; q += a.stats[(r * 2 + 1) * C + c]; }
-    mean = s * a.inv_n;
-    float var = fmaxf(q * a.inv_n - mean * mean, 0.f);
-    rstd = rsqrtf(var + a.eps);
-  } else {
-    mean = a.rmean[c];
-    rstd = rsqrtf(a.rvar[c] + a.eps);
-  }
+  for (int r = 0; r < TN_NREP; ++r) { s += a.stats[(r * 2 + 0) * C + c]; q += a.stats[(r * 2 + 1) * C + c]; }
+  mean = s * a.inv_n;
+  const float var = fmaxf(q * a.inv_n - mean * mean, 0.f);
+  rstd = rsqrtf(var + a.eps);
 }
 // scale/shift so that bn(x) = x*scale + shift
 __device__ __forceinline__ void bn_scale_shift(const BnAct& a, int C, int c, float& sc, float& sh) {

@@ -418,6 +418,17 @@ struct BnUpdateDesc {
   int n;                // rows reduced
 };
 
+// eval mode: sums that make the batch-statistics formula reproduce the running statistics
+__global__ void bn_eval_prepare_kernel(const BnUpdateDesc* descs, float* const* stats_out) {
+  const BnUpdateDesc d = descs[blockIdx.y];
+  float* st = stats_out[blockIdx.y];
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < d.C; c += gridDim.x * blockDim.x) {
+    const float m = d.rmean[c], v = d.rvar[c], n = (float)d.n;
+    st[c] = m * n;                    // replica 0 sum          (other replicas stay zero)
+    st[d.C + c] = (v + m * m) * n;    // replica 0 sum of squares
+  }
+}
+
 __global__ void bn_running_update_kernel(const BnUpdateDesc* descs, float momentum, int64_t* nbt, int n_layers) {
   const BnUpdateDesc d = descs[blockIdx.y];
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < d.C; c += gridDim.x * blockDim.x) {

@@ -71,6 +71,7 @@ struct BlockWs {
 struct tn_plan {
   const tn_model* model;
   int B, T, M, prec;
+  int use_v2 = 0;           // specialised hidden=256 bf16 kernels (tn_v2_kernels.h)
   size_t esz;               // activation element size
   size_t ws_bytes = 0;
   // bound buffers
@@ -89,7 +90,7 @@ struct tn_plan {
   std::vector<BlockWs> blk;
   size_t E, HID, EN, pooled, smax, sinv, qv, lin, emb, emb_norm, dlogits, dscale, logits, preds;
   WcRef wprolog, wepi, wwin, wwout;
-  size_t cast_table, bn_table;
+  size_t cast_table, bn_table, stats_ptr_table;
   int n_cast = 0;
   // backward scratch
   size_t dA[2];        // ping-pong grad wrt block outputs (rows x hidden, AT)

@@ -1,0 +1,232 @@
+// titanet_amd — "v2" kernels: the three heavy kernels of a mega-block sub-block, specialised for the
+// headline shape (hidden = 256 channels, bf16 activations; TitaNet-S, BASELINE.json configs[1]).
+//
+// What the generic v1 kernels lose on this HBM-bound shape is latency, not bandwidth: they run
+// produce -> barrier -> MFMA -> barrier once per K chunk at 1-2 workgroups per CU.  Here instead:
+//   * a row tile of the rows x 256 activation matrix is ONE contiguous 32 KB block of HBM (64 rows x
+//     512 B): each thread prefetches the NEXT tile into registers (4 x 16 B per input stream) while
+//     the current tile is transformed / multiplied / stored (global -> reg -> LDS double buffering:
+//     the compiler counts vmcnt for us, loads stay in flight across the barriers);
+//   * workgroups are persistent (grid = resident workgroups), the 256 x 256 weight matrix lives in
+//     REGISTERS as MFMA B fragments for the whole kernel (each of the 8 waves owns 32 output columns
+//     x all 256 K = 16 fragments = 64 VGPRs), so LDS only holds activations and the K loop runs
+//     without any weight staging or barrier;
+//   * per-channel reductions (BatchNorm sums, depthwise weight gradients) accumulate in registers
+//     across all tiles of the workgroup and hit global atomics once per workgroup.
+#pragma once
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "tn_common.h"
+#include "tn_gemm.h"
+
+#define V2_C 256            // channels (hidden width)
+#define V2_R 64             // raw rows per tile
+#define V2_AP (V2_C + 8)    // padded pitch of MFMA operand tiles (conflict-free ds_read_b128)
+#define V2_NT 512
+#ifndef V2_DBG_SKIP
+#define V2_DBG_SKIP 0   // tuning only: 1 skip MFMA, 2 skip stencil, 4 skip global stores, 8 skip act
+#endif
+
+// 16-byte vector <-> 8 floats with a uint4 register image (prefetch buffers)
+__device__ __forceinline__ void unpack8(const uint4& a, float v[8]) {
+  v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+  v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+  v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+  v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+
+// act with per-thread register scale/shift (the thread's 8 channels never change)
+__device__ __forceinline__ void act8_reg(float v[8], const float sc[8], const float sh[8], const BnAct& a, uint32_t row,
+                                         int c0) {
+  if (a.mode != 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[i] + sh[i];
+  }
+  if (a.relu) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+  }
+  if (a.drop_thr) {
+    const uint32_t pair = (row * (uint32_t)V2_C + (uint32_t)c0) >> 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t k = tn_keep_pair(pair + i, a.drop_key, a.drop_thr);
+      v[2 * i] = (k & 1u) ? v[2 * i] * a.inv_keep : 0.f;
+      v[2 * i + 1] = (k & 2u) ? v[2 * i + 1] * a.inv_keep : 0.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward sub-block (reference src/modules.py:65-78 + BN statistics of :128):
+//   Y = W_pw * dwconv_KD(act(X)) + b   (DW = true)      or      Y = W * act(X) + b   (DW = false)
+// ------------------------------------------------------------------------------------------
+struct SubFwdV2Args {
+  const bf16_t* X;      // [M][256] raw input
+  BnAct act;
+  const float* wdw;     // [256][KD]
+  const float* bdw;     // [256]
+  const bf16_t* W;      // [256][256] bf16, row = output channel, K contiguous
+  const float* bias;    // [256]
+  bf16_t* Y;            // [M][256]
+  float* stats;         // [TN_NREP][2][256] or null
+  int M, T, ntiles;
+};
+
+template <int KD, bool DW>
+__global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v2_kernel(SubFwdV2Args a) {
+  constexpr int PADR = DW ? (KD - 1) / 2 : 0;
+  constexpr int OUTR = DW ? V2_R - (KD - 1) : V2_R;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* Xa = reinterpret_cast<bf16_t*>(smem);     // [64][256] activated input rows; reused as the output staging tile
+  bf16_t* As = Xa + V2_R * V2_C;                    // [64][264] MFMA A operand (depthwise output)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vc = tid & 31, rq = tid >> 5;          // this thread's channel vector and row phase (rows rq + 16 q)
+  const int c0 = vc * 8;
+
+  // ---- per-thread constants: BN scale/shift and depthwise taps of the thread's 8 channels.
+  // Computed cooperatively (one channel per thread, 18 loads) and redistributed through LDS: having
+  // every thread reduce the 8 statistic replicas of its own 8 channels costs 144 gather loads per
+  // thread and dominated the kernel.
+  float sc[8], sh[8];
+  float wd[DW ? KD : 1][8], bd[8];
+  {
+    float* tmp = reinterpret_cast<float*>(As);      // scratch before the first tile: [2 + KD + 1][256]
+    if (tid < V2_C) {
+      float s, h;
+      bn_scale_shift(a.act, V2_C, tid, s, h);
+      tmp[tid] = s;
+      tmp[V2_C + tid] = h;
+      if (DW) {
+        tmp[2 * V2_C + tid] = a.bdw[tid];
+#pragma unroll
+        for (int k = 0; k < KD; ++k) tmp[(3 + k) * V2_C + tid] = a.wdw[(size_t)tid * KD + k];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sc[i] = tmp[c0 + i];
+      sh[i] = tmp[V2_C + c0 + i];
+      if (DW) {
+        bd[i] = tmp[2 * V2_C + c0 + i];
+#pragma unroll
+        for (int k = 0; k < KD; ++k) wd[k][i] = tmp[(3 + k) * V2_C + c0 + i];
+      }
+    }
+    __syncthreads();
+  }
+  // ---- this wave's 32 output columns of W as MFMA B fragments, resident for the whole kernel
+  const int ncol = wave * 32 + (lane & 31), half = lane >> 5;
+  bf16x8_t wf[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks)
+    wf[ks] = *reinterpret_cast<const bf16x8_t*>(a.W + (size_t)ncol * V2_C + ks * 16 + half * 8);
+  const float bias = a.bias[ncol];
+  float st_s = 0.f, st_q = 0.f;
+
+  uint4 pf[4];
+  auto prefetch = [&](int tile) {
+    const int raw0 = tile * OUTR - PADR;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int gr = raw0 + rq + 16 * q;
+      if (gr >= 0 && gr < a.M) pf[q] = *reinterpret_cast<const uint4*>(a.X + (size_t)gr * V2_C + c0);
+      else pf[q] = make_uint4(0, 0, 0, 0);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) prefetch(tile);
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    const int out0 = tile * OUTR, raw0 = out0 - PADR;
+    __syncthreads();   // (1) previous tile's output staging (aliases Xa) has been stored
+    // ---- registers -> LDS with the activation applied once per element
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = rq + 16 * q, gr = raw0 + r;
+      float v[8];
+      unpack8(pf[q], v);
+      if (!(V2_DBG_SKIP & 8) && gr >= 0 && gr < a.M) act8_reg(v, sc, sh, a.act, (uint32_t)gr, c0);
+      if (DW) store8(Xa + r * V2_C + c0, v);
+      else store8(As + r * V2_AP + c0, v);
+    }
+    if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);   // next tile's loads fly during the rest
+    __syncthreads();   // (2)
+    if (DW) {
+      // ---- depthwise stencil over time -> MFMA operand tile
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int o = rq + 16 * q;           // output row within the tile (valid: o < OUTR)
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = bd[i];
+        if (!(V2_DBG_SKIP & 2) && o < OUTR) {
+          const int t = (out0 + o) % a.T;
+#pragma unroll
+          for (int k = 0; k < KD; ++k) {
+            const int tt = t + k - PADR;
+            if (tt >= 0 && tt < a.T) {
+              float v[8];
+              load8(Xa + (o + k) * V2_C + c0, v);
+#pragma unroll
+              for (int i = 0; i < 8; ++i) acc[i] = fmaf(wd[k][i], v[i], acc[i]);
+            }
+          }
+        }
+        store8(As + o * V2_AP + c0, acc);
+      }
+      __syncthreads();   // (3)
+    }
+    // ---- pointwise GEMM: [64 x 256] x W^T, weights from registers
+    f32x16_t acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const bf16_t* arow = As + (lane & 31) * V2_AP + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < ((V2_DBG_SKIP & 1) ? 1 : 16); ++ks) {
+      const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(arow + ks * 16);
+      const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(arow + 32 * V2_AP + ks * 16);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[ks], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[ks], acc1, 0, 0, 0);
+    }
+    // ---- epilogue: bias, BN statistics in registers, stage the tile for coalesced stores
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int r0l = cd_row(r, lane), r1l = 32 + r0l;
+      const float y0 = acc0[r] + bias, y1 = acc1[r] + bias;
+      if (r0l < OUTR && out0 + r0l < a.M) { st_s += y0; st_q += y0 * y0; }
+      if (r1l < OUTR && out0 + r1l < a.M) { st_s += y1; st_q += y1 * y1; }
+      Xa[r0l * V2_C + ncol] = f2bf(y0);
+      Xa[r1l * V2_C + ncol] = f2bf(y1);
+    }
+    __syncthreads();   // (4)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = rq + 16 * q, gr = out0 + o;
+      if (!(V2_DBG_SKIP & 4) && o < OUTR && gr < a.M)
+        *reinterpret_cast<uint4*>(a.Y + (size_t)gr * V2_C + c0) = *reinterpret_cast<const uint4*>(Xa + o * V2_C + c0);
+    }
+  }
+  if (a.stats) {
+    st_s += __shfl_xor(st_s, 32, 64);
+    st_q += __shfl_xor(st_q, 32, 64);
+    if (lane < 32) {
+      const int rep = blockIdx.x % TN_NREP;
+      atomic_add_f32(&a.stats[(size_t)(rep * 2 + 0) * V2_C + ncol], st_s);
+      atomic_add_f32(&a.stats[(size_t)(rep * 2 + 1) * V2_C + ncol], st_q);
+    }
+  }
+}
+
+template <int KD, bool DW>
+inline int launch_sub_fwd_v2(SubFwdV2Args a, int resident_wgs, hipStream_t st) {
+  constexpr int OUTR = DW ? V2_R - (KD - 1) : V2_R;
+  a.ntiles = (a.M + OUTR - 1) / OUTR;
+  const int grid = a.ntiles < resident_wgs ? a.ntiles : resident_wgs;
+  const size_t smem = (size_t)(V2_R * V2_C + V2_R * V2_AP) * sizeof(bf16_t);
+  auto kern = sub_fwd_v2_kernel<KD, DW>;
+  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
+  return (int)hipGetLastError();
+}
