@@ -160,6 +160,10 @@ def main():
         esz = 2 if args.precision == "bf16" else 4
         rows = args.batch * T
         kbytes = kernel_algorithmic_bytes(dom, rows, 256, esz)
+        # the v2 weight-gradient kernel covers all 17 x (3 sub-blocks + skip) pointwise layers in one launch
+        per_step = cnt.value / max(args.steps, 1)
+        if dom == 2 and per_step < 17 * 3:
+            kbytes = int(kbytes * (17 * 4) / max(per_step, 1))
         avg_s = (ms.value / 1e3) / max(cnt.value, 1)
         achieved = kbytes / avg_s / 1e9
         value = args.batch * world * args.steps / dt

@@ -178,6 +178,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   for (int i = 0; i < m->n_bn; ++i) p->stats[i] = b.take((size_t)TN_NREP * 2 * m->all_bn[i].C * sizeof(float));
   for (int i = 0; i < m->n_bn; ++i) p->bsums[i] = b.take((size_t)TN_NREP * 2 * m->all_bn[i].C * sizeof(float));
   p->loss_acc = b.take(256);
+  p->wg2_count = b.take(sizeof(int) * (size_t)(c.n_mega_blocks * (c.n_sub_blocks + 1) + 1));
   p->zero_bytes = ((b.off + 255) & ~(size_t)255) - p->zero_begin;
   // ---- compute-precision weights
   auto wc = [&](size_t n, size_t k) { WcRef r; r.w = b.take(n * k * e); r.wt = b.take(n * k * e); return r; };
@@ -198,6 +199,8 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     bw.g = b.take((size_t)batch * H * 4);
     bw.dpre2 = b.take((size_t)batch * H * 4);
     bw.dpre1 = b.take((size_t)batch * Hr * 4);
+    for (int j = 0; j < c.n_sub_blocks; ++j) bw.dY.push_back(b.take(M * H * e));
+    bw.dZk = b.take(M * H * e);
   }
   p->E = b.take(M * D * e);
   p->HID = b.take(M * A * e);
@@ -232,6 +235,17 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     size_t biggest = std::max({H * H, D * H, D * A, H * (size_t)c.n_mels * c.prolog_kernel});
     p->slab_bytes = biggest * sizeof(float) * 64;   // up to 64 K-splits
     p->slabs = b.take(p->slab_bytes);
+  }
+  if (p->use_v2) {
+    p->wg2_layers = c.n_mega_blocks * (c.n_sub_blocks + 1);
+    p->wg2_grid = 256;
+    const int chunks = (p->M + 31) / 32;
+    const long total = (long)p->wg2_layers * chunks;
+    p->wg2_units_per_wg = (int)((total + p->wg2_grid - 1) / p->wg2_grid);
+    p->wg2_maxparts = (chunks + p->wg2_units_per_wg - 1) / p->wg2_units_per_wg + 1;
+    p->wg2_slabs = b.take((size_t)p->wg2_layers * p->wg2_maxparts * 256 * 256 * sizeof(float));
+    p->wg2_desc = b.take((size_t)p->wg2_layers * 256);   // >= sizeof(WgradV2Desc) each (checked at upload)
+    p->wg2_out = b.take((size_t)p->wg2_layers * 16);
   }
   p->cast_table = b.take(sizeof(CastDesc) * (8 + (size_t)c.n_mega_blocks * (c.n_sub_blocks + 1)));
   p->bn_table = b.take(sizeof(BnUpdateDesc) * m->n_bn);

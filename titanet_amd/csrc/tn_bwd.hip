@@ -6,6 +6,7 @@
 
 #include "tn_bwd_kernels.h"
 #include "tn_internal.h"
+#include "tn_v2_bwd_kernels.h"
 
 namespace {
 
@@ -60,6 +61,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   auto wt = [&](const WcRef& r) -> const void* { return ws + r.wt; };
 
   TN_CHECK_HIP(hipMemsetAsync(grads, 0, (size_t)m->n_params * sizeof(float), st));
+  const bool batched_wgrad = sizeof(AT) == 2 && (p->use_v2 & 4) && training && p->wg2_layers > 0;
 
   // ================= loss head -> d emb =================
   {
@@ -176,20 +178,21 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       auto k1 = combine_bwd1_kernel<AT>;
       if (smem > 64 * 1024) TN_CHECK_HIP(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
       hipLaunchKernelGGL(k1, dim3(B), dim3(512), smem, st, (const AT*)(ws + p->dA[cur]), (const AT*)(ws + bw.OUT),
-                         (const AT*)(ws + bw.Y[nsub - 1]), act3, (const AT*)(ws + bw.S), acts, T, H, inv_keep, (AT*)(ws + p->dZ),
+                         (const AT*)(ws + bw.Y[nsub - 1]), act3, (const AT*)(ws + bw.S), acts, T, H, inv_keep, (AT*)(ws + bw.dZk),
                          (float*)(ws + bw.dpre2), bsum(mb.bnskip));
       smem = (size_t)(7 * H + ((Hr + 3) & ~3) + TG * 2 * H) * sizeof(float);
       auto k2 = combine_bwd2_kernel<AT>;
       if (smem > 64 * 1024) TN_CHECK_HIP(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      hipLaunchKernelGGL(k2, dim3(B), dim3(512), smem, st, (const AT*)(ws + p->dZ), (const AT*)(ws + bw.Y[nsub - 1]), act3,
+      hipLaunchKernelGGL(k2, dim3(B), dim3(512), smem, st, (const AT*)(ws + bw.dZk), (const AT*)(ws + bw.Y[nsub - 1]), act3,
                          (const float*)(ws + bw.g), (const float*)(ws + bw.h), (float*)(ws + bw.dpre2), (float*)(ws + bw.dpre1),
-                         params + mb.se_w1, params + mb.se_w2, T, H, Hr, (AT*)(ws + p->dYbn), bsum(mb.sub[nsub - 1].bn));
+                         params + mb.se_w1, params + mb.se_w2, T, H, Hr, (AT*)(ws + bw.dY[nsub - 1]), bsum(mb.sub[nsub - 1].bn));
     }
     // ---- skip connection: d S = BN-backward(dZ); dXs = dS * W_skip; d W_skip = dS^T X
     {
-      ProdDy::Args pa{ws + p->dZ, ws + bw.S, H, make_bnbwd(p, mb.bnskip, M, training)};
+      ProdDy::Args pa{ws + bw.dZk, ws + bw.S, H, make_bnbwd(p, mb.bnskip, M, training)};
       ProdPlain::Args qa{xin, H, actx};
-      int rc = launch_wgrad<AT, ProdDy, ProdPlain>(M, H, H, pa, qa, 0, slabs, p->slab_bytes, grads + mb.wskip, st);
+      int rc = 0;
+      if (!batched_wgrad) rc = launch_wgrad<AT, ProdDy, ProdPlain>(M, H, H, pa, qa, 0, slabs, p->slab_bytes, grads + mb.wskip, st);
       if (rc) return rc;
       GemmShape g{M, H, H, wt(bw.wskip)};
       EpiStoreArgs ea{ws + p->dXs, H, nullptr, nullptr};
@@ -201,8 +204,8 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       const SubBlockRef& sb = mb.sub[j];
       const void* sin = j > 0 ? (const void*)(ws + bw.Y[j - 1]) : xin;
       BnAct asin = j > 0 ? make_act(p, mb.sub[j - 1].bn, M, training, 1, pd, seed, i * (nsub + 1) + j - 1) : actx;
-      ProdDy::Args pa{ws + p->dYbn, ws + bw.Y[j], H, make_bnbwd(p, sb.bn, M, training)};
-      {
+      ProdDy::Args pa{ws + bw.dY[j], ws + bw.Y[j], H, make_bnbwd(p, sb.bn, M, training)};
+      if (!batched_wgrad) {
         ProdDw::Args qa{sin, H, asin, params + sb.wdw, params + sb.bdw, c.kernel, T};
         int rc = launch_wgrad<AT, ProdDy, ProdDw>(M, H, H, pa, qa, c.kernel, slabs, p->slab_bytes, grads + sb.wpw, st, p,
                                                   TN_PROF_BWD_WGRAD);
@@ -229,7 +232,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       da.M = M; da.T = T; da.C = H;
       if (j > 0) {
         da.ADD = nullptr;
-        da.OUT = ws + p->dYbn;
+        da.OUT = ws + bw.dY[j - 1];
         da.bsumsX = bsum(mb.sub[j - 1].bn);
       } else {
         da.ADD = ws + p->dXs;
@@ -262,6 +265,20 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       hipLaunchKernelGGL(prolog_input_grad_kernel<AT>, dim3((n + 255) / 256), dim3(256), 0, st, (const AT*)(ws + p->dA[cur]),
                          (const AT*)(ws + p->Y0), pa.bn, params + m->prolog_w, B, c.n_mels, T, H, c.prolog_kernel, grad_input);
     }
+  }
+  // ================= all mega-block pointwise weight gradients in one launch (v2) =================
+  if (batched_wgrad) {
+    const int chunks = (M + 31) / 32;
+    const size_t smem = (size_t)(2 * WG2_RK * WG2_PITCH + (WG2_RK + 2) * V2_C) * sizeof(bf16_t) + (size_t)(6 + 3) * V2_C * sizeof(float);
+    auto kern = wgrad_batched_v2_kernel<3>;
+    TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    {
+      ProfScope ps(p, TN_PROF_BWD_WGRAD, st);
+      hipLaunchKernelGGL(kern, dim3(p->wg2_grid), dim3(V2_NT), smem, st, (const WgradV2Desc*)(ws + p->wg2_desc), p->wg2_layers, M, T,
+                         chunks, p->wg2_units_per_wg, (int*)(ws + p->wg2_count), seed);
+    }
+    hipLaunchKernelGGL(wgrad_v2_reduce_kernel, dim3(32, p->wg2_layers), dim3(256), 0, st, (const WgradV2Out*)(ws + p->wg2_out),
+                       (const int*)(ws + p->wg2_count));
   }
   // ================= gradients that are functions of the accumulated sums =================
   hipLaunchKernelGGL(bn_param_grad_kernel, dim3(2, m->n_bn), dim3(256), 0, st,
@@ -314,6 +331,49 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
   }
   if (!sd.empty())
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->se_table, sd.data(), sd.size() * sizeof(SeGradDesc), hipMemcpyHostToDevice, st));
+  if (p->use_v2 && p->wg2_layers > 0) {
+    const tn_config& c = m->cfg;
+    const int nsub = c.n_sub_blocks, M = p->M;
+    std::vector<WgradV2Desc> wd;
+    std::vector<WgradV2Out> wo;
+    const size_t slab_stride = (size_t)p->wg2_maxparts * 256 * 256;
+    auto add = [&](size_t dz, size_t y, const BnRef& bn, const void* x, const BnAct& ax, int drop_layer, int64_t wdw, int64_t bdw,
+                   int64_t wout) {
+      WgradV2Desc d;
+      memset(&d, 0, sizeof(d));
+      d.dZ = (const bf16_t*)(p->ws + dz);
+      d.Y = (const bf16_t*)(p->ws + y);
+      d.fstats = (const float*)(p->ws + p->stats[bn.id]);
+      d.bsums = (const float*)(p->ws + p->bsums[bn.id]);
+      d.gamma = p->params + bn.gamma;
+      d.inv_n = 1.f / (float)M; d.eps = 1e-5f; d.batch = 1.f;
+      d.X = (const bf16_t*)x;
+      d.actX = ax;
+      d.drop_layer = drop_layer;
+      d.wdw = wdw >= 0 ? p->params + wdw : nullptr;
+      d.bdw = bdw >= 0 ? p->params + bdw : nullptr;
+      d.slabs = (float*)(p->ws + p->wg2_slabs) + wd.size() * slab_stride;
+      WgradV2Out o{d.slabs, p->grads + wout};
+      wd.push_back(d);
+      wo.push_back(o);
+    };
+    const float pd = c.dropout;
+    for (int i = 0; i < c.n_mega_blocks; ++i) {
+      const MegaBlockRef& mb = m->blocks[i];
+      const BlockWs& bw = p->blk[i];
+      const void* xin = i > 0 ? (const void*)(p->ws + p->blk[i - 1].OUT) : (const void*)(p->ws + p->Y0);
+      BnAct actx = i > 0 ? identity_act() : make_act(p, m->prolog_bn, M, 1, 1, 0.f, 0, 0);
+      add(bw.dZk, bw.S, mb.bnskip, xin, actx, 0, -1, -1, mb.wskip);
+      for (int j = 0; j < nsub; ++j) {
+        const void* sin = j > 0 ? (const void*)(p->ws + bw.Y[j - 1]) : xin;
+        BnAct asin = j > 0 ? make_act(p, mb.sub[j - 1].bn, M, 1, 1, pd, 0, 0) : actx;
+        add(bw.dY[j], bw.Y[j], mb.sub[j].bn, sin, asin, i * (nsub + 1) + j - 1, mb.sub[j].wdw, mb.sub[j].bdw, mb.sub[j].wpw);
+      }
+    }
+    if (sizeof(WgradV2Desc) > 256 || sizeof(WgradV2Out) > 16) return TN_E_STATE;
+    TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_desc, wd.data(), wd.size() * sizeof(WgradV2Desc), hipMemcpyHostToDevice, st));
+    TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_out, wo.data(), wo.size() * sizeof(WgradV2Out), hipMemcpyHostToDevice, st));
+  }
   TN_CHECK_HIP(hipStreamSynchronize(st));
   return 0;
 }

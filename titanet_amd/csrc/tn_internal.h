@@ -66,6 +66,9 @@ struct BlockWs {
   WcRef wskip;
   // backward (float): SE pre-activation grads
   size_t dpre2, dpre1;
+  // per-layer activation gradients kept for the batched weight-gradient launch (v2)
+  std::vector<size_t> dY;   // d loss / d BN-output of sub-block j
+  size_t dZk;               // d loss / d BN-output of the skip connection
 };
 
 struct tn_plan {
@@ -105,6 +108,8 @@ struct tn_plan {
   size_t slabs;        // split-K partial weight gradients
   size_t slab_bytes = 0;
   size_t bwd_table, bwd_table_eval, se_table;
+  size_t wg2_desc, wg2_out, wg2_count, wg2_slabs;   // batched weight-gradient launch (v2)
+  int wg2_layers = 0, wg2_maxparts = 0, wg2_units_per_wg = 0, wg2_grid = 0;
   size_t bwd_table_bytes = 0;
   // per-kernel event timing (tn_profile_*)
   int prof_class = 0;

@@ -24,6 +24,8 @@
 #define V2_R 64             // raw rows per tile
 #define V2_AP (V2_C + 8)    // padded pitch of MFMA operand tiles (conflict-free ds_read_b128)
 #define V2_NT 512
+#define WG2_RK 32
+#define WG2_PITCH 288      // 576-byte rows: the 4 rows of a transpose read land on distinct banks
 #ifndef V2_DBG_SKIP
 #define V2_DBG_SKIP 0   // tuning only: 1 skip MFMA, 2 skip stencil, 4 skip global stores, 8 skip act
 #endif
@@ -230,3 +232,4 @@ inline int launch_sub_fwd_v2(SubFwdV2Args a, int resident_wgs, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
   return (int)hipGetLastError();
 }
+
