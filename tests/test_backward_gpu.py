@@ -146,12 +146,12 @@ def test_grad_accumulation_and_zero_grad_semantics():
     p = next(m.parameters())
     ga = p.grad.clone()
     m(xc, speakers=yc)[2].backward()        # second backward accumulates (torch semantics)
-    assert torch.allclose(p.grad, 2 * ga, rtol=1e-4, atol=1e-7)
+    assert rel_err(p.grad.cpu().numpy(), 2 * ga.cpu().numpy()) < 1e-5   # (atomics reorder fp32 sums: not bitwise)
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
     opt.zero_grad()                          # set_to_none=True
     assert p.grad is None
     m(xc, speakers=yc)[2].backward()
-    assert torch.allclose(p.grad, ga, rtol=1e-4, atol=1e-7)
+    assert rel_err(p.grad.cpu().numpy(), ga.cpu().numpy()) < 1e-5
     before = m.flat_parameters().clone()
     opt.step()
     assert not torch.equal(before, m.flat_parameters())

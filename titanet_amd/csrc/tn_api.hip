@@ -163,8 +163,8 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   p->esz = precision == TN_PREC_BF16 ? 2 : 4;
   {
     const char* e = getenv("TN_V2");
-    // TN_V2 = bit mask (debug / A-B): 1 forward sub-block, 2 forward skip conv, 4 backward kernels; default all
-    const int mask = e ? atoi(e) : 7;
+    // TN_V2 = bit mask (debug / A-B): 1 forward sub-block, 2 forward skip conv, 4 batched weight gradients, 8 fused data-gradient kernel; default all
+    const int mask = e ? atoi(e) : 15;
     p->use_v2 = (precision == TN_PREC_BF16 && m->cfg.hidden == 256 && m->cfg.kernel == 3) ? mask : 0;
   }
   const tn_config& c = m->cfg;

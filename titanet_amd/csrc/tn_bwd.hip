@@ -62,6 +62,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
 
   TN_CHECK_HIP(hipMemsetAsync(grads, 0, (size_t)m->n_params * sizeof(float), st));
   const bool batched_wgrad = sizeof(AT) == 2 && (p->use_v2 & 4) && training && p->wg2_layers > 0;
+  const bool v2_bwd = sizeof(AT) == 2 && (p->use_v2 & 8);
 
   // ================= loss head -> d emb =================
   {
@@ -194,9 +195,17 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       int rc = 0;
       if (!batched_wgrad) rc = launch_wgrad<AT, ProdDy, ProdPlain>(M, H, H, pa, qa, 0, slabs, p->slab_bytes, grads + mb.wskip, st);
       if (rc) return rc;
-      GemmShape g{M, H, H, wt(bw.wskip)};
-      EpiStoreArgs ea{ws + p->dXs, H, nullptr, nullptr};
-      rc = gemm_any<AT, ProdDy, EpiStore>(g, pa, ea, st);
+      if (v2_bwd) {
+        SubBwdV2Args va;
+        memset(&va, 0, sizeof(va));
+        va.dZ = (const bf16_t*)(ws + bw.dZk); va.Y = (const bf16_t*)(ws + bw.S); va.bn = pa.bn;
+        va.Wt = (const bf16_t*)(ws + bw.wskip.wt); va.OUT = (bf16_t*)(ws + p->dXs); va.M = M; va.T = T;
+        rc = launch_sub_bwd_v2<1, false>(va, 256, st);
+      } else {
+        GemmShape g{M, H, H, wt(bw.wskip)};
+        EpiStoreArgs ea{ws + p->dXs, H, nullptr, nullptr};
+        rc = gemm_any<AT, ProdDy, EpiStore>(g, pa, ea, st);
+      }
       if (rc) return rc;
     }
     // ---- sub-blocks, last to first
@@ -210,6 +219,36 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         int rc = launch_wgrad<AT, ProdDy, ProdDw>(M, H, H, pa, qa, c.kernel, slabs, p->slab_bytes, grads + sb.wpw, st, p,
                                                   TN_PROF_BWD_WGRAD);
         if (rc) return rc;
+      }
+      if (v2_bwd) {
+        // (A) pointwise data gradient dD = BN-backward(dZ, Y) * W   (persistent MFMA kernel, W^T in registers)
+        SubBwdV2Args va;
+        memset(&va, 0, sizeof(va));
+        va.dZ = (const bf16_t*)(ws + bw.dY[j]); va.Y = (const bf16_t*)(ws + bw.Y[j]); va.bn = pa.bn;
+        va.Wt = (const bf16_t*)(ws + bw.wpw[j].wt); va.OUT = (bf16_t*)(ws + p->dD); va.M = M; va.T = T;
+        int rc;
+        {
+          ProfScope ps(p, TN_PROF_BWD_DGRAD, st);
+          rc = launch_sub_bwd_v2<1, false>(va, 256, st);
+        }
+        if (rc) return rc;
+        // (B) depthwise backward + activation backward + BN sums (streaming kernel)
+        DwBwdV3Args da;
+        memset(&da, 0, sizeof(da));
+        da.dD = (const bf16_t*)(ws + p->dD); da.X = (const bf16_t*)sin; da.actX = asin;
+        da.wdw = params + sb.wdw; da.g_wdw = grads + sb.wdw; da.g_bdw = grads + sb.bdw; da.M = M; da.T = T;
+        if (j > 0) {
+          da.ADD = nullptr; da.OUT = (bf16_t*)(ws + bw.dY[j - 1]); da.bsumsX = bsum(mb.sub[j - 1].bn);
+        } else {
+          da.ADD = (const bf16_t*)(ws + p->dXs); da.OUT = (bf16_t*)(ws + p->dA[cur ^ 1]);
+          da.bsumsX = (i == 0) ? bsum(m->prolog_bn) : nullptr;
+        }
+        {
+          ProfScope ps(p, TN_PROF_BWD_DW, st);
+          rc = launch_dw_bwd_v3<3>(da, 512, st);
+        }
+        if (rc) return rc;
+        continue;
       }
       {
         GemmShape g{M, H, H, wt(bw.wpw[j])};
