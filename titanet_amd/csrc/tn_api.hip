@@ -179,6 +179,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   for (int i = 0; i < m->n_bn; ++i) p->bsums[i] = b.take((size_t)TN_NREP * 2 * m->all_bn[i].C * sizeof(float));
   p->loss_acc = b.take(256);
   p->wg2_count = b.take(sizeof(int) * (size_t)(c.n_mega_blocks * (c.n_sub_blocks + 1) + 1));
+  p->dw_gacc = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * TN_NREP * (c.kernel + 1) * H * sizeof(float));
   p->zero_bytes = ((b.off + 255) & ~(size_t)255) - p->zero_begin;
   // ---- compute-precision weights
   auto wc = [&](size_t n, size_t k) { WcRef r; r.w = b.take(n * k * e); r.wt = b.take(n * k * e); return r; };
@@ -246,6 +247,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     p->wg2_slabs = b.take((size_t)p->wg2_layers * p->wg2_maxparts * 256 * 256 * sizeof(float));
     p->wg2_desc = b.take((size_t)p->wg2_layers * 256);   // >= sizeof(WgradV2Desc) each (checked at upload)
     p->wg2_out = b.take((size_t)p->wg2_layers * 16);
+    p->dw_table = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * 32);
   }
   p->cast_table = b.take(sizeof(CastDesc) * (8 + (size_t)c.n_mega_blocks * (c.n_sub_blocks + 1)));
   p->bn_table = b.take(sizeof(BnUpdateDesc) * m->n_bn);

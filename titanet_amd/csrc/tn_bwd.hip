@@ -236,7 +236,8 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         DwBwdV3Args da;
         memset(&da, 0, sizeof(da));
         da.dD = (const bf16_t*)(ws + p->dD); da.X = (const bf16_t*)sin; da.actX = asin;
-        da.wdw = params + sb.wdw; da.g_wdw = grads + sb.wdw; da.g_bdw = grads + sb.bdw; da.M = M; da.T = T;
+        da.wdw = params + sb.wdw; da.M = M; da.T = T;
+        da.gacc = (float*)(ws + p->dw_gacc) + (size_t)(i * nsub + j) * TN_NREP * (c.kernel + 1) * H;
         if (j > 0) {
           da.ADD = nullptr; da.OUT = (bf16_t*)(ws + bw.dY[j - 1]); da.bsumsX = bsum(mb.sub[j - 1].bn);
         } else {
@@ -304,6 +305,9 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       hipLaunchKernelGGL(prolog_input_grad_kernel<AT>, dim3((n + 255) / 256), dim3(256), 0, st, (const AT*)(ws + p->dA[cur]),
                          (const AT*)(ws + p->Y0), pa.bn, params + m->prolog_w, B, c.n_mels, T, H, c.prolog_kernel, grad_input);
     }
+  }
+  if (v2_bwd && nb > 0) {
+    hipLaunchKernelGGL(dw_grad_finalize_kernel, dim3(nb * nsub), dim3(256), 0, st, (const DwGradOut*)(ws + p->dw_table), c.kernel);
   }
   // ================= all mega-block pointwise weight gradients in one launch (v2) =================
   if (batched_wgrad) {
@@ -412,6 +416,17 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
     if (sizeof(WgradV2Desc) > 256 || sizeof(WgradV2Out) > 16) return TN_E_STATE;
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_desc, wd.data(), wd.size() * sizeof(WgradV2Desc), hipMemcpyHostToDevice, st));
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_out, wo.data(), wo.size() * sizeof(WgradV2Out), hipMemcpyHostToDevice, st));
+    std::vector<DwGradOut> dg;
+    for (int i = 0; i < c.n_mega_blocks; ++i)
+      for (int j = 0; j < nsub; ++j) {
+        DwGradOut o;
+        o.gacc = (const float*)(p->ws + p->dw_gacc) + (size_t)(i * nsub + j) * TN_NREP * (c.kernel + 1) * c.hidden;
+        o.g_wdw = p->grads + m->blocks[i].sub[j].wdw;
+        o.g_bdw = p->grads + m->blocks[i].sub[j].bdw;
+        dg.push_back(o);
+      }
+    if (sizeof(DwGradOut) > 32) return TN_E_STATE;
+    TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->dw_table, dg.data(), dg.size() * sizeof(DwGradOut), hipMemcpyHostToDevice, st));
   }
   TN_CHECK_HIP(hipStreamSynchronize(st));
   return 0;

@@ -484,29 +484,55 @@ struct DwBwdV3Args {
   const bf16_t* ADD;   // or null
   bf16_t* OUT;
   const float* wdw;
-  float* g_wdw;
-  float* g_bdw;
+  float* gacc;         // [TN_NREP][KD + 1][256] replicated accumulators of d w_dw (k-major) and d b_dw (pre-zeroed)
   float* bsumsX;       // or null
   int M, T, ntiles;
 };
 
+// 4 channels per thread, one wave per 8-row strip (all lanes of a wave share the row, so the utterance
+// boundary tests are wave-uniform scalar branches), 512 threads per 64-row tile, <= 128 VGPRs so that two
+// workgroups (16 waves) share a CU and hide each other's LDS / VALU latency.
+__device__ __forceinline__ void unpack4(const uint2& a, float v[4]) {
+  v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+  v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+}
+__device__ __forceinline__ void act4_reg(float v[4], const float sc[4], const float sh[4], const BnAct& a, uint32_t row, int c0) {
+  if (a.mode != 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = v[i] * sc[i] + sh[i];
+  }
+  if (a.relu) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+  }
+  if (a.drop_thr) {
+    const uint32_t pair = (row * (uint32_t)V2_C + (uint32_t)c0) >> 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t k = tn_keep_pair(pair + i, a.drop_key, a.drop_thr);
+      v[2 * i] = (k & 1u) ? v[2 * i] * a.inv_keep : 0.f;
+      v[2 * i + 1] = (k & 2u) ? v[2 * i + 1] * a.inv_keep : 0.f;
+    }
+  }
+}
+
 template <int KD>
-__global__ __launch_bounds__(256, 2) void dw_bwd_v3_kernel(DwBwdV3Args a) {
-  constexpr int PADR = (KD - 1) / 2, ROWS = 64 + KD - 1, NT = 256;
+__global__ __launch_bounds__(512, 4) void dw_bwd_v3_kernel(DwBwdV3Args a) {
+  constexpr int PADR = (KD - 1) / 2, ROWS = 64 + KD - 1, NT = 512;
   static_assert(KD == 3, "sliding window below is written for K = 3");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* Ds = reinterpret_cast<bf16_t*>(smem);     // [ROWS][256] raw dD
   bf16_t* Xs = Ds + ROWS * V2_C;                     // [ROWS][256] raw X
   float* cst = reinterpret_cast<float*>(Xs + ROWS * V2_C);   // sc, sh, mean, rstd, wd[KD] : [4 + KD][256]; later the reduction scratch
   const int tid = threadIdx.x;
-  const int vc = tid & 31, strip = tid >> 5, c0 = vc * 8;
+  const int lane = tid & 63, strip = tid >> 6, c0 = lane * 4;
   const bool has_bn = a.actX.mode != 0;
   const bool has_mask = has_bn || a.actX.relu || a.actX.drop_thr;
   const float mscale = a.actX.drop_thr ? a.actX.inv_keep : 1.f;
 
-  {
+  if (tid < V2_C) {
     float s = 1.f, h = 0.f, mean = 0.f, rstd = 1.f;
-    if (has_bn) {
+    if (has_bn && !(V2_DBG_SKIP & 64)) {
       bn_scale_shift(a.actX, V2_C, tid, s, h);
       bn_mean_rstd(a.actX, V2_C, tid, mean, rstd);
     }
@@ -515,22 +541,22 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_v3_kernel(DwBwdV3Args a) {
     for (int k = 0; k < KD; ++k) cst[(4 + k) * V2_C + tid] = a.wdw[(size_t)tid * KD + k];
   }
   __syncthreads();
-  float sc[8], sh[8], mean[8], rstd[8], wd[KD][8];
+  float sc[4], sh[4], mean[4], rstd[4], wd[KD][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 4; ++i) {
     sc[i] = cst[c0 + i]; sh[i] = cst[V2_C + c0 + i]; mean[i] = cst[2 * V2_C + c0 + i]; rstd[i] = cst[3 * V2_C + c0 + i];
 #pragma unroll
     for (int k = 0; k < KD; ++k) wd[k][i] = cst[(4 + k) * V2_C + c0 + i];
   }
-  float gw[KD][8], gb[8], s1[8], s2[8];
+  float gw[KD][4], gb[4], s1[4], s2[4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 4; ++i) {
     gb[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f;
 #pragma unroll
     for (int k = 0; k < KD; ++k) gw[k][i] = 0.f;
   }
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  for (int tile = blockIdx.x; tile < ((V2_DBG_SKIP & 16) ? 0 : a.ntiles); tile += gridDim.x) {
     const int out0 = tile * 64, raw0 = out0 - PADR;
     __syncthreads();
     // ---- stage the raw tiles: all loads of the tile are issued before any is consumed
@@ -552,89 +578,111 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_v3_kernel(DwBwdV3Args a) {
       }
     }
     __syncthreads();
-    // ---- sliding window over this thread's 8 output rows
+    // ---- sliding window over this wave's 8 output rows
     const int l0 = strip * 8;            // LDS row of (first output row - PADR)
-    float Dp[8], Dc[8], Dn[8], Ap[8], Ac[8], An[8];
+    float Dp[4], Dc[4], Dn[4], Ap[4], Ac[4], An[4];
     auto load_row = [&](int l, float* D, float* A) {
-      load8(Ds + l * V2_C + c0, D);
-      load8(Xs + l * V2_C + c0, A);
+      unpack4(*reinterpret_cast<const uint2*>(Ds + l * V2_C + c0), D);
+      unpack4(*reinterpret_cast<const uint2*>(Xs + l * V2_C + c0), A);
       const int gr = raw0 + l;
-      if (gr >= 0 && gr < a.M) act8_reg(A, sc, sh, a.actX, (uint32_t)gr, c0);
+      if (gr >= 0 && gr < a.M) act4_reg(A, sc, sh, a.actX, (uint32_t)gr, c0);
       else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) A[i] = 0.f;
+        for (int i = 0; i < 4; ++i) A[i] = 0.f;
       }
     };
     load_row(l0, Dp, Ap);
     load_row(l0 + 1, Dc, Ac);
-    uint4 addn = make_uint4(0, 0, 0, 0);
-    if (a.ADD && out0 + l0 < a.M) addn = *reinterpret_cast<const uint4*>(a.ADD + (size_t)(out0 + l0) * V2_C + c0);
+    uint2 addn = make_uint2(0, 0);
+    if (a.ADD && out0 + l0 < a.M) addn = *reinterpret_cast<const uint2*>(a.ADD + (size_t)(out0 + l0) * V2_C + c0);
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
-      const int gr = out0 + l0 + o;       // global output row
+      const int gr = out0 + l0 + o;       // global output row (wave-uniform)
       load_row(l0 + o + 2, Dn, An);
-      const uint4 addc = addn;
-      if (a.ADD && o + 1 < 8 && gr + 1 < a.M) addn = *reinterpret_cast<const uint4*>(a.ADD + (size_t)(gr + 1) * V2_C + c0);
+      const uint2 addc = addn;
+      if (a.ADD && o + 1 < 8 && gr + 1 < a.M) addn = *reinterpret_cast<const uint2*>(a.ADD + (size_t)(gr + 1) * V2_C + c0);
       if (gr < a.M) {
         const int t = gr % a.T;
-        const bool vprev = t - 1 >= 0, vnext = t + 1 < a.T;
-        float dA[8];
+        float dA[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4; ++i) {
           gb[i] += Dc[i];
-          // data gradient: k = 0 -> dD[r + 1], k = 1 -> dD[r], k = 2 -> dD[r - 1]
-          float v = wd[1][i] * Dc[i];
-          if (vnext) v = fmaf(wd[0][i], Dn[i], v);
-          if (vprev) v = fmaf(wd[2][i], Dp[i], v);
-          dA[i] = v;
-          // weight gradient: k = 0 -> A[r - 1], k = 1 -> A[r], k = 2 -> A[r + 1]
+          dA[i] = wd[1][i] * Dc[i];
           gw[1][i] = fmaf(Dc[i], Ac[i], gw[1][i]);
-          if (vprev) gw[0][i] = fmaf(Dc[i], Ap[i], gw[0][i]);
-          if (vnext) gw[2][i] = fmaf(Dc[i], An[i], gw[2][i]);
+        }
+        if (t + 1 < a.T) {    // wave-uniform: next row belongs to the same utterance
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { dA[i] = fmaf(wd[0][i], Dn[i], dA[i]); gw[2][i] = fmaf(Dc[i], An[i], gw[2][i]); }
+        }
+        if (t > 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { dA[i] = fmaf(wd[2][i], Dp[i], dA[i]); gw[0][i] = fmaf(Dc[i], Ap[i], gw[0][i]); }
         }
         if (a.ADD) {
-          float ad[8];
-          unpack8(addc, ad);
+          float ad[4];
+          unpack4(addc, ad);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) dA[i] += ad[i];
+          for (int i = 0; i < 4; ++i) dA[i] += ad[i];
         }
         if (has_mask) {
-          float y[8];
-          load8(Xs + (l0 + o + 1) * V2_C + c0, y);
+          float y[4];
+          unpack4(*reinterpret_cast<const uint2*>(Xs + (l0 + o + 1) * V2_C + c0), y);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
+          for (int i = 0; i < 4; ++i) {
             const float m = a.actX.relu ? ((Ac[i] > 0.f) ? mscale : 0.f) : mscale;
             dA[i] *= m;
             s1[i] += dA[i];
             s2[i] += dA[i] * (y[i] - mean[i]) * rstd[i];
           }
         }
-        store8(a.OUT + (size_t)gr * V2_C + c0, dA);
+        uint2 ov;
+        ov.x = f2bf_pk(dA[0], dA[1]);
+        ov.y = f2bf_pk(dA[2], dA[3]);
+        *reinterpret_cast<uint2*>(a.OUT + (size_t)gr * V2_C + c0) = ov;
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { Dp[i] = Dc[i]; Dc[i] = Dn[i]; Ap[i] = Ac[i]; Ac[i] = An[i]; }
+      for (int i = 0; i < 4; ++i) { Dp[i] = Dc[i]; Dc[i] = Dn[i]; Ap[i] = Ac[i]; Ac[i] = An[i]; }
     }
   }
-  // ---- reductions: across the 8 strips through LDS atomics, then once to HBM
+  // ---- reductions: the 8 waves (row strips) hold the same channels -> plain LDS stores + a short sum,
+  // then COALESCED, 8-way replicated global atomics (LDS atomics with same-address traffic and strided,
+  // unreplicated global atomics made this epilogue cost more than the tiles themselves).
   __syncthreads();
-  for (int i = tid; i < (KD + 3) * V2_C; i += NT) cst[i] = 0.f;
-  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);       // [8 waves][KD + 3][256]
+  {
+    float* mine = red + (size_t)strip * (KD + 3) * V2_C + c0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-#pragma unroll
-    for (int k = 0; k < KD; ++k) atomicAdd(&cst[k * V2_C + c0 + i], gw[k][i]);
-    atomicAdd(&cst[KD * V2_C + c0 + i], gb[i]);
-    atomicAdd(&cst[(KD + 1) * V2_C + c0 + i], s1[i]);
-    atomicAdd(&cst[(KD + 2) * V2_C + c0 + i], s2[i]);
+    for (int k = 0; k < KD; ++k) *reinterpret_cast<float4*>(mine + k * V2_C) = make_float4(gw[k][0], gw[k][1], gw[k][2], gw[k][3]);
+    *reinterpret_cast<float4*>(mine + KD * V2_C) = make_float4(gb[0], gb[1], gb[2], gb[3]);
+    *reinterpret_cast<float4*>(mine + (KD + 1) * V2_C) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+    *reinterpret_cast<float4*>(mine + (KD + 2) * V2_C) = make_float4(s2[0], s2[1], s2[2], s2[3]);
   }
   __syncthreads();
   const int rep = blockIdx.x % TN_NREP;
-  for (int i = tid; i < (KD + 3) * V2_C; i += NT) {
+  for (int i = tid; i < ((V2_DBG_SKIP & 32) ? 0 : (KD + 3) * V2_C); i += NT) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += red[(size_t)w * (KD + 3) * V2_C + i];
     const int k = i / V2_C, c = i % V2_C;
-    const float v = cst[i];
-    if (k < KD) atomic_add_f32(&a.g_wdw[(size_t)c * KD + k], v);
-    else if (k == KD) atomic_add_f32(&a.g_bdw[c], v);
+    if (k <= KD) atomic_add_f32(&a.gacc[(size_t)(rep * (KD + 1) + k) * V2_C + c], v);
     else if (a.bsumsX && has_mask) atomic_add_f32(&a.bsumsX[(size_t)(rep * 2 + (k - KD - 1)) * V2_C + c], v);
+  }
+}
+
+// d w_dw[c][k] / d b_dw[c] of every depthwise layer from the replicated accumulators (one launch)
+struct DwGradOut {
+  const float* gacc;   // [TN_NREP][KD + 1][256]
+  float* g_wdw;        // [256][KD]
+  float* g_bdw;        // [256]
+};
+__global__ void dw_grad_finalize_kernel(const DwGradOut* __restrict__ outs, int KD) {
+  const DwGradOut o = outs[blockIdx.x];
+  for (int i = threadIdx.x; i < (KD + 1) * V2_C; i += blockDim.x) {
+    const int k = i / V2_C, c = i % V2_C;
+    float v = 0.f;
+    for (int r = 0; r < TN_NREP; ++r) v += o.gacc[(size_t)(r * (KD + 1) + k) * V2_C + c];
+    if (k < KD) o.g_wdw[(size_t)c * KD + k] = v;
+    else o.g_bdw[c] = v;
   }
 }
 
@@ -646,6 +694,6 @@ inline int launch_dw_bwd_v3(DwBwdV3Args a, int max_wgs, hipStream_t st) {
   const size_t smem = (size_t)2 * ROWS * V2_C * sizeof(bf16_t) + (size_t)(4 + KD) * V2_C * sizeof(float);
   auto kern = dw_bwd_v3_kernel<KD>;
   TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a);
   return (int)hipGetLastError();
 }

@@ -10,7 +10,7 @@ int main(int argc, char** argv) {
   bf16_t *dD, *X, *ADD, *OUT; float *stats, *gamma, *beta, *wdw, *gw, *gb, *bs;
   CK(hipMalloc(&dD, (size_t)M * C * 2)); CK(hipMalloc(&X, (size_t)M * C * 2)); CK(hipMalloc(&ADD, (size_t)M * C * 2)); CK(hipMalloc(&OUT, (size_t)M * C * 2));
   CK(hipMalloc(&stats, 8 * 2 * C * 4)); CK(hipMalloc(&gamma, C * 4)); CK(hipMalloc(&beta, C * 4)); CK(hipMalloc(&wdw, C * 3 * 4));
-  CK(hipMalloc(&gw, C * 3 * 4)); CK(hipMalloc(&gb, C * 4)); CK(hipMalloc(&bs, 8 * 2 * C * 4));
+  CK(hipMalloc(&gw, C * 3 * 4)); CK(hipMalloc(&gb, C * 4)); CK(hipMalloc(&bs, 8 * 2 * C * 4)); float* gacc; CK(hipMalloc(&gacc, 8 * 4 * C * 4)); CK(hipMemset(gacc, 0, 8 * 4 * C * 4));
   { std::vector<unsigned short> hx((size_t)M * C); for (size_t i = 0; i < hx.size(); ++i) hx[i] = (unsigned short)((0x3c00 + (i * 7919u) % 0x300) ^ ((i & 1) << 15));
     CK(hipMemcpy(X, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dD, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(ADD, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); }
   std::vector<float> ones(C * 3, 0.3f);
@@ -18,7 +18,7 @@ int main(int argc, char** argv) {
   { std::vector<float> hs(8 * 2 * C, 0.f); for (int c = 0; c < C; ++c) { hs[c] = 0.1f * M; hs[C + c] = 1.5f * M; } CK(hipMemcpy(stats, hs.data(), hs.size() * 4, hipMemcpyHostToDevice)); }
   CK(hipMemset(gw, 0, C * 3 * 4)); CK(hipMemset(gb, 0, C * 4)); CK(hipMemset(bs, 0, 8 * 2 * C * 4));
   DwBwdV3Args a; memset(&a, 0, sizeof(a));
-  a.dD = dD; a.X = X; a.ADD = nullptr; a.OUT = OUT; a.wdw = wdw; a.g_wdw = gw; a.g_bdw = gb; a.bsumsX = bs; a.M = M; a.T = T;
+  a.dD = dD; a.X = X; a.ADD = nullptr; a.OUT = OUT; a.wdw = wdw; a.gacc = gacc; a.bsumsX = bs; a.M = M; a.T = T;
   a.actX.stats = stats; a.actX.gamma = gamma; a.actX.beta = beta; a.actX.inv_n = 1.f / M; a.actX.eps = 1e-5f; a.actX.mode = 1; a.actX.relu = 1;
   a.actX.drop_thr = 6554; a.actX.drop_key = 12345; a.actX.inv_keep = 1.f / 0.9f;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
