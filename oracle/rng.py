@@ -3,13 +3,14 @@
 The reference draws dropout masks from torch's ``bernoulli_`` stream
 (``src/modules.py:133``, ``src/models.py:470-472``); that stream cannot be matched by any
 other implementation, so parity with dropout > 0 is checked against THIS restatement of
-the HIP kernels' counter-based generator (``titanet_amd/csrc/tn_common.h: tn_keep_pair``)
+the HIP kernels' counter-based generator (``titanet_amd/csrc/tn_common.h: tn_drop8``)
 while the statistical contract (keep rate 1-p, survivors scaled by 1/(1-p)) is what is
 checked against the reference semantics.
 
 Element index space: activations are stored rows x channels ("NTC": row = b*T + t), the
-element index is e = row*C + c, one 32-bit hash serves the element pair (e>>1): low 16 bits
--> even element, high 16 bits -> odd element; keep iff bits >= round(p * 65536).
+element index is e = row*C + c.  Each group of 8 consecutive elements shares one mixing round
+x = f(e>>3 + key); element pair j of the group takes h = x*C_j ^ (x*C_j >> 16): low 16 bits -> even
+element, high 16 bits -> odd element; keep iff bits >= round(p * 65536).
 """
 import numpy as np
 
@@ -41,13 +42,23 @@ def threshold(p):
     return int(round(float(p) * 65536.0))
 
 
+_DROP_C = np.array([0x846CA68B, 0x9E3779B1, 0x85EBCA77, 0xC2B2AE3D], dtype=np.uint32)
+
+
 def keep_mask_rows(seed, layer, rows, channels, p):
-    """bool [rows, channels] keep mask in the kernels' row-major (NTC) element order."""
+    """bool [rows, channels] keep mask in the kernels' row-major (NTC) element order
+    (restates tn_common.h: tn_drop_shared / tn_drop_final)."""
     n = rows * channels
     e = np.arange(n, dtype=np.uint64)
-    pair = (e >> np.uint64(1)).astype(np.uint32)
+    idx8 = (e >> np.uint64(3)).astype(np.uint32)
     with np.errstate(over="ignore"):
-        h = mix32(pair + layer_key(seed, layer))
+        x = idx8 + layer_key(seed, layer)
+        x ^= x >> np.uint32(16)
+        x *= _M1
+        x ^= x >> np.uint32(15)
+        c = _DROP_C[((e >> np.uint64(1)) & np.uint64(3)).astype(np.int64)]
+        h = x * c
+        h ^= h >> np.uint32(16)
     bits = np.where((e & np.uint64(1)) == 0, h & np.uint32(0xFFFF), h >> np.uint32(16))
     return (bits >= np.uint32(threshold(p))).reshape(rows, channels)
 

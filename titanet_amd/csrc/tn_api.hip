@@ -606,11 +606,7 @@ __global__ void fetch_bct_kernel(const AT* __restrict__ src, BnAct act, int M, i
     float v = Elem<AT>::to_f(src[i]);
     if (act.mode != 0) { float sc, sh; bn_scale_shift(act, C, c, sc, sh); v = v * sc + sh; }
     if (act.relu) v = fmaxf(v, 0.f);
-    if (act.drop_thr) {
-      const uint32_t e = (uint32_t)i;
-      const uint32_t k = tn_keep_pair(e >> 1, act.drop_key, act.drop_thr);
-      v = ((k >> (e & 1u)) & 1u) ? v * act.inv_keep : 0.f;
-    }
+    if (act.drop_thr && !tn_keep_elem((uint32_t)i, act.drop_key, act.drop_thr)) v = 0.f;   // (1/(1-p) is in sc, sh)
     const int b = row / T, t = row % T;
     dst[((size_t)b * C + c) * T + t] = v;
   }

@@ -102,10 +102,44 @@ __host__ __device__ __forceinline__ uint32_t tn_layer_key(uint64_t seed, uint32_
   uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
   return tn_mix32(lo ^ tn_mix32(hi + layer * 0x9E3779B9u + 1u));
 }
-// keep bits for the element pair (e, e+1), e even: bit0 -> element e, bit1 -> element e+1
-__device__ __forceinline__ uint32_t tn_keep_pair(uint32_t pair_index, uint32_t key, uint32_t thr) {
-  uint32_t h = tn_mix32(pair_index + key);
-  return ((h & 0xffffu) >= thr ? 1u : 0u) | ((h >> 16) >= thr ? 2u : 0u);
+// Keep decisions for the 8 consecutive elements 8*idx8 .. 8*idx8+7 (one shared mixing round per group
+// of 8, then one multiply-xorshift finaliser per element pair: 16 bits per element, keep iff >= thr).
+// The kernels are VALU-bound on exactly this arithmetic, hence the shared round.
+#define TN_DROP_C0 0x846ca68bu
+#define TN_DROP_C1 0x9e3779b1u
+#define TN_DROP_C2 0x85ebca77u
+#define TN_DROP_C3 0xc2b2ae3du
+__host__ __device__ __forceinline__ uint32_t tn_drop_shared(uint32_t idx8, uint32_t key) {
+  uint32_t x = idx8 + key;
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t tn_drop_final(uint32_t x, uint32_t c) {
+  uint32_t h = x * c;
+  return h ^ (h >> 16);    // low 16 bits -> even element, high 16 bits -> odd element of the pair
+}
+// zero the dropped ones among 8 consecutive channels (no rescale: 1/(1-p) is folded into BN scale/shift)
+__device__ __forceinline__ void tn_drop8(float v[8], uint32_t idx8, uint32_t key, uint32_t thr) {
+  const uint32_t x = tn_drop_shared(idx8, key);
+  const uint32_t h0 = tn_drop_final(x, TN_DROP_C0), h1 = tn_drop_final(x, TN_DROP_C1);
+  const uint32_t h2 = tn_drop_final(x, TN_DROP_C2), h3 = tn_drop_final(x, TN_DROP_C3);
+  v[0] = ((h0 & 0xffffu) >= thr) ? v[0] : 0.f; v[1] = ((h0 >> 16) >= thr) ? v[1] : 0.f;
+  v[2] = ((h1 & 0xffffu) >= thr) ? v[2] : 0.f; v[3] = ((h1 >> 16) >= thr) ? v[3] : 0.f;
+  v[4] = ((h2 & 0xffffu) >= thr) ? v[4] : 0.f; v[5] = ((h2 >> 16) >= thr) ? v[5] : 0.f;
+  v[6] = ((h3 & 0xffffu) >= thr) ? v[6] : 0.f; v[7] = ((h3 >> 16) >= thr) ? v[7] : 0.f;
+}
+// the 4 channels 4*half .. 4*half+3 of the group
+__device__ __forceinline__ void tn_drop4(float v[4], uint32_t idx8, uint32_t half, uint32_t key, uint32_t thr) {
+  const uint32_t x = tn_drop_shared(idx8, key);
+  const uint32_t h0 = tn_drop_final(x, half ? TN_DROP_C2 : TN_DROP_C0), h1 = tn_drop_final(x, half ? TN_DROP_C3 : TN_DROP_C1);
+  v[0] = ((h0 & 0xffffu) >= thr) ? v[0] : 0.f; v[1] = ((h0 >> 16) >= thr) ? v[1] : 0.f;
+  v[2] = ((h1 & 0xffffu) >= thr) ? v[2] : 0.f; v[3] = ((h1 >> 16) >= thr) ? v[3] : 0.f;
+}
+__host__ __device__ __forceinline__ bool tn_keep_elem(uint32_t e, uint32_t key, uint32_t thr) {
+  const uint32_t x = tn_drop_shared(e >> 3, key);
+  const uint32_t cs[4] = {TN_DROP_C0, TN_DROP_C1, TN_DROP_C2, TN_DROP_C3};
+  const uint32_t h = tn_drop_final(x, cs[(e >> 1) & 3u]);
+  return ((e & 1u) ? (h >> 16) : (h & 0xffffu)) >= thr;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -148,6 +182,8 @@ __device__ __forceinline__ void bn_scale_shift(const BnAct& a, int C, int c, flo
   bn_mean_rstd(a, C, c, mean, rstd);
   sc = a.gamma[c] * rstd;
   sh = a.beta[c] - mean * sc;
+  // dropout survivors are scaled by 1/(1-p): relu commutes with a positive scale, so fold it in here
+  if (a.drop_thr) { sc *= a.inv_keep; sh *= a.inv_keep; }
 }
 
 // apply act to 8 consecutive channels of row `row` (element index = row*C + c0 + i)
@@ -161,34 +197,19 @@ __device__ __forceinline__ void act8(float v[8], const float* sc, const float* s
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
   }
-  if (a.drop_thr) {
-    uint32_t pair = (row * (uint32_t)C + (uint32_t)c0) >> 1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      uint32_t k = tn_keep_pair(pair + i, a.drop_key, a.drop_thr);
-      v[2 * i] = (k & 1u) ? v[2 * i] * a.inv_keep : 0.f;
-      v[2 * i + 1] = (k & 2u) ? v[2 * i + 1] * a.inv_keep : 0.f;
-    }
-  }
+  if (a.drop_thr) tn_drop8(v, (row * (uint32_t)C + (uint32_t)c0) >> 3, a.drop_key, a.drop_thr);
 }
 // mask-only variant for the backward pass: given the raw value's post-BN sign and the keep
 // bits, returns the multiplier d(act)/d(bn output) for each of the 8 channels.
 __device__ __forceinline__ void act8_grad_mask(const float raw[8], float m[8], const float* sc, const float* sh,
                                                const BnAct& a, uint32_t row, int C, int c0) {
+  const float on = a.drop_thr ? a.inv_keep : 1.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    float z = (a.mode != 0) ? raw[i] * sc[i] + sh[i] : raw[i];
-    m[i] = (!a.relu || z > 0.f) ? 1.f : 0.f;
+    float z = (a.mode != 0) ? raw[i] * sc[i] + sh[i] : raw[i];     // (sc, sh carry the 1/(1-p) factor: sign unchanged)
+    m[i] = (!a.relu || z > 0.f) ? on : 0.f;
   }
-  if (a.drop_thr) {
-    uint32_t pair = (row * (uint32_t)C + (uint32_t)c0) >> 1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      uint32_t k = tn_keep_pair(pair + i, a.drop_key, a.drop_thr);
-      m[2 * i] = (k & 1u) ? m[2 * i] * a.inv_keep : 0.f;
-      m[2 * i + 1] = (k & 2u) ? m[2 * i + 1] * a.inv_keep : 0.f;
-    }
-  }
+  if (a.drop_thr) tn_drop8(m, (row * (uint32_t)C + (uint32_t)c0) >> 3, a.drop_key, a.drop_thr);
 }
 
 // ------------------------------------------------------------------------------------------

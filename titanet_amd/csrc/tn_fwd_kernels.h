@@ -126,13 +126,9 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(const AT* __restrict__
 #pragma unroll
     for (int q = 0; q < 8; ++q) o[q] = fmaxf(s[q] * scS[c0 + q] + shS[c0 + q] + g[q] * y[q], 0.f);
     if (drop_thr) {
-      const uint32_t pair = ((uint32_t)row * (uint32_t)C + (uint32_t)c0) >> 1;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t k = tn_keep_pair(pair + q, drop_key, drop_thr);
-        o[2 * q] = (k & 1u) ? o[2 * q] * inv_keep : 0.f;
-        o[2 * q + 1] = (k & 2u) ? o[2 * q + 1] * inv_keep : 0.f;
-      }
+      for (int q = 0; q < 8; ++q) o[q] *= inv_keep;
+      tn_drop8(o, ((uint32_t)row * (uint32_t)C + (uint32_t)c0) >> 3, drop_key, drop_thr);
     }
     store8(OUT + (size_t)row * C + c0, o);
   }

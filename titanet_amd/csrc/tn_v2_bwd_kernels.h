@@ -505,15 +505,7 @@ __device__ __forceinline__ void act4_reg(float v[4], const float sc[4], const fl
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
   }
-  if (a.drop_thr) {
-    const uint32_t pair = (row * (uint32_t)V2_C + (uint32_t)c0) >> 1;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const uint32_t k = tn_keep_pair(pair + i, a.drop_key, a.drop_thr);
-      v[2 * i] = (k & 1u) ? v[2 * i] * a.inv_keep : 0.f;
-      v[2 * i + 1] = (k & 2u) ? v[2 * i + 1] * a.inv_keep : 0.f;
-    }
-  }
+  if (a.drop_thr) tn_drop4(v, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, (uint32_t)(c0 >> 2) & 1u, a.drop_key, a.drop_thr);
 }
 
 template <int KD>
@@ -695,5 +687,119 @@ inline int launch_dw_bwd_v3(DwBwdV3Args a, int max_wgs, hipStream_t st) {
   auto kern = dw_bwd_v3_kernel<KD>;
   TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a);
+  return (int)hipGetLastError();
+}
+
+// ==========================================================================================
+// Pointwise data gradient, lean version:  dD = BatchNorm-backward-on-load(dZ, Y) * W
+// (the 1x1-conv dgrad of sub-blocks and skip connections).  R rows per tile; R = 32 keeps the kernel
+// under 128 VGPRs so TWO workgroups (16 waves) share a CU and overlap each other's load / transform /
+// MFMA / store phases; W^T stays resident in registers as MFMA A fragments.
+// ==========================================================================================
+struct DgradV2Args {
+  const bf16_t* dZ;
+  const bf16_t* Y;
+  BnBwd bn;
+  const bf16_t* Wt;    // [256 in-channels][256 out-channels]
+  bf16_t* OUT;         // [M][256]
+  int M, ntiles;
+};
+
+template <int R>
+__global__ __launch_bounds__(V2_NT, (R == 32 ? 4 : 2)) void dgrad_v2_kernel(DgradV2Args a) {
+  constexpr int NQ = R / 16;      // 16-byte vectors per thread per stream (512 threads cover 16 rows x 32 vectors)
+  constexpr int NTILE = R / 32;   // 32-row MFMA N tiles
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* Pt = reinterpret_cast<bf16_t*>(smem);      // [R][264] dY rows (MFMA B operand)
+  bf16_t* Dt = Pt + R * V2_AP;                        // [R][264] dD rows
+  float* cst = reinterpret_cast<float*>(Dt + R * V2_AP);   // k0, k1, k2 : [3][256]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vc = tid & 31, rq = tid >> 5, c0 = vc * 8, half = lane >> 5;
+  if (tid < V2_C) {
+    float k0, k1, k2;
+    bn_bwd_coefs(a.bn, V2_C, tid, k0, k1, k2);
+    cst[tid] = k0; cst[V2_C + tid] = k1; cst[2 * V2_C + tid] = k2;
+  }
+  bf16x8_t wf[16];
+  {
+    const int ci = wave * 32 + (lane & 31);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) wf[ks] = *reinterpret_cast<const bf16x8_t*>(a.Wt + (size_t)ci * V2_C + ks * 16 + half * 8);
+  }
+  uint4 pz[NQ], py[NQ];
+  auto prefetch = [&](int tile) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int gr = tile * R + rq + 16 * q;
+      const bool ok = gr < a.M;
+      const size_t o = (size_t)gr * V2_C + c0;
+      pz[q] = ok ? *reinterpret_cast<const uint4*>(a.dZ + o) : make_uint4(0, 0, 0, 0);
+      py[q] = ok ? *reinterpret_cast<const uint4*>(a.Y + o) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) prefetch(tile);
+  __syncthreads();
+  float k0[8], k1[8], k2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { k0[i] = cst[c0 + i]; k1[i] = cst[V2_C + c0 + i]; k2[i] = cst[2 * V2_C + c0 + i]; }
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    const int out0 = tile * R;
+    __syncthreads();   // (1) previous tile's Dt rows have been stored
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int r = rq + 16 * q;
+      float z[8], y[8];
+      unpack8(pz[q], z);
+      unpack8(py[q], y);
+      if (out0 + r < a.M) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) z[i] = k0[i] * z[i] + k1[i] * y[i] + k2[i];
+      }
+      store8(Pt + r * V2_AP + c0, z);
+    }
+    if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
+    __syncthreads();   // (2)
+    f32x16_t acc[NTILE];
+#pragma unroll
+    for (int n = 0; n < NTILE; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    const bf16_t* brow = Pt + (lane & 31) * V2_AP + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+      for (int n = 0; n < NTILE; ++n) {
+        const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(brow + n * 32 * V2_AP + ks * 16);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b, acc[n], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NTILE; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ci = wave * 32 + 8 * g + 4 * half;
+        uint2 w;
+        w.x = f2bf_pk(acc[n][4 * g], acc[n][4 * g + 1]);
+        w.y = f2bf_pk(acc[n][4 * g + 2], acc[n][4 * g + 3]);
+        *reinterpret_cast<uint2*>(Dt + (n * 32 + (lane & 31)) * V2_AP + ci) = w;
+      }
+    __syncthreads();   // (3)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int o = rq + 16 * q, gr = out0 + o;
+      if (gr < a.M) *reinterpret_cast<uint4*>(a.OUT + (size_t)gr * V2_C + c0) = *reinterpret_cast<const uint4*>(Dt + o * V2_AP + c0);
+    }
+  }
+}
+
+template <int R>
+inline int launch_dgrad_v2(DgradV2Args a, int max_wgs, hipStream_t st) {
+  a.ntiles = (a.M + R - 1) / R;
+  const int grid = a.ntiles < max_wgs ? a.ntiles : max_wgs;
+  const size_t smem = (size_t)2 * R * V2_AP * sizeof(bf16_t) + (size_t)3 * V2_C * sizeof(float);
+  auto kern = dgrad_v2_kernel<R>;
+  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
   return (int)hipGetLastError();
 }

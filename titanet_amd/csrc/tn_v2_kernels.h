@@ -49,15 +49,7 @@ __device__ __forceinline__ void act8_reg(float v[8], const float sc[8], const fl
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
   }
-  if (a.drop_thr) {
-    const uint32_t pair = (row * (uint32_t)V2_C + (uint32_t)c0) >> 1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t k = tn_keep_pair(pair + i, a.drop_key, a.drop_thr);
-      v[2 * i] = (k & 1u) ? v[2 * i] * a.inv_keep : 0.f;
-      v[2 * i + 1] = (k & 2u) ? v[2 * i + 1] * a.inv_keep : 0.f;
-    }
-  }
+  if (a.drop_thr) tn_drop8(v, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, a.drop_key, a.drop_thr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -81,8 +73,9 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v2_kernel(SubFwdV2Args a) {
   constexpr int PADR = DW ? (KD - 1) / 2 : 0;
   constexpr int OUTR = DW ? V2_R - (KD - 1) : V2_R;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* Xa = reinterpret_cast<bf16_t*>(smem);     // [64][256] activated input rows; reused as the output staging tile
-  bf16_t* As = Xa + V2_R * V2_C;                    // [64][264] MFMA A operand (depthwise output)
+  bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);     // [64][264] output staging tile; its first 32 KB double as
+  bf16_t* Xa = Cs;                                  // [64][256] the activated input rows (dead once the stencil ran)
+  bf16_t* As = Cs + V2_R * V2_AP;                   // [64][264] MFMA B operand (depthwise output)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vc = tid & 31, rq = tid >> 5;          // this thread's channel vector and row phase (rows rq + 16 q)
   const int c0 = vc * 8;
@@ -119,14 +112,25 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v2_kernel(SubFwdV2Args a) {
     }
     __syncthreads();
   }
-  // ---- this wave's 32 output columns of W as MFMA B fragments, resident for the whole kernel
-  const int ncol = wave * 32 + (lane & 31), half = lane >> 5;
+  // ---- this wave's 32 output channels of W as MFMA A fragments, resident for the whole kernel.  The
+  // activation rows are the B operand, so a lane ends up with 4 CONSECUTIVE channels of one row per
+  // accumulator quad: the output tile is staged with 8-byte LDS writes (2-byte writes cost 4x more).
+  const int half = lane >> 5;
   bf16x8_t wf[16];
+  {
+    const int co = wave * 32 + (lane & 31);
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks)
-    wf[ks] = *reinterpret_cast<const bf16x8_t*>(a.W + (size_t)ncol * V2_C + ks * 16 + half * 8);
-  const float bias = a.bias[ncol];
-  float st_s = 0.f, st_q = 0.f;
+    for (int ks = 0; ks < 16; ++ks)
+      wf[ks] = *reinterpret_cast<const bf16x8_t*>(a.W + (size_t)co * V2_C + ks * 16 + half * 8);
+  }
+  float biasr[16];   // bias of this lane's 16 output channels: 32*wave + 8g + 4*half + j
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) biasr[4 * g + j] = a.bias[wave * 32 + 8 * g + 4 * half + j];
+  float st_s[8], st_q[8];   // BN statistics of this thread's 8 channels (from the staged bf16 tile)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
 
   uint4 pf[4];
   auto prefetch = [&](int tile) {
@@ -156,27 +160,38 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v2_kernel(SubFwdV2Args a) {
     if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);   // next tile's loads fly during the rest
     __syncthreads();   // (2)
     if (DW) {
-      // ---- depthwise stencil over time -> MFMA operand tile
+      // ---- depthwise stencil over time -> MFMA operand tile.  Each thread owns 4 CONSECUTIVE output rows
+      // (a sliding window over KD + 3 activated rows: every LDS row is read and unpacked once, not KD times).
+      {
+        const int o0 = rq * 4;
+        float win[KD + 3][8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int o = rq + 16 * q;           // output row within the tile (valid: o < OUTR)
-        float acc[8];
+        for (int j = 0; j < KD + 3; ++j) {
+          if (o0 + j < V2_R) load8(Xa + (o0 + j) * V2_C + c0, win[j]);
+          else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = bd[i];
-        if (!(V2_DBG_SKIP & 2) && o < OUTR) {
-          const int t = (out0 + o) % a.T;
-#pragma unroll
-          for (int k = 0; k < KD; ++k) {
-            const int tt = t + k - PADR;
-            if (tt >= 0 && tt < a.T) {
-              float v[8];
-              load8(Xa + (o + k) * V2_C + c0, v);
-#pragma unroll
-              for (int i = 0; i < 8; ++i) acc[i] = fmaf(wd[k][i], v[i], acc[i]);
-            }
+            for (int i = 0; i < 8; ++i) win[j][i] = 0.f;
           }
         }
-        store8(As + o * V2_AP + c0, acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int o = o0 + q;
+          float acc[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] = bd[i];
+          if (!(V2_DBG_SKIP & 2) && o < OUTR) {
+            const int t = (out0 + o) % a.T;
+#pragma unroll
+            for (int k = 0; k < KD; ++k) {
+              const int tt = t + k - PADR;
+              if (tt >= 0 && tt < a.T) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = fmaf(wd[k][i], win[q + k][i], acc[i]);
+              }
+            }
+          }
+          store8(As + o * V2_AP + c0, acc);
+        }
       }
       __syncthreads();   // (3)
     }
@@ -184,39 +199,57 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v2_kernel(SubFwdV2Args a) {
     f32x16_t acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const bf16_t* arow = As + (lane & 31) * V2_AP + half * 8;
+    const bf16_t* brow = As + (lane & 31) * V2_AP + half * 8;
 #pragma unroll
     for (int ks = 0; ks < ((V2_DBG_SKIP & 1) ? 1 : 16); ++ks) {
-      const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(arow + ks * 16);
-      const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(arow + 32 * V2_AP + ks * 16);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[ks], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[ks], acc1, 0, 0, 0);
+      const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(brow + ks * 16);
+      const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(brow + 32 * V2_AP + ks * 16);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b1, acc1, 0, 0, 0);
     }
-    // ---- epilogue: bias, BN statistics in registers, stage the tile for coalesced stores
+    // ---- epilogue: lane = row (lane&31 [+32]), regs 4g..4g+3 = channels 32*wave + 8g + 4*half + 0..3
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int r0l = cd_row(r, lane), r1l = 32 + r0l;
-      const float y0 = acc0[r] + bias, y1 = acc1[r] + bias;
-      if (r0l < OUTR && out0 + r0l < a.M) { st_s += y0; st_q += y0 * y0; }
-      if (r1l < OUTR && out0 + r1l < a.M) { st_s += y1; st_q += y1 * y1; }
-      Xa[r0l * V2_C + ncol] = f2bf(y0);
-      Xa[r1l * V2_C + ncol] = f2bf(y1);
+    for (int g = 0; g < 4; ++g) {
+      const int co = wave * 32 + 8 * g + 4 * half;
+      uint2 w0, w1;
+      w0.x = f2bf_pk(acc0[4 * g] + biasr[4 * g], acc0[4 * g + 1] + biasr[4 * g + 1]);
+      w0.y = f2bf_pk(acc0[4 * g + 2] + biasr[4 * g + 2], acc0[4 * g + 3] + biasr[4 * g + 3]);
+      w1.x = f2bf_pk(acc1[4 * g] + biasr[4 * g], acc1[4 * g + 1] + biasr[4 * g + 1]);
+      w1.y = f2bf_pk(acc1[4 * g + 2] + biasr[4 * g + 2], acc1[4 * g + 3] + biasr[4 * g + 3]);
+      *reinterpret_cast<uint2*>(Cs + (lane & 31) * V2_AP + co) = w0;
+      *reinterpret_cast<uint2*>(Cs + (32 + (lane & 31)) * V2_AP + co) = w1;
     }
     __syncthreads();   // (4)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int o = rq + 16 * q, gr = out0 + o;
-      if (!(V2_DBG_SKIP & 4) && o < OUTR && gr < a.M)
-        *reinterpret_cast<uint4*>(a.Y + (size_t)gr * V2_C + c0) = *reinterpret_cast<const uint4*>(Xa + o * V2_C + c0);
+      if (!(V2_DBG_SKIP & 4) && o < OUTR && gr < a.M) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(Cs + o * V2_AP + c0);
+        *reinterpret_cast<uint4*>(a.Y + (size_t)gr * V2_C + c0) = raw;
+        float y[8];
+        unpack8(raw, y);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { st_s[i] += y[i]; st_q[i] = fmaf(y[i], y[i], st_q[i]); }
+      }
     }
   }
   if (a.stats) {
-    st_s += __shfl_xor(st_s, 32, 64);
-    st_q += __shfl_xor(st_q, 32, 64);
-    if (lane < 32) {
-      const int rep = blockIdx.x % TN_NREP;
-      atomic_add_f32(&a.stats[(size_t)(rep * 2 + 0) * V2_C + ncol], st_s);
-      atomic_add_f32(&a.stats[(size_t)(rep * 2 + 1) * V2_C + ncol], st_q);
+    // the 16 row phases hold the same channels: plain LDS stores + a short sum, then coalesced replicated atomics
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);      // [16][2][256]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      red[(rq * 2 + 0) * V2_C + c0 + i] = st_s[i];
+      red[(rq * 2 + 1) * V2_C + c0 + i] = st_q[i];
+    }
+    __syncthreads();
+    const int rep = blockIdx.x % TN_NREP;
+    {
+      const int which = tid >> 8, c = tid & 255;
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v += red[(r * 2 + which) * V2_C + c];
+      atomic_add_f32(&a.stats[(size_t)(rep * 2 + which) * V2_C + c], v);
     }
   }
 }
@@ -226,7 +259,7 @@ inline int launch_sub_fwd_v2(SubFwdV2Args a, int resident_wgs, hipStream_t st) {
   constexpr int OUTR = DW ? V2_R - (KD - 1) : V2_R;
   a.ntiles = (a.M + OUTR - 1) / OUTR;
   const int grid = a.ntiles < resident_wgs ? a.ntiles : resident_wgs;
-  const size_t smem = (size_t)(V2_R * V2_C + V2_R * V2_AP) * sizeof(bf16_t);
+  const size_t smem = (size_t)(2 * V2_R * V2_AP) * sizeof(bf16_t);
   auto kern = sub_fwd_v2_kernel<KD, DW>;
   TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
