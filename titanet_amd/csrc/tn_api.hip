@@ -234,7 +234,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   // split-K slabs for weight gradients: sized for the largest weight (see tn_bwd.hip)
   {
     size_t biggest = std::max({H * H, D * H, D * A, H * (size_t)c.n_mels * c.prolog_kernel});
-    p->slab_bytes = biggest * sizeof(float) * 64;   // up to 64 K-splits
+    p->slab_bytes = biggest * sizeof(float) * 48;   // ~48 K-splits of the largest weight, more for smaller ones
     p->slabs = b.take(p->slab_bytes);
   }
   if (p->use_v2) {
@@ -501,8 +501,8 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   // ---- decoder tail + loss head (reference src/models.py:504-513, src/losses.py)
   {
     BnAct actp = make_act(p, m->pool_bn, B, training, 0, 0.f, seed, 0);
-    hipLaunchKernelGGL(tail_linear_fwd_kernel, dim3(B), dim3(256), (size_t)2 * D * sizeof(float), st,
-                       (const float*)(ws + p->pooled), actp, 2 * D, c.emb, params + m->lin_w, params + m->lin_b,
+    hipLaunchKernelGGL(tail_linear_fwd_kernel, dim3((B + 3) / 4, (c.emb + 63) / 64), dim3(256), (size_t)4 * 2 * D * sizeof(float), st,
+                       (const float*)(ws + p->pooled), actp, B, 2 * D, c.emb, params + m->lin_w, params + m->lin_b,
                        (float*)(ws + p->lin), statp(m->lin_bn));
     HeadArgs ha;
     memset(&ha, 0, sizeof(ha));

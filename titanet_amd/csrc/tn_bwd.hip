@@ -95,15 +95,15 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     const float* lin = (const float*)(ws + p->lin);
     const float* pooled = (const float*)(ws + p->pooled);
     const int K2 = 2 * D;
-    hipLaunchKernelGGL(rows_bn_bwd_sums_kernel, dim3((c.emb + 255) / 256), dim3(256), 0, st, demb, lin, actL, B, c.emb, bsum(m->lin_bn));
+    hipLaunchKernelGGL(rows_bn_bwd_sums_kernel, dim3((c.emb + 255) / 256, (B + 15) / 16), dim3(256), 0, st, demb, lin, actL, B, c.emb, bsum(m->lin_bn));
     hipLaunchKernelGGL(rows_bn_bwd_apply_kernel, dim3((B * c.emb + 255) / 256), dim3(256), 0, st, demb, lin,
                        make_bnbwd(p, m->lin_bn, B, training), B, c.emb, dlin);
-    hipLaunchKernelGGL(tail_bwd_dw_kernel, dim3((K2 + 255) / 256, c.emb), dim3(256), 0, st, (const float*)dlin, pooled, actP, B, K2,
+    hipLaunchKernelGGL(tail_bwd_dw_kernel, dim3((K2 + 255) / 256, (c.emb + 7) / 8), dim3(256), (size_t)B * 8 * sizeof(float), st, (const float*)dlin, pooled, actP, B, K2,
                        c.emb, grads + m->lin_w);
     // d pbn -> (in place) d pooled
     hipLaunchKernelGGL(tail_bwd_dp_kernel, dim3((K2 + 255) / 256, B), dim3(256), 0, st, (const float*)dlin, params + m->lin_w, B, K2,
                        c.emb, dpool);
-    hipLaunchKernelGGL(rows_bn_bwd_sums_kernel, dim3((K2 + 255) / 256), dim3(256), 0, st, (const float*)dpool, pooled, actP, B, K2,
+    hipLaunchKernelGGL(rows_bn_bwd_sums_kernel, dim3((K2 + 255) / 256, (B + 15) / 16), dim3(256), 0, st, (const float*)dpool, pooled, actP, B, K2,
                        bsum(m->pool_bn));
     hipLaunchKernelGGL(rows_bn_bwd_apply_kernel, dim3((B * K2 + 255) / 256), dim3(256), 0, st, (const float*)dpool, pooled,
                        make_bnbwd(p, m->pool_bn, B, training), B, K2, dpool);

@@ -365,8 +365,10 @@ inline int launch_wgrad(int M, int CA, int CB, const typename ProdP::Args& pa, c
                         int prof_cls = 0) {
   constexpr int RK = WgTile<AT>::RK, PITCH = 128 + WgTile<AT>::PAD;
   const int tiles = ((CA + 127) / 128) * ((CB + 127) / 128);
-  int splits = (256 + tiles - 1) / tiles;
-  if (splits > 64) splits = 64;
+  // aim at ~4 resident workgroups per CU (the kernel is latency-bound per workgroup: produce -> barrier
+  // -> MFMA), bounded by the slab buffer
+  int splits = (1024 + tiles - 1) / tiles;
+  if (splits > 128) splits = 128;
   const int max_by_rows = (M + RK - 1) / RK;
   if (splits > max_by_rows) splits = max_by_rows;
   while ((size_t)splits * CA * CB * sizeof(float) > slab_bytes && splits > 1) --splits;
@@ -861,7 +863,7 @@ __global__ __launch_bounds__(256) void head_bwd_x_kernel(HeadBwdArgs a) {
 // ------------------------------------------------------------------------------------------
 // Decoder tail backward (reference src/models.py:506-513): small [B x features] matrices in fp32.
 // ------------------------------------------------------------------------------------------
-// column sums for a BN over rows: bsums += (sum_r dz, sum_r dz * yhat)
+// column sums for a BN over rows: bsums += (sum_r dz, sum_r dz * yhat).  grid = (ceil(C/256), row groups of 16)
 __global__ __launch_bounds__(256) void rows_bn_bwd_sums_kernel(const float* __restrict__ dz, const float* __restrict__ y,
                                                                BnAct act, int R, int C, float* __restrict__ bsums) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -869,13 +871,15 @@ __global__ __launch_bounds__(256) void rows_bn_bwd_sums_kernel(const float* __re
   float mean, rstd;
   bn_mean_rstd(act, C, c, mean, rstd);
   float s1 = 0.f, s2 = 0.f;
-  for (int r = 0; r < R; ++r) {
+  const int r0 = blockIdx.y * 16, r1 = min(R, r0 + 16);
+  for (int r = r0; r < r1; ++r) {
     const float d = dz[(size_t)r * C + c];
     s1 += d;
     s2 += d * (y[(size_t)r * C + c] - mean) * rstd;
   }
-  bsums[c] = s1;          // replica 0 only (others stay zero)
-  bsums[C + c] = s2;
+  const int rep = blockIdx.y % TN_NREP;
+  atomic_add_f32(&bsums[(size_t)(rep * 2 + 0) * C + c], s1);
+  atomic_add_f32(&bsums[(size_t)(rep * 2 + 1) * C + c], s2);
 }
 
 // dy = k0 dz + k1 y + k2 for a [R][C] fp32 matrix
@@ -890,17 +894,34 @@ __global__ __launch_bounds__(256) void rows_bn_bwd_apply_kernel(const float* __r
   }
 }
 
-// d W_lin[e][k] = sum_b dlin[b][e] * pbn[b][k],  pbn = BN(pooled)
+// d W_lin[e][k] = sum_b dlin[b][e] * pbn[b][k],  pbn = BN(pooled).  grid = (ceil(K/256), ceil(E/8)): every
+// thread owns one k and 8 consecutive e (pbn is read once per 8 outputs; dlin comes from LDS as a broadcast).
 __global__ __launch_bounds__(256) void tail_bwd_dw_kernel(const float* __restrict__ dlin, const float* __restrict__ pooled,
                                                           BnAct actP, int B, int K, int E, float* __restrict__ g_W) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* dl = reinterpret_cast<float*>(smem);   // [B][8]
+  const int e0 = blockIdx.y * 8;
+  for (int i = threadIdx.x; i < B * 8; i += 256) {
+    const int b = i >> 3, j = i & 7;
+    dl[i] = (e0 + j < E) ? dlin[(size_t)b * E + e0 + j] : 0.f;
+  }
+  __syncthreads();
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  const int e = blockIdx.y;
   if (k >= K) return;
   float sc, sh;
   bn_scale_shift(actP, K, k, sc, sh);
-  float s = 0.f;
-  for (int b = 0; b < B; ++b) s = fmaf(dlin[(size_t)b * E + e], pooled[(size_t)b * K + k] * sc + sh, s);
-  g_W[(size_t)e * K + k] = s;
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float pv = pooled[(size_t)b * K + k] * sc + sh;
+    const float4 d0 = *reinterpret_cast<const float4*>(dl + b * 8), d1 = *reinterpret_cast<const float4*>(dl + b * 8 + 4);
+    s[0] = fmaf(d0.x, pv, s[0]); s[1] = fmaf(d0.y, pv, s[1]); s[2] = fmaf(d0.z, pv, s[2]); s[3] = fmaf(d0.w, pv, s[3]);
+    s[4] = fmaf(d1.x, pv, s[4]); s[5] = fmaf(d1.y, pv, s[5]); s[6] = fmaf(d1.z, pv, s[6]); s[7] = fmaf(d1.w, pv, s[7]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (e0 + j < E) g_W[(size_t)(e0 + j) * K + k] = s[j];
 }
 
 // d pbn[b][k] = sum_e dlin[b][e] * W[e][k]

@@ -222,34 +222,49 @@ __global__ __launch_bounds__(256) void asp_pool_fwd_kernel(const AT* __restrict_
 // Decoder tail: lin = Linear(BN(pooled))  (reference src/models.py:506-511).  One workgroup per
 // utterance; the K = 2D reduction is split over lanes with coalesced float4 weight reads.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tail_linear_fwd_kernel(const float* __restrict__ pooled, BnAct actP, int K, int E,
+// grid = (ceil(B/4), ceil(E/64)): 4 utterances per workgroup share every weight row read (the naive
+// one-utterance-per-workgroup version re-read the whole 2.4 MB weight matrix 256 times).
+__global__ __launch_bounds__(256) void tail_linear_fwd_kernel(const float* __restrict__ pooled, BnAct actP, int B, int K, int E,
                                                               const float* __restrict__ W, const float* __restrict__ bias,
                                                               float* __restrict__ lin, float* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* p = reinterpret_cast<float*>(smem);   // [K]
-  const int tid = threadIdx.x, b = blockIdx.x;
+  float* p = reinterpret_cast<float*>(smem);   // [4][K] normalised pooled rows
+  const int tid = threadIdx.x, b0 = blockIdx.x * 4, e0 = blockIdx.y * 64;
   for (int k = tid; k < K; k += 256) {
     float sc, sh;
     bn_scale_shift(actP, K, k, sc, sh);
-    p[k] = pooled[(size_t)b * K + k] * sc + sh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) p[s * K + k] = (b0 + s < B) ? pooled[(size_t)(b0 + s) * K + k] * sc + sh : 0.f;
   }
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
-  for (int e = wave; e < E; e += 4) {
+  for (int e = e0 + wave; e < min(E, e0 + 64); e += 4) {
     const float* w = W + (size_t)e * K;
-    float s = 0.f;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (int k = lane * 4; k < K; k += 256) {
       const float4 wv = *reinterpret_cast<const float4*>(w + k);
-      s += wv.x * p[k] + wv.y * p[k + 1] + wv.z * p[k + 2] + wv.w * p[k + 3];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 pv = *reinterpret_cast<const float4*>(p + q * K + k);
+        s[q] += wv.x * pv.x + wv.y * pv.y + wv.z * pv.z + wv.w * pv.w;
+      }
     }
-    s = wave_sum(s);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[q] = wave_sum(s[q]);
     if (lane == 0) {
-      s += bias[e];
-      lin[(size_t)b * E + e] = s;
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (b0 + q < B) {
+          const float v = s[q] + bias[e];
+          lin[(size_t)(b0 + q) * E + e] = v;
+          t1 += v; t2 += v * v;
+        }
+      }
       if (stats) {
-        const int rep = b % TN_NREP;
-        atomic_add_f32(&stats[(size_t)(rep * 2 + 0) * E + e], s);
-        atomic_add_f32(&stats[(size_t)(rep * 2 + 1) * E + e], s * s);
+        const int rep = blockIdx.x % TN_NREP;
+        atomic_add_f32(&stats[(size_t)(rep * 2 + 0) * E + e], t1);
+        atomic_add_f32(&stats[(size_t)(rep * 2 + 1) * E + e], t2);
       }
     }
   }
