@@ -28,6 +28,25 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/
 ALG_BYTES_PER_UTT_BF16 = 70.66e6   # 7,065,600 elements x 5 passes x 2 B (S/17, T=300, fwd+bwd)
 
 PROF_CLASSES = {1: "fwd_subblock_gemm", 2: "bwd_pointwise_wgrad", 3: "bwd_pointwise_dgrad", 4: "bwd_depthwise"}
+# kernel behind each class on the headline shape (for the PMC traffic lookup)
+PROF_KERNELS = {1: "sub_fwd_v2_kernel<3, true>", 2: "wgrad_batched_v2_kernel<3>", 3: "sub_bwd_v2_kernel<1, false>",
+                4: "dw_bwd_v3_kernel<3>"}
+
+
+def pmc_traffic(cls):
+    """HBM bytes per launch of the class's kernel from the committed rocprofv3 PMC passes
+    (profiles/*pmc_traffic.json, produced by tools/pmc_summary.py from separate `--pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` runs of this same command).  FETCH_SIZE is doubled: on gfx950 it reports half of
+    the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section); units are KiB."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1])).get(PROF_KERNELS[cls])
+        return int((2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024) if d else None
+    except Exception:
+        return None
 
 
 def kernel_algorithmic_bytes(cls, rows, hidden, esz):
@@ -89,6 +108,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--loss", default="ce", choices=["ce", "arc"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo for single-GPU smoke tests)")
+    ap.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,11 +117,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU execution path for the product)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
     assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
 
     from titanet_amd import LOSSES, TitaNet
@@ -151,7 +177,7 @@ def main():
     lib.tn_profile_read(plan.handle, C.byref(ms), C.byref(cnt))
     lib.tn_profile_begin(plan.handle, 0)
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss_value = float(lv.item())
@@ -185,7 +211,8 @@ def main():
                        "global_batch": args.batch * world, "frames": T, "parallelism": f"dp{world}", "dropout": 0.1,
                        "loss": loss_value},
             "roofline": {"bound": "hbm", "kernel": PROF_CLASSES[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic(dom) if (args.precision == "bf16" and args.batch == 256) else None,
                          "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt.value,
                          "algorithmic_bytes_per_launch": kbytes,
                          "step_frac_of_hbm_roofline": round(step_alg * world / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
