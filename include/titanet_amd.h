@@ -119,6 +119,21 @@ int tn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
                  float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_mult,
                  void* stream);
 
+/* ---- mel front end: MelSpectrogram.__call__ (reference src/transforms.py:158-203) -----------------------
+ * Spectrogram(n_fft, win_length, hop_length, power=None) -> |.|^2 -> MelScale(n_mels, sample_rate) ->
+ * AmplitudeToDB() -> F.normalize(dim=1) -> SpecAugment frequency/time masks, for a batch of equal-length
+ * waveforms.  waves: float32 [batch][n_samples]; out: float32 [batch][n_mels][frames],
+ * frames = 1 + n_samples / hop_length (center=True), i.e. exactly the tensor tn_forward consumes.
+ * masks: int32 [batch][4] = {f_start, f_end, t_start, t_end} (zeros = no mask) or NULL; the mask draws
+ * (torchaudio.functional.mask_along_axis) stay on the host.  The phase-vocoder TimeStretch of the
+ * reference's SpecAugment branch (src/transforms.py:168-175) is not implemented. */
+typedef struct tn_mel tn_mel;
+int tn_mel_create(int32_t sample_rate, int32_t n_fft, int32_t win_length, int32_t hop_length, int32_t n_mels, tn_mel** out);
+void tn_mel_destroy(tn_mel* m);
+int64_t tn_mel_num_frames(const tn_mel* m, int64_t n_samples);
+int tn_mel_forward(tn_mel* m, const float* waves, int32_t batch, int64_t n_samples, const int32_t* masks, float* out,
+                   void* stream);
+
 /* ---- per-kernel timing with HIP events on the launch stream (roofline measurement) ----------------
  * Kernel classes: the heavy kernels of one mega-block sub-block (there are n_mega_blocks*n_sub_blocks
  * launches of each per step). */

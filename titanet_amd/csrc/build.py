@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ["tn_api.hip", "tn_bwd.hip"]
+SOURCES = ["tn_api.hip", "tn_bwd.hip", "tn_mel.hip"]
 HEADERS = ["tn_common.h", "tn_gemm.h", "tn_fwd_kernels.h", "tn_bwd_kernels.h", "tn_v2_kernels.h", "tn_v2_bwd_kernels.h", "tn_internal.h",
            "../../include/titanet_amd.h"]
 OUT = os.path.join(PKG, "libtitanet_amd.so")

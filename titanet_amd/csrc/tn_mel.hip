@@ -1,0 +1,154 @@
+// titanet_amd — mel front end on the GPU (reference src/transforms.py:158-203, torchaudio 0.13 semantics:
+// Spectrogram(n_fft, win_length, hop, power=None, center, reflect) -> |.|^2 -> MelScale(HTK, norm=None)
+// -> AmplitudeToDB(power, amin 1e-10, ref 1) -> F.normalize over the mel axis -> SpecAugment masks).
+// One workgroup per frame: windowed frame -> radix-2 FFT in LDS -> power -> sparse mel triangles -> dB
+// -> L2 normalisation -> masked store in the [B, n_mels, T] layout TitaNet.forward consumes.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/titanet_amd.h"
+#include "tn_common.h"
+
+struct tn_mel {
+  int sample_rate, n_fft, win_length, hop, n_mels, log2n, n_freqs;
+  float* window = nullptr;   // [n_fft] hann (periodic) centred in n_fft
+  float* fb = nullptr;       // [n_mels][n_freqs]
+  int* range = nullptr;      // [n_mels][2] first / one-past-last non-zero bin
+  float* twiddle = nullptr;  // [n_fft/2][2] cos, -sin of 2 pi k / n_fft
+};
+
+__global__ void mel_frame_kernel(const float* __restrict__ waves, int64_t n_samples, int T, int n_fft, int log2n, int hop,
+                                 int n_mels, int n_freqs, const float* __restrict__ window, const float* __restrict__ fb,
+                                 const int* __restrict__ range, const float* __restrict__ twiddle,
+                                 const int32_t* __restrict__ masks, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* re = reinterpret_cast<float*>(smem);
+  float* im = re + n_fft;
+  float* pw = im + n_fft;            // [n_freqs]
+  float* mel = pw + n_freqs + 3;     // [n_mels]
+  __shared__ float s_norm;
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, half_n = n_fft >> 1;
+  const float* wave = waves + (size_t)b * n_samples;
+  // ---- windowed frame (center=True, reflect padding), bit-reversed order
+  for (int n = tid; n < n_fft; n += blockDim.x) {
+    int64_t s = (int64_t)t * hop - half_n + n;
+    if (s < 0) s = -s;
+    if (s >= n_samples) s = 2 * (n_samples - 1) - s;
+    if (s < 0) s = 0;   // degenerate: utterance shorter than the padding
+    const unsigned r = __brev((unsigned)n) >> (32 - log2n);
+    re[r] = wave[s] * window[n];
+    im[r] = 0.f;
+  }
+  __syncthreads();
+  // ---- radix-2 decimation-in-time FFT
+  for (int st = 0; st < log2n; ++st) {
+    const int half = 1 << st, len = half << 1;
+    for (int j = tid; j < half_n; j += blockDim.x) {
+      const int grp = j >> st, pos = j & (half - 1);
+      const int i0 = grp * len + pos, i1 = i0 + half;
+      const int tw = pos << (log2n - 1 - st);
+      const float c = twiddle[2 * tw], s = twiddle[2 * tw + 1];
+      const float xr = re[i1] * c - im[i1] * s, xi = re[i1] * s + im[i1] * c;
+      const float ar = re[i0], ai = im[i0];
+      re[i0] = ar + xr; im[i0] = ai + xi;
+      re[i1] = ar - xr; im[i1] = ai - xi;
+    }
+    __syncthreads();
+  }
+  for (int k = tid; k < n_freqs; k += blockDim.x) pw[k] = re[k] * re[k] + im[k] * im[k];
+  __syncthreads();
+  // ---- mel triangles (sparse), dB
+  for (int m = tid; m < n_mels; m += blockDim.x) {
+    float s = 0.f;
+    const int lo = range[2 * m], hi = range[2 * m + 1];
+    for (int k = lo; k < hi; ++k) s = fmaf(fb[(size_t)m * n_freqs + k], pw[k], s);
+    mel[m] = 10.f * log10f(fmaxf(s, 1e-10f));
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float q = 0.f;
+    for (int m = tid; m < n_mels; m += 64) q += mel[m] * mel[m];
+    q = wave_sum(q);
+    if (tid == 0) s_norm = fmaxf(sqrtf(q), 1e-12f);
+  }
+  __syncthreads();
+  int f0 = 0, f1 = 0, t0 = 0, t1 = 0;
+  if (masks) { f0 = masks[4 * b]; f1 = masks[4 * b + 1]; t0 = masks[4 * b + 2]; t1 = masks[4 * b + 3]; }
+  const bool tmask = t >= t0 && t < t1;
+  const float inv = 1.f / s_norm;
+  for (int m = tid; m < n_mels; m += blockDim.x) {
+    float v = mel[m] * inv;
+    if (tmask || (m >= f0 && m < f1)) v = 0.f;
+    out[((size_t)b * n_mels + m) * T + t] = v;
+  }
+}
+
+extern "C" int tn_mel_create(int32_t sample_rate, int32_t n_fft, int32_t win_length, int32_t hop_length, int32_t n_mels,
+                             tn_mel** out) {
+  if (!out || n_fft < 16 || n_fft > 4096 || (n_fft & (n_fft - 1)) || win_length <= 0 || win_length > n_fft || hop_length <= 0 ||
+      n_mels <= 0 || sample_rate <= 0)
+    return TN_E_BADARG;
+  tn_mel* m = new tn_mel();
+  m->sample_rate = sample_rate; m->n_fft = n_fft; m->win_length = win_length; m->hop = hop_length; m->n_mels = n_mels;
+  m->n_freqs = n_fft / 2 + 1;
+  m->log2n = 0;
+  while ((1 << m->log2n) < n_fft) ++m->log2n;
+  const double PI = 3.14159265358979323846;
+  std::vector<float> win(n_fft, 0.f), tw(n_fft), fb((size_t)n_mels * m->n_freqs, 0.f);
+  std::vector<int> range(2 * n_mels);
+  const int left = (n_fft - win_length) / 2;
+  for (int n = 0; n < win_length; ++n) win[left + n] = (float)(0.5 - 0.5 * cos(2.0 * PI * n / win_length));
+  for (int k = 0; k < n_fft / 2; ++k) { tw[2 * k] = (float)cos(2.0 * PI * k / n_fft); tw[2 * k + 1] = (float)(-sin(2.0 * PI * k / n_fft)); }
+  // torchaudio.functional.melscale_fbanks(n_freqs, 0, sr/2, n_mels, sr, norm=None, mel_scale="htk")
+  const double f_max = sample_rate / 2.0;
+  const double m_min = 0.0, m_max = 2595.0 * log10(1.0 + f_max / 700.0);
+  std::vector<double> f_pts(n_mels + 2);
+  for (int i = 0; i < n_mels + 2; ++i) {
+    const double mp = m_min + (m_max - m_min) * i / (n_mels + 1);
+    f_pts[i] = 700.0 * (pow(10.0, mp / 2595.0) - 1.0);
+  }
+  for (int j = 0; j < n_mels; ++j) {
+    int lo = m->n_freqs, hi = 0;
+    for (int k = 0; k < m->n_freqs; ++k) {
+      const double f = (double)(sample_rate / 2) * k / (m->n_freqs - 1);
+      const double down = (f - f_pts[j]) / (f_pts[j + 1] - f_pts[j]);
+      const double up = (f_pts[j + 2] - f) / (f_pts[j + 2] - f_pts[j + 1]);
+      const double v = fmax(0.0, fmin(down, up));
+      fb[(size_t)j * m->n_freqs + k] = (float)v;
+      if (v > 0.0) { lo = k < lo ? k : lo; hi = k + 1; }
+    }
+    if (hi <= lo) { lo = 0; hi = 0; }
+    range[2 * j] = lo; range[2 * j + 1] = hi;
+  }
+  TN_CHECK_HIP(hipMalloc(&m->window, win.size() * sizeof(float)));
+  TN_CHECK_HIP(hipMalloc(&m->twiddle, tw.size() * sizeof(float)));
+  TN_CHECK_HIP(hipMalloc(&m->fb, fb.size() * sizeof(float)));
+  TN_CHECK_HIP(hipMalloc(&m->range, range.size() * sizeof(int)));
+  TN_CHECK_HIP(hipMemcpy(m->window, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
+  TN_CHECK_HIP(hipMemcpy(m->twiddle, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+  TN_CHECK_HIP(hipMemcpy(m->fb, fb.data(), fb.size() * sizeof(float), hipMemcpyHostToDevice));
+  TN_CHECK_HIP(hipMemcpy(m->range, range.data(), range.size() * sizeof(int), hipMemcpyHostToDevice));
+  *out = m;
+  return 0;
+}
+
+extern "C" void tn_mel_destroy(tn_mel* m) {
+  if (!m) return;
+  (void)hipFree(m->window); (void)hipFree(m->twiddle); (void)hipFree(m->fb); (void)hipFree(m->range);
+  delete m;
+}
+
+extern "C" int64_t tn_mel_num_frames(const tn_mel* m, int64_t n_samples) { return m ? 1 + n_samples / m->hop : 0; }
+
+extern "C" int tn_mel_forward(tn_mel* m, const float* waves, int32_t batch, int64_t n_samples, const int32_t* masks, float* out,
+                              void* stream) {
+  if (!m || !waves || !out || batch <= 0 || n_samples <= 0) return TN_E_BADARG;
+  const int T = (int)(1 + n_samples / m->hop);
+  const size_t smem = (size_t)(2 * m->n_fft + m->n_freqs + 3 + m->n_mels) * sizeof(float);
+  const int threads = m->n_fft / 2 < 64 ? 64 : (m->n_fft / 2 > 1024 ? 1024 : m->n_fft / 2);
+  hipLaunchKernelGGL(mel_frame_kernel, dim3(T, batch), dim3(threads), smem, (hipStream_t)stream, waves, n_samples, T, m->n_fft,
+                     m->log2n, m->hop, m->n_mels, m->n_freqs, m->window, m->fb, m->range, m->twiddle, masks, out);
+  return (int)hipGetLastError();
+}
