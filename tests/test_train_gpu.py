@@ -1,0 +1,41 @@
+"""The parameters.yml-driven harness: the reference's config schema drives a real (tiny) training run on the
+HIP path and the loss goes down (the reference's own 'can it overfit' smoke idea, src/train.py:59-60)."""
+import os
+
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+
+# the reference's parameters.yml keys that are in scope (values: reference defaults, shrunk model)
+PARAMS = {
+    "training": {"optimizer": {"type": "adam", "start_lr": 0.001, "scheduler": False, "end_lr": 0.00001, "weight_decay": 0.0},
+                 "checkpoints_path": "./checkpoints", "checkpoints_frequency": 25, "batch_size": 16, "epochs": 250, "loss": "arc"},
+    "loss": {"sphere": {"margin": 4}, "cos": {"margin": 0.2, "scale": 64}, "arc": {"margin": 0.2, "scale": 30}},
+    "titanet": {"enabled": True, "model_size": "s", "n_mega_blocks": 2, "attention_hidden_size": 128, "simple_pool": False,
+                "dropout": 0.1},
+    "generic": {"seed": 42, "workers": 2, "log_console": False, "chart_dependencies": False, "embedding_size": 192},
+    "audio": {"sample_rate": 16000, "spectrogram": {"n_fft": 512, "win_length": 25, "hop_length": 10, "n_mels": 80}},
+}
+
+
+def test_yaml_driven_training_reduces_loss(tmp_path):
+    from titanet_amd import train
+    p = tmp_path / "parameters.yml"
+    p.write_text(yaml.safe_dump(PARAMS))
+    params = train.Struct(**yaml.load(open(p), Loader=yaml.SafeLoader))
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(16, 80, 151, generator=g) * 0.11 - 0.1).cuda()
+    y = torch.randint(0, 8, (16,), generator=g).cuda()
+
+    def fixed():
+        while True:
+            yield x, None, y
+    model, trainer, hist = train.run(params, steps=60, n_classes=8, data=fixed(), log_every=20)
+    assert hist[-1][1] < hist[0][1] * 0.7, hist            # overfits a fixed batch
+    ck = tmp_path / "ck" / "epoch_1.pth"
+    train.save_checkpoint(model, trainer, 1, str(ck))
+    d = torch.load(ck)
+    assert set(d) == {"model", "optimizer", "lr_scheduler", "epoch"}
+    assert "encoder.prolog.conv_block.0.weight" in d["model"] and "loss_function.fc.weight" in d["model"]

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Training harness consuming the reference's ``parameters.yml`` schema.
+
+    python -m titanet_amd.train -p parameters.yml [--steps N] [--synthetic]
+
+Reproduces the step protocol of the reference (``train.train``, src/train.py:11-183; ``learn.train_one_epoch``
+/ ``training_loop`` / ``save_checkpoint``, src/learn.py:64-310) for the part that is in scope: it reads
+``training.{batch_size,epochs,loss,optimizer.*,checkpoints_*}``, ``loss.*``, ``titanet.*``,
+``generic.{seed,embedding_size}``, ``audio.spectrogram.*`` from the same YAML, builds the loss through
+``LOSSES[name](embedding_size, n_classes, **loss.<name>)`` and the model through ``TitaNet.get_titanet``,
+always uses Adam (the reference's ``== "sgd"`` test can never be true, src/train.py:130), an optional
+per-epoch cosine LR (src/learn.py:257-258), and writes checkpoints as
+``{"model", "optimizer", "lr_scheduler", "epoch"}`` (src/learn.py:188-195).  Datasets / W&B / plots are out of
+scope: batches are synthetic ``[B, n_mels, T]`` tensors with the collate_fn layout
+(src/datasets.py:48-73) unless a data iterator is passed to :func:`run`.
+"""
+import argparse
+import math
+import os
+
+import torch
+import yaml
+
+from . import LOSSES, TitaNet
+from .trainer import Trainer
+
+
+class Struct:
+    """reference src/utils.py:31-63: nested dict -> attribute access, keeps ``.entries``."""
+
+    def __init__(self, **entries):
+        self.entries = entries
+        for k, v in entries.items():
+            setattr(self, k, Struct(**v) if isinstance(v, dict) else v)
+
+
+def synthetic_batches(batch_size, n_mels, n_classes, device, frames=(151, 201, 301), seed=42):
+    """collate_fn layout: spectrograms [B, n_mels, T] fp32 (T from the RandomChunk lengths 1.5/2/3 s),
+    lengths, speaker ids (reference src/datasets.py:48-73, src/transforms.py:206-233)."""
+    g = torch.Generator().manual_seed(seed)
+    while True:
+        T = frames[int(torch.randint(0, len(frames), (1,), generator=g))]
+        x = torch.randn(batch_size, n_mels, T, generator=g) * 0.11 - 0.10
+        y = torch.randint(0, n_classes, (batch_size,), generator=g)
+        yield x.to(device), torch.full((batch_size,), T), y.to(device)
+
+
+def run(params, steps=None, n_classes=251, data=None, device="cuda", precision="fp32", log_every=10):
+    torch.manual_seed(params.generic.seed)
+    loss_name = params.training.loss
+    loss_kw = dict(getattr(params.loss, loss_name).entries) if hasattr(params.loss, loss_name) else {}
+    loss_function = LOSSES[loss_name](params.generic.embedding_size, n_classes, device=device, **loss_kw)
+    model = TitaNet.get_titanet(embedding_size=params.generic.embedding_size, n_mels=params.audio.spectrogram.n_mels,
+                                n_mega_blocks=params.titanet.n_mega_blocks, model_size=params.titanet.model_size,
+                                attention_hidden_size=params.titanet.attention_hidden_size, simple_pool=params.titanet.simple_pool,
+                                loss_function=loss_function, dropout=params.titanet.dropout, device=device, precision=precision)
+    model.train()
+    opt = params.training.optimizer
+    trainer = Trainer(model, lr=opt.start_lr, weight_decay=opt.weight_decay)
+    data = data or synthetic_batches(params.training.batch_size, params.audio.spectrogram.n_mels, n_classes, device,
+                                     seed=params.generic.seed)
+    epochs = params.training.epochs
+    total = steps if steps is not None else epochs
+    history = []
+    for step in range(1, total + 1):
+        if opt.scheduler:   # CosineAnnealingLR(T_max=epochs, eta_min=end_lr) stepped per epoch (src/train.py:137-144)
+            trainer.lr = opt.end_lr + 0.5 * (opt.start_lr - opt.end_lr) * (1 + math.cos(math.pi * min(step - 1, epochs) / epochs))
+        spectrograms, _, speakers = next(data)
+        emb, preds, loss = trainer.step(spectrograms, speakers)
+        if step % log_every == 0 or step == total:
+            lv = float(loss.item())
+            if not math.isfinite(lv):                                   # src/learn.py:110-112
+                raise SystemExit(f"Loss is {lv}, stopping training")
+            acc = float((preds == speakers).float().mean().item())
+            history.append((step, lv, acc))
+            print(f"step {step:5d}  loss {lv:.4f}  acc {acc:.3f}", flush=True)
+    return model, trainer, history
+
+
+def save_checkpoint(model, trainer, epoch, path):
+    """reference src/learn.py:180-201 layout (optimizer state in torch.optim.Adam's state_dict shape)."""
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    torch.save({"model": model.state_dict(),
+                "optimizer": {"state": {"flat": {"step": trainer.step_count, "exp_avg": trainer.exp_avg, "exp_avg_sq": trainer.exp_avg_sq}},
+                              "param_groups": [{"lr": trainer.lr, "betas": trainer.betas, "eps": trainer.eps,
+                                                "weight_decay": trainer.weight_decay}]},
+                "lr_scheduler": None, "epoch": epoch}, path)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-p", "--params", default="parameters.yml")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--checkpoint", default=None)
+    args = ap.parse_args()
+    with open(args.params) as fh:
+        params = Struct(**yaml.load(fh, Loader=yaml.SafeLoader))
+    model, trainer, _ = run(params, steps=args.steps, precision=args.precision)
+    if args.checkpoint:
+        save_checkpoint(model, trainer, args.steps or params.training.epochs, args.checkpoint)
+
+
+if __name__ == "__main__":
+    main()
