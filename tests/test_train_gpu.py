@@ -39,3 +39,23 @@ def test_yaml_driven_training_reduces_loss(tmp_path):
     d = torch.load(ck)
     assert set(d) == {"model", "optimizer", "lr_scheduler", "epoch"}
     assert "encoder.prolog.conv_block.0.weight" in d["model"] and "loss_function.fc.weight" in d["model"]
+
+
+def test_flat_all_reducer_on_rccl_world1():
+    """The RCCL leg of the data-parallel step (side stream, event ordering, bucketed all-reduce) runs on a
+    one-rank "nccl" group: sums are the identity, so the buffer must come back unchanged."""
+    import torch.distributed as dist
+    from titanet_amd.trainer import FlatAllReducer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        red = FlatAllReducer(n_buckets=4)
+        red.world = 2                      # force the collective path on the 1-rank group
+        flat = torch.arange(5000, device="cuda", dtype=torch.float32)
+        want = flat.clone()
+        red.all_reduce_(flat)
+        torch.cuda.synchronize()
+        assert torch.equal(flat, want)
+    finally:
+        dist.destroy_process_group()

@@ -118,3 +118,43 @@ class Resample:
         if example["sample_rate"] != self.sample_rate:
             raise NotImplementedError("resampling is outside the MI355X hot-path scope (SURVEY.md §8a14)")
         return copy_example(example)
+
+
+class RandomChunk:
+    """reference src/transforms.py:206-233: if the waveform is longer than ``max_length`` seconds, keep a random
+    chunk of one of ``lengths`` seconds (same ``random.choice`` / ``random.randint`` draws, in the same order)."""
+
+    def __init__(self, max_length, lengths):
+        self.max_length = max_length
+        self.lengths = lengths
+
+    def __call__(self, example):
+        assert isinstance(example, dict) and "waveform" in example and "sample_rate" in example, "Wrong input structure"
+        new_example = copy_example(example)
+        num_samples = new_example["waveform"].size(-1)
+        if num_samples / new_example["sample_rate"] > self.max_length:
+            length = random.choice(self.lengths)
+            samples = int(length * new_example["sample_rate"])
+            start = random.randint(0, num_samples - samples)
+            new_example["waveform"] = new_example["waveform"][:, start:start + samples]
+        return new_example
+
+
+def get_transforms(enabled, rir_corpora_path=None, max_length=3, chunk_lengths=(1.5, 2, 3), min_speed=0.95, max_speed=1.05,
+                   sample_rate=16000, n_fft=512, win_length=25, hop_length=10, n_mels=80, freq_mask_ratio=0.35,
+                   freq_mask_num=1, time_mask_ratio=0.15, time_mask_num=1, probability=1.0, device="cuda", training=True):
+    """reference src/transforms.py:24-74: Resample -> [RandomChunk] -> MelSpectrogram (window / hop given in ms).
+    "reverb" (sox + RIR corpora, src/transforms.py:236-317) is outside the hot-path scope and is refused."""
+    enabled = list(enabled or [])
+    if "reverb" in enabled and training:
+        raise NotImplementedError("reverb augmentation is outside the MI355X hot-path scope (SURVEY.md §8f)")
+    transformations = [Resample(sample_rate)]
+    if "chunk" in enabled:
+        transformations.append(RandomChunk(max_length, list(chunk_lengths)))
+    transformations.append(MelSpectrogram(
+        sample_rate, n_fft=n_fft, win_length=int(win_length / 1000 * sample_rate), hop_length=int(hop_length / 1000 * sample_rate),
+        n_mels=n_mels, specaugment_min_speed=min_speed, specaugment_max_speed=max_speed,
+        specaugment_freq_mask_ratio=freq_mask_ratio, specaugment_freq_mask_num=freq_mask_num,
+        specaugment_time_mask_ratio=time_mask_ratio, specaugment_time_mask_num=time_mask_num,
+        specaugment_probability=(probability if "specaugment" in enabled and training else 0.0), device=device))
+    return transformations
