@@ -171,16 +171,22 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   const size_t M = p->M, H = c.hidden, D = c.enc_out, A = c.attn_hidden, Hr = c.hidden / c.se_reduction;
   const size_t e = p->esz;
   Bump b;
-  // ---- zeroed-every-step region: statistics, backward sums, loss accumulator
+  // ---- region cleared at the start of every forward: statistics, loss accumulator
   p->zero_begin = b.take(0);
   p->stats.resize(m->n_bn);
   p->bsums.resize(m->n_bn);
   for (int i = 0; i < m->n_bn; ++i) p->stats[i] = b.take((size_t)TN_NREP * 2 * m->all_bn[i].C * sizeof(float));
-  for (int i = 0; i < m->n_bn; ++i) p->bsums[i] = b.take((size_t)TN_NREP * 2 * m->all_bn[i].C * sizeof(float));
   p->loss_acc = b.take(256);
+  p->zero_bytes = ((b.off + 255) & ~(size_t)255) - p->zero_begin;
+  b.off = p->zero_begin + p->zero_bytes;
+  // ---- region cleared at the start of every backward (so a backward can be repeated from one forward,
+  //      loss.backward(retain_graph=True) twice): BN-backward sums, split-K counters, depthwise accumulators
+  p->bzero_begin = b.take(0);
+  for (int i = 0; i < m->n_bn; ++i) p->bsums[i] = b.take((size_t)TN_NREP * 2 * m->all_bn[i].C * sizeof(float));
   p->wg2_count = b.take(sizeof(int) * (size_t)(c.n_mega_blocks * (c.n_sub_blocks + 1) + 1));
   p->dw_gacc = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * TN_NREP * (c.kernel + 1) * H * sizeof(float));
-  p->zero_bytes = ((b.off + 255) & ~(size_t)255) - p->zero_begin;
+  p->bzero_bytes = ((b.off + 255) & ~(size_t)255) - p->bzero_begin;
+  b.off = p->bzero_begin + p->bzero_bytes;
   // ---- compute-precision weights
   auto wc = [&](size_t n, size_t k) { WcRef r; r.w = b.take(n * k * e); r.wt = b.take(n * k * e); return r; };
   p->wprolog = wc(H, (size_t)c.n_mels * c.prolog_kernel);

@@ -61,6 +61,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   auto wt = [&](const WcRef& r) -> const void* { return ws + r.wt; };
 
   TN_CHECK_HIP(hipMemsetAsync(grads, 0, (size_t)m->n_params * sizeof(float), st));
+  TN_CHECK_HIP(hipMemsetAsync(ws + p->bzero_begin, 0, p->bzero_bytes, st));
   const bool batched_wgrad = sizeof(AT) == 2 && (p->use_v2 & 4) && training && p->wg2_layers > 0;
   const bool v2_bwd = sizeof(AT) == 2 && (p->use_v2 & 8);
 

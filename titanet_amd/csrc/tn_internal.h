@@ -85,7 +85,8 @@ struct tn_plan {
   char* ws = nullptr;
   bool bound = false;
   // workspace layout (byte offsets)
-  size_t zero_begin, zero_bytes;        // region cleared at the start of every step
+  size_t zero_begin, zero_bytes;        // region cleared at the start of every forward
+  size_t bzero_begin, bzero_bytes;      // region cleared at the start of every backward
   std::vector<size_t> stats;            // per BN id: forward sums  float[NREP][2][C]
   std::vector<size_t> bsums;            // per BN id: backward sums float[NREP][2][C]
   size_t loss_acc;
