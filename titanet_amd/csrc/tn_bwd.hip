@@ -247,7 +247,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         }
         {
           ProfScope ps(p, TN_PROF_BWD_DW, st);
-          rc = launch_dw_bwd_v3<3>(da, 512, st);
+          rc = launch_dw_bwd_v4<3>(da, 256, st);
         }
         if (rc) return rc;
         continue;

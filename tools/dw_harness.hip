@@ -29,5 +29,20 @@ int main(int argc, char** argv) {
   CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   printf("dw_bwd_v3 grid=%d: %.2f us/launch (%.2f TB/s algorithmic 3t)\n", grid, ms * 1e3 / iters, 3.0 * M * C * 2 / (ms * 1e-3 / iters) / 1e12);
+  for (int it = 0; it < 3; ++it) launch_dw_bwd_v4<3>(a, grid, 0);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  for (int it = 0; it < iters; ++it) launch_dw_bwd_v4<3>(a, grid, 0);
+  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("dw_bwd_v4 grid=%d: %.2f us/launch (%.2f TB/s algorithmic 3t)\n", grid, ms * 1e3 / iters, 3.0 * M * C * 2 / (ms * 1e-3 / iters) / 1e12);
+  a.ADD = ADD; a.actX.mode = 0; a.actX.relu = 0; a.actX.drop_thr = 0;
+  for (int it = 0; it < 3; ++it) launch_dw_bwd_v4<3>(a, grid, 0);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  for (int it = 0; it < iters; ++it) launch_dw_bwd_v4<3>(a, grid, 0);
+  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("dw_bwd_v4 (first sub-block: +ADD, identity act) grid=%d: %.2f us/launch\n", grid, ms * 1e3 / iters);
   return 0;
 }
