@@ -197,11 +197,11 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       if (!batched_wgrad) rc = launch_wgrad<AT, ProdDy, ProdPlain>(M, H, H, pa, qa, 0, slabs, p->slab_bytes, grads + mb.wskip, st);
       if (rc) return rc;
       if (v2_bwd) {
-        SubBwdV2Args va;
+        DgradV2Args va;
         memset(&va, 0, sizeof(va));
         va.dZ = (const bf16_t*)(ws + bw.dZk); va.Y = (const bf16_t*)(ws + bw.S); va.bn = pa.bn;
-        va.Wt = (const bf16_t*)(ws + bw.wskip.wt); va.OUT = (bf16_t*)(ws + p->dXs); va.M = M; va.T = T;
-        rc = launch_sub_bwd_v2<1, false>(va, 256, st);
+        va.Wt = (const bf16_t*)(ws + bw.wskip.wt); va.OUT = (bf16_t*)(ws + p->dXs); va.M = M;
+        rc = launch_dgrad_v2<64>(va, 256, st);
       } else {
         GemmShape g{M, H, H, wt(bw.wskip)};
         EpiStoreArgs ea{ws + p->dXs, H, nullptr, nullptr};
@@ -223,14 +223,14 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       }
       if (v2_bwd) {
         // (A) pointwise data gradient dD = BN-backward(dZ, Y) * W   (persistent MFMA kernel, W^T in registers)
-        SubBwdV2Args va;
+        DgradV2Args va;
         memset(&va, 0, sizeof(va));
         va.dZ = (const bf16_t*)(ws + bw.dY[j]); va.Y = (const bf16_t*)(ws + bw.Y[j]); va.bn = pa.bn;
-        va.Wt = (const bf16_t*)(ws + bw.wpw[j].wt); va.OUT = (bf16_t*)(ws + p->dD); va.M = M; va.T = T;
+        va.Wt = (const bf16_t*)(ws + bw.wpw[j].wt); va.OUT = (bf16_t*)(ws + p->dD); va.M = M;
         int rc;
         {
           ProfScope ps(p, TN_PROF_BWD_DGRAD, st);
-          rc = launch_sub_bwd_v2<1, false>(va, 256, st);
+          rc = launch_dgrad_v2<64>(va, 256, st);
         }
         if (rc) return rc;
         // (B) depthwise backward + activation backward + BN sums (streaming kernel)

@@ -51,6 +51,148 @@ struct WgradV2Desc {
 };
 
 
+struct WgSeg {
+  bf16_t* Pt; bf16_t* Qt; bf16_t* Xa; float* cst;
+  int chunk0, nchunks, M, T;
+};
+// FL = activation flags of the layer input (1 BN, 2 ReLU, 4 dropout) or -1 = decide at run time
+template <int FL>
+__device__ __forceinline__ void wg2_act8(float v[8], const float* sc, const float* sh, const BnAct& a, uint32_t row, int c0) {
+  if (FL < 0) { act8(v, sc, sh, a, row, V2_C, c0); return; }
+  if (FL & 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
+  }
+  if (FL & 2) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+  }
+  if (FL & 4) tn_drop8(v, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, a.drop_key, a.drop_thr);
+}
+
+template <int KD, bool DW, int FL>
+__device__ __forceinline__ void wg2_chunks(const WgradV2Desc& d, const WgSeg& sg, f32x16_t (&acc)[4][2]) {
+  constexpr int PADR = (KD - 1) / 2;
+  bf16_t* Pt = sg.Pt; bf16_t* Qt = sg.Qt; bf16_t* Xa = sg.Xa; const float* cst = sg.cst;
+  const int M = sg.M, T = sg.T, chunk0 = sg.chunk0, nchunks = sg.nchunks;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vc = tid & 31, rq = tid >> 5, c0 = vc * 8;
+  const int wa = wave >> 2, wb = wave & 3;
+  uint4 pz[2], py[2], px[3];
+  auto prefetch = [&](int chunk) {
+    const int r0 = chunk * WG2_RK;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int gr = r0 + rq + 16 * q;
+      if (gr < M) {
+        pz[q] = *reinterpret_cast<const uint4*>(d.dZ + (size_t)gr * V2_C + c0);
+        py[q] = *reinterpret_cast<const uint4*>(d.Y + (size_t)gr * V2_C + c0);
+      } else {
+        pz[q] = make_uint4(0, 0, 0, 0); py[q] = make_uint4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int i = rq + 16 * q;               // Xa row 0 .. 47 (need < 32 + KD - 1)
+      const int gr = r0 - PADR + i;
+      if (i < WG2_RK + KD - 1 && gr >= 0 && gr < M) px[q] = *reinterpret_cast<const uint4*>(d.X + (size_t)gr * V2_C + c0);
+      else px[q] = make_uint4(0, 0, 0, 0);
+    }
+  };
+  prefetch(chunk0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int r0 = (chunk0 + ch) * WG2_RK;
+    const bool interior = r0 - PADR >= 0 && r0 + WG2_RK + PADR <= M;               // workgroup-uniform
+    const bool one_utt = interior && ((r0 - PADR) % T) + WG2_RK + 2 * PADR <= T;   // ... rows + halo in ONE utterance
+    __syncthreads();   // previous MFMA done with Pt/Qt; constants visible
+    // ---- P tile: BN backward on load  (out-of-range rows were loaded as zeros; their k2 term only matters
+    //      for rows < M, so it is masked in the non-interior case)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = rq + 16 * q, gr = r0 + r;
+      float z[8], y[8];
+      unpack8(pz[q], z);
+      unpack8(py[q], y);
+      if (interior || gr < M) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) z[i] = cst[c0 + i] * z[i] + cst[V2_C + c0 + i] * y[i] + cst[2 * V2_C + c0 + i];
+      }
+      store8(Pt + r * WG2_PITCH + c0, z);
+      __builtin_amdgcn_sched_barrier(0);   // bound the live temporaries (the 128 accumulators leave ~100 VGPRs)
+    }
+    // ---- activated input rows (with halo)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int i = rq + 16 * q, gr = r0 - PADR + i;
+      if (i < WG2_RK + KD - 1) {
+        float v[8];
+        unpack8(px[q], v);
+        if (interior || (gr >= 0 && gr < M)) wg2_act8<FL>(v, cst + 3 * V2_C + c0, cst + 4 * V2_C + c0, d.actX, (uint32_t)gr, c0);
+        if (DW) store8(Xa + i * V2_C + c0, v);
+        else if (i >= PADR && i < PADR + WG2_RK) store8(Qt + (i - PADR) * WG2_PITCH + c0, v);   // plain 1x1: Q row r = input row r
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ch + 1 < nchunks) prefetch(chunk0 + ch + 1);
+    __syncthreads();
+    if (DW) {
+      if (one_utt) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int r = rq + 16 * q;
+          float o[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = cst[5 * V2_C + c0 + i];
+#pragma unroll
+          for (int k = 0; k < KD; ++k) {
+            float v[8];
+            load8(Xa + (r + k) * V2_C + c0, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = fmaf(cst[(6 + k) * V2_C + c0 + i], v[i], o[i]);
+          }
+          store8(Qt + r * WG2_PITCH + c0, o);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int r = rq + 16 * q;
+          const int t = (r0 + r) % T;
+          float o[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = cst[5 * V2_C + c0 + i];
+#pragma unroll
+          for (int k = 0; k < KD; ++k) {
+            const int tt = t + k - PADR;
+            if (tt >= 0 && tt < T) {
+              float v[8];
+              load8(Xa + (r + k) * V2_C + c0, v);
+#pragma unroll
+              for (int i = 0; i < 8; ++i) o[i] = fmaf(cst[(6 + k) * V2_C + c0 + i], v[i], o[i]);
+            }
+          }
+          store8(Qt + r * WG2_PITCH + c0, o);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+    }
+    // ---- contraction over the 32 rows: 2 k-steps x (4 x 2) MFMA tiles per wave
+#pragma unroll
+    for (int ks = 0; ks < WG2_RK / 16; ++ks) {
+      bf16x8_t af[4], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = wg_frag_v2(Pt, ks * 16, wa * 128 + i * 32, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfr[j] = wg_frag_v2(Qt, ks * 16, wb * 64 + j * 32, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+}
+
 template <int KD>
 __global__ __launch_bounds__(V2_NT, 2) void wgrad_batched_v2_kernel(const WgradV2Desc* __restrict__ descs, int n_layers,
                                                                      int M, int T, int chunks_per_layer,
@@ -96,92 +238,24 @@ __global__ __launch_bounds__(V2_NT, 2) void wgrad_batched_v2_kernel(const WgradV
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    uint4 pz[2], py[2], px[3];
-    auto prefetch = [&](int chunk) {
-      const int r0 = chunk * WG2_RK;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int gr = r0 + rq + 16 * q;
-        if (gr < M) {
-          pz[q] = *reinterpret_cast<const uint4*>(d.dZ + (size_t)gr * V2_C + c0);
-          py[q] = *reinterpret_cast<const uint4*>(d.Y + (size_t)gr * V2_C + c0);
-        } else {
-          pz[q] = make_uint4(0, 0, 0, 0); py[q] = make_uint4(0, 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int i = rq + 16 * q;               // Xa row 0 .. 47 (need < 32 + KD - 1)
-        const int gr = r0 - PADR + i;
-        if (i < WG2_RK + KD - 1 && gr >= 0 && gr < M) px[q] = *reinterpret_cast<const uint4*>(d.X + (size_t)gr * V2_C + c0);
-        else px[q] = make_uint4(0, 0, 0, 0);
-      }
-    };
-    prefetch(chunk0);
-    for (int ch = 0; ch < nchunks; ++ch) {
-      const int r0 = (chunk0 + ch) * WG2_RK;
-      __syncthreads();   // previous MFMA done with Pt/Qt; constants visible
-      // ---- P tile: BN backward on load
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int r = rq + 16 * q, gr = r0 + r;
-        float z[8], y[8];
-        unpack8(pz[q], z);
-        unpack8(py[q], y);
-        if (gr < M) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) z[i] = cst[c0 + i] * z[i] + cst[V2_C + c0 + i] * y[i] + cst[2 * V2_C + c0 + i];
-        }
-        store8(Pt + r * WG2_PITCH + c0, z);
-      }
-      // ---- activated input rows (with halo)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int i = rq + 16 * q, gr = r0 - PADR + i;
-        if (i < WG2_RK + KD - 1) {
-          float v[8];
-          unpack8(px[q], v);
-          if (gr >= 0 && gr < M) act8(v, cst + 3 * V2_C + c0, cst + 4 * V2_C + c0, d.actX, (uint32_t)gr, V2_C, c0);
-          if (dw) store8(Xa + i * V2_C + c0, v);
-          else if (i >= PADR && i < PADR + WG2_RK) store8(Qt + (i - PADR) * WG2_PITCH + c0, v);   // plain 1x1: Q row r = input row r
-        }
-      }
-      if (ch + 1 < nchunks) prefetch(chunk0 + ch + 1);
-      __syncthreads();
+    // the chunk loop is specialised on (depthwise?, activation flags of the layer input): no runtime flag tests
+    // and no boundary tests inside it for interior / single-utterance chunks
+    {
+      const int fl = (d.actX.mode != 0 ? 1 : 0) | (d.actX.relu ? 2 : 0) | (d.actX.drop_thr ? 4 : 0);
+      WgSeg sg{Pt, Qt, Xa, cst, chunk0, nchunks, M, T};
       if (dw) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int r = rq + 16 * q;
-          const int t = (r0 + r) % T;
-          float o[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] = cst[5 * V2_C + c0 + i];
-#pragma unroll
-          for (int k = 0; k < KD; ++k) {
-            const int tt = t + k - PADR;
-            if (tt >= 0 && tt < T) {
-              float v[8];
-              load8(Xa + (r + k) * V2_C + c0, v);
-#pragma unroll
-              for (int i = 0; i < 8; ++i) o[i] = fmaf(cst[(6 + k) * V2_C + c0 + i], v[i], o[i]);
-            }
-          }
-          store8(Qt + r * WG2_PITCH + c0, o);
+        switch (fl) {
+          case 7: wg2_chunks<KD, true, 7>(d, sg, acc); break;
+          case 3: wg2_chunks<KD, true, 3>(d, sg, acc); break;
+          case 0: wg2_chunks<KD, true, 0>(d, sg, acc); break;
+          default: wg2_chunks<KD, true, -1>(d, sg, acc); break;
         }
-        __syncthreads();
-      }
-      // ---- contraction over the 32 rows: 2 k-steps x (4 x 2) MFMA tiles per wave
-#pragma unroll
-      for (int ks = 0; ks < WG2_RK / 16; ++ks) {
-        bf16x8_t af[4], bfr[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = wg_frag_v2(Pt, ks * 16, wa * 128 + i * 32, lane);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bfr[j] = wg_frag_v2(Qt, ks * 16, wb * 64 + j * 32, lane);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      } else {
+        switch (fl) {
+          case 0: wg2_chunks<KD, false, 0>(d, sg, acc); break;
+          case 3: wg2_chunks<KD, false, 3>(d, sg, acc); break;
+          default: wg2_chunks<KD, false, -1>(d, sg, acc); break;
+        }
       }
     }
     // ---- partial slab of this (layer, segment)
