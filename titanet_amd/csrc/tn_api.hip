@@ -166,6 +166,8 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     // TN_V2 = bit mask (debug / A-B): 1 forward sub-block, 2 forward skip conv, 4 batched weight gradients, 8 fused data-gradient kernel; default all
     const int mask = e ? atoi(e) : 15;
     p->use_v2 = (precision == TN_PREC_BF16 && m->cfg.hidden == 256 && m->cfg.kernel == 3) ? mask : 0;
+    const char* pe = getenv("TN_PARTS");
+    if (pe && atoi(pe) > 0) p->combine_parts = atoi(pe);
   }
   const tn_config& c = m->cfg;
   const size_t M = p->M, H = c.hidden, D = c.enc_out, A = c.attn_hidden, Hr = c.hidden / c.se_reduction;
@@ -206,6 +208,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     bw.g = b.take((size_t)batch * H * 4);
     bw.dpre2 = b.take((size_t)batch * H * 4);
     bw.dpre1 = b.take((size_t)batch * Hr * 4);
+    bw.dgate = b.take((size_t)batch * H * 4);
     for (int j = 0; j < c.n_sub_blocks; ++j) bw.dY.push_back(b.take(M * H * e));
     bw.dZk = b.take(M * H * e);
   }
@@ -461,8 +464,18 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
     {
       const int CV = H / 8, TG = 512 / CV;
       size_t smem = (size_t)(3 * H + ((Hr + 3) & ~3) + TG * H) * sizeof(float);
-      hipLaunchKernelGGL(se_squeeze_fc_kernel<AT>, dim3(B), dim3(512), smem, st, (const AT*)cur, acur, T, H, Hr,
-                         params + mb.se_w1, params + mb.se_w2, (float*)(ws + bw.m), (float*)(ws + bw.h), (float*)(ws + bw.g));
+      int rc1 = -1000;
+      if (sizeof(AT) == 2 && H == V2_C && Hr == 16 && (p->use_v2 & 1)) {
+        SeSqueezeV2Args sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.Y = (const bf16_t*)cur; sa.act = acur; sa.W1 = params + mb.se_w1; sa.W2 = params + mb.se_w2;
+        sa.m_out = (float*)(ws + bw.m); sa.h_out = (float*)(ws + bw.h); sa.g_out = (float*)(ws + bw.g); sa.T = T;
+        rc1 = launch_se_squeeze_v2(sa, B, st);
+        if (rc1 > 0) return rc1;
+      }
+      if (rc1 == -1000)
+        hipLaunchKernelGGL(se_squeeze_fc_kernel<AT>, dim3(B), dim3(512), smem, st, (const AT*)cur, acur, T, H, Hr,
+                           params + mb.se_w1, params + mb.se_w2, (float*)(ws + bw.m), (float*)(ws + bw.h), (float*)(ws + bw.g));
       BnAct acts = make_act(p, mb.bnskip, M, training, 0, 0.f, seed, 0);
       uint32_t thr = 0, key = 0;
       float ik = 1.f;
@@ -471,10 +484,22 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
         key = tn_layer_key(seed, (uint32_t)(i * (c.n_sub_blocks + 1) + c.n_sub_blocks));
         ik = 1.f / (1.f - pd);
       }
-      const int rpb = 64;
-      hipLaunchKernelGGL(combine_fwd_kernel<AT>, dim3((M + rpb - 1) / rpb), dim3(256), (size_t)4 * H * sizeof(float), st,
-                         (const AT*)(ws + bw.S), acts, (const AT*)cur, acur, (const float*)(ws + bw.g), (AT*)(ws + bw.OUT), M,
-                         T, H, rpb, thr, key, ik);
+      int rc2 = -1000;
+      if (sizeof(AT) == 2 && H == V2_C && (p->use_v2 & 1)) {
+        CombineFwdV2Args ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.S = (const bf16_t*)(ws + bw.S); ca.actS = acts; ca.Y3 = (const bf16_t*)cur; ca.act3 = acur;
+        ca.gate = (const float*)(ws + bw.g); ca.OUT = (bf16_t*)(ws + bw.OUT); ca.T = T; ca.parts = p->combine_parts;
+        ca.drop_thr = thr; ca.drop_key = key; ca.inv_keep = ik;
+        rc2 = launch_combine_fwd_v2(ca, B, st);
+        if (rc2 > 0) return rc2;
+      }
+      if (rc2 == -1000) {
+        const int rpb = 64;
+        hipLaunchKernelGGL(combine_fwd_kernel<AT>, dim3((M + rpb - 1) / rpb), dim3(256), (size_t)4 * H * sizeof(float), st,
+                           (const AT*)(ws + bw.S), acts, (const AT*)cur, acur, (const float*)(ws + bw.g), (AT*)(ws + bw.OUT), M,
+                           T, H, rpb, thr, key, ik);
+      }
     }
     xin = ws + bw.OUT;
     actx = identity_act();

@@ -181,13 +181,31 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       if (smem > 64 * 1024) TN_CHECK_HIP(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
       hipLaunchKernelGGL(k1, dim3(B), dim3(512), smem, st, (const AT*)(ws + p->dA[cur]), (const AT*)(ws + bw.OUT),
                          (const AT*)(ws + bw.Y[nsub - 1]), act3, (const AT*)(ws + bw.S), acts, T, H, inv_keep, (AT*)(ws + bw.dZk),
-                         (float*)(ws + bw.dpre2), bsum(mb.bnskip));
-      smem = (size_t)(7 * H + ((Hr + 3) & ~3) + TG * 2 * H) * sizeof(float);
-      auto k2 = combine_bwd2_kernel<AT>;
-      if (smem > 64 * 1024) TN_CHECK_HIP(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      hipLaunchKernelGGL(k2, dim3(B), dim3(512), smem, st, (const AT*)(ws + bw.dZk), (const AT*)(ws + bw.Y[nsub - 1]), act3,
-                         (const float*)(ws + bw.g), (const float*)(ws + bw.h), (float*)(ws + bw.dpre2), (float*)(ws + bw.dpre1),
-                         params + mb.se_w1, params + mb.se_w2, T, H, Hr, (AT*)(ws + bw.dY[nsub - 1]), bsum(mb.sub[nsub - 1].bn));
+                         (float*)(ws + ((v2_bwd && Hr == 16) ? bw.dgate : bw.dpre2)), bsum(mb.bnskip));
+      int rc2 = -1000;
+      if (v2_bwd && Hr == 16) {
+        // pass 1 left dgate in bw.dpre2; copy-free hand-over: pass 2 (v2) reads it from bw.dgate, so move the pointer roles:
+        // pass 1 wrote to bw.dgate (see above), pass 2 writes bw.dpre2
+        CombineBwd2V2Args ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.dZ = (const bf16_t*)(ws + bw.dZk); ca.Y3 = (const bf16_t*)(ws + bw.Y[nsub - 1]); ca.act3 = act3;
+        ca.gate = (const float*)(ws + bw.g); ca.hid = (const float*)(ws + bw.h); ca.dgate = (const float*)(ws + bw.dgate);
+        ca.dpre2 = (float*)(ws + bw.dpre2); ca.dpre1 = (float*)(ws + bw.dpre1);
+        ca.W1 = params + mb.se_w1; ca.W2 = params + mb.se_w2; ca.dYbn = (bf16_t*)(ws + bw.dY[nsub - 1]);
+        ca.bsums3 = bsum(mb.sub[nsub - 1].bn); ca.T = T; ca.parts = p->combine_parts >= 2 ? 2 : 1;
+        rc2 = launch_combine_bwd2_v2(ca, B, st);
+        if (rc2 > 0) return rc2;
+      }
+      if (rc2 == -1000) {
+        if (v2_bwd && Hr == 16)   // pass 1 wrote dgate to bw.dgate; the generic pass 2 works in place on bw.dpre2
+          TN_CHECK_HIP(hipMemcpyAsync(ws + bw.dpre2, ws + bw.dgate, (size_t)B * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+        smem = (size_t)(7 * H + ((Hr + 3) & ~3) + TG * 2 * H) * sizeof(float);
+        auto k2 = combine_bwd2_kernel<AT>;
+        if (smem > 64 * 1024) TN_CHECK_HIP(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(k2, dim3(B), dim3(512), smem, st, (const AT*)(ws + bw.dZk), (const AT*)(ws + bw.Y[nsub - 1]), act3,
+                           (const float*)(ws + bw.g), (const float*)(ws + bw.h), (float*)(ws + bw.dpre2), (float*)(ws + bw.dpre1),
+                           params + mb.se_w1, params + mb.se_w2, T, H, Hr, (AT*)(ws + bw.dY[nsub - 1]), bsum(mb.sub[nsub - 1].bn));
+      }
     }
     // ---- skip connection: d S = BN-backward(dZ); dXs = dS * W_skip; d W_skip = dS^T X
     {

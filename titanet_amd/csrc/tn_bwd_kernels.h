@@ -428,6 +428,7 @@ __global__ __launch_bounds__(512) void combine_bwd1_kernel(const AT* __restrict_
     float dg[8], s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { dg[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
+#pragma unroll 4
     for (int t = tg; t < T; t += TG) {
       const uint32_t row = (uint32_t)b * T + t;
       const size_t o = (size_t)row * C + c0;
@@ -524,6 +525,7 @@ __global__ __launch_bounds__(512) void combine_bwd2_kernel(const AT* __restrict_
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+#pragma unroll 4
     for (int t = tg; t < T; t += TG) {
       const uint32_t row = (uint32_t)b * T + t;
       const size_t o = (size_t)row * C + c0;

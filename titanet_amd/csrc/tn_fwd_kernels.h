@@ -53,6 +53,7 @@ __global__ __launch_bounds__(512) void se_squeeze_fc_kernel(const AT* __restrict
     float s[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = 0.f;
+#pragma unroll 4
     for (int t = tg; t < T; t += TG) {
       const uint32_t row = (uint32_t)b * T + t;
       float v[8];

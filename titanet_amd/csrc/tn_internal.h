@@ -65,7 +65,7 @@ struct BlockWs {
   std::vector<WcRef> wpw;
   WcRef wskip;
   // backward (float): SE pre-activation grads
-  size_t dpre2, dpre1;
+  size_t dpre2, dpre1, dgate;
   // per-layer activation gradients kept for the batched weight-gradient launch (v2)
   std::vector<size_t> dY;   // d loss / d BN-output of sub-block j
   size_t dZk;               // d loss / d BN-output of the skip connection
@@ -86,6 +86,7 @@ struct tn_plan {
   bool bound = false;
   // workspace layout (byte offsets)
   size_t zero_begin, zero_bytes;        // region cleared at the start of every forward
+  int combine_parts = 4;                // row parts per utterance of the v2 element-wise kernels (env TN_PARTS)
   size_t bzero_begin, bzero_bytes;      // region cleared at the start of every backward
   std::vector<size_t> stats;            // per BN id: forward sums  float[NREP][2][C]
   std::vector<size_t> bsums;            // per BN id: backward sums float[NREP][2][C]

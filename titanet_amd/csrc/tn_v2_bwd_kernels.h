@@ -1042,6 +1042,142 @@ inline int launch_dw_bwd_v4(DwBwdV3Args a, int max_wgs, hipStream_t st) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// combine_bwd2_v2: mega-block tail backward, pass 2, for hidden = 256 / bf16 / Hr = 16: SE backward (tiny
+// mat-vecs, reference src/modules.py:182-189), then  dA3 = dZ * g + dmean / T ;  dY3bn = dA3 * d act3 / d bn
+// -> stored + BN3 backward sums.  `parts` workgroups per utterance (each repeats the tiny SE backward and streams
+// its share of the rows: 16 waves per CU overlap each other's serial prologue with streaming); per-thread
+// constants in registers; the first rows are already in flight while the prologue runs.
+// dgate comes from pass 1 in its own buffer (pass 2 of part 0 writes dpre2 / dpre1 for the SE weight gradients).
+// ------------------------------------------------------------------------------------------
+struct CombineBwd2V2Args {
+  const bf16_t* dZ; const bf16_t* Y3; BnAct act3;
+  const float* gate; const float* hid; const float* dgate;
+  float* dpre2; float* dpre1;
+  const float* W1;    // [16][256]
+  const float* W2;    // [256][16]
+  bf16_t* dYbn;
+  float* bsums3;
+  int T, parts;
+};
+template <int FL3>
+__global__ __launch_bounds__(512) void combine_bwd2_v2_kernel(CombineBwd2V2Args a) {
+  constexpr int HR = 16;
+  __shared__ float cst[4 * V2_C];       // sc3, sh3, mean3*rstd3, rstd3
+  __shared__ float gS[V2_C], dmT[V2_C], p2[V2_C], p1[HR];
+  __shared__ float part[16][2][V2_C];
+  const int tid = threadIdx.x, vc = tid & 31, tg = tid >> 5, c0 = vc * 8;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / a.parts, prt = blockIdx.x % a.parts;
+  const int per = (a.T + a.parts - 1) / a.parts;
+  const int t0 = prt * per, t1 = min(a.T, t0 + per);
+  constexpr int U = 2;
+  uint4 rd[U], ry[U];
+  auto fetch = [&](int tb) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = tb + 16 * u;
+      if (t < t1) {
+        const size_t o = ((size_t)b * a.T + t) * V2_C + c0;
+        rd[u] = *reinterpret_cast<const uint4*>(a.dZ + o);
+        ry[u] = *reinterpret_cast<const uint4*>(a.Y3 + o);
+      }
+    }
+  };
+  fetch(t0 + tg);                        // in flight during the SE-backward prologue
+  if (tid < V2_C) {
+    float s = 1.f, h = 0.f, mean = 0.f, rstd = 1.f;
+    if (FL3 & 1) { bn_scale_shift(a.act3, V2_C, tid, s, h); bn_mean_rstd(a.act3, V2_C, tid, mean, rstd); }
+    cst[tid] = s; cst[V2_C + tid] = h; cst[2 * V2_C + tid] = mean * rstd; cst[3 * V2_C + tid] = rstd;
+    const float g = a.gate[(size_t)b * V2_C + tid];
+    gS[tid] = g;
+    const float d2 = a.dgate[(size_t)b * V2_C + tid] * g * (1.f - g);
+    p2[tid] = d2;
+    if (prt == 0) a.dpre2[(size_t)b * V2_C + tid] = d2;
+  }
+  __syncthreads();
+  // p1[j] = relu'(hid[j]) * sum_c W2[c][j] p2[c]  (2 outputs per wave)
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int j = wave + 8 * jj;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s = fmaf(a.W2[(size_t)(lane + 64 * k) * HR + j], p2[lane + 64 * k], s);
+    s = wave_sum(s);
+    if (lane == 0) {
+      s = (a.hid[(size_t)b * HR + j] > 0.f) ? s : 0.f;
+      p1[j] = s;
+      if (prt == 0) a.dpre1[(size_t)b * HR + j] = s;
+    }
+  }
+  __syncthreads();
+  if (tid < V2_C) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < HR; ++j) s = fmaf(a.W1[(size_t)j * V2_C + tid], p1[j], s);
+    dmT[tid] = s / (float)a.T;
+  }
+  __syncthreads();
+  float sc[8], sh[8], g[8], dm[8], s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    sc[i] = cst[c0 + i]; sh[i] = cst[V2_C + c0 + i]; g[i] = gS[c0 + i]; dm[i] = dmT[c0 + i]; s1[i] = 0.f; s2[i] = 0.f;
+  }
+  const float on = (FL3 & 4) ? a.act3.inv_keep : 1.f;
+  const uint32_t dkey = a.act3.drop_key, dthr = a.act3.drop_thr;
+  for (int tb = t0 + tg; tb < t1; tb += 16 * U) {
+    uint4 cd[U], cy[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { cd[u] = rd[u]; cy[u] = ry[u]; }
+    fetch(tb + 16 * U);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = tb + 16 * u;
+      if (t < t1) {
+        const uint32_t row = (uint32_t)b * a.T + t;
+        float d[8], y[8], m[8];
+        unpack8(cd[u], d);
+        unpack8(cy[u], y);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float z = (FL3 & 1) ? fmaf(y[i], sc[i], sh[i]) : y[i];
+          m[i] = (!(FL3 & 2) || z > 0.f) ? on : 0.f;
+        }
+        if (FL3 & 4) tn_drop8(m, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, dkey, dthr);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float v = fmaf(d[i], g[i], dm[i]) * m[i];
+          d[i] = v;
+          s1[i] += v;
+          s2[i] = fmaf(v, y[i], s2[i]);          // against the raw y; converted to xhat below (linear)
+        }
+        store8(a.dYbn + (size_t)row * V2_C + c0, d);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    part[tg][0][c0 + i] = s1[i];
+    part[tg][1][c0 + i] = cst[3 * V2_C + c0 + i] * s2[i] - cst[2 * V2_C + c0 + i] * s1[i];
+  }
+  __syncthreads();
+  {
+    const int which = tid >> 8, c = tid & 255;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += part[k][which][c];
+    atomic_add_f32(&a.bsums3[(size_t)((blockIdx.x % TN_NREP) * 2 + which) * V2_C + c], v);
+  }
+}
+inline int launch_combine_bwd2_v2(const CombineBwd2V2Args& a, int B, hipStream_t st) {
+  const int fl = (a.act3.mode != 0 ? 1 : 0) | (a.act3.relu ? 2 : 0) | (a.act3.drop_thr ? 4 : 0);
+  const dim3 grid(B * a.parts), blk(512);
+  if (fl == 7) hipLaunchKernelGGL((combine_bwd2_v2_kernel<7>), grid, blk, 0, st, a);
+  else if (fl == 3) hipLaunchKernelGGL((combine_bwd2_v2_kernel<3>), grid, blk, 0, st, a);
+  else return -1000;
+  return (int)hipGetLastError();
+}
+
 // ==========================================================================================
 // Pointwise data gradient, lean version:  dD = BatchNorm-backward-on-load(dZ, Y) * W
 // (the 1x1-conv dgrad of sub-blocks and skip connections).  R rows per tile; R = 32 keeps the kernel

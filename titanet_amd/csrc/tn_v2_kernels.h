@@ -523,3 +523,191 @@ inline int launch_sub_fwd_v4(SubFwdV2Args a, int resident_wgs, hipStream_t st) {
     default: return launch_sub_fwd_v2<KD, DW>(a, resident_wgs, st);
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// combine_fwd_v2: OUT = dropout(relu(BN(S) + g * act3(Y3))) for hidden = 256, bf16 (reference src/models.py:467-472).
+// One workgroup per (utterance, row part); a thread owns a FIXED 8-channel vector, so the two BatchNorm
+// scale/shift pairs and the SE gate live in registers (the generic kernel re-read them from LDS per element and
+// spent ~60 instructions per vector on integer div/mod of a flat index); rows are 4-way unrolled so 8 loads fly.
+// FL3 = activation flags of Y3 (1 BN, 2 ReLU, 4 dropout); DROP = dropout on the block output.
+// ------------------------------------------------------------------------------------------
+struct CombineFwdV2Args {
+  const bf16_t* S; BnAct actS;
+  const bf16_t* Y3; BnAct act3;
+  const float* gate;     // [B][256]
+  bf16_t* OUT;
+  int T, parts;
+  uint32_t drop_thr, drop_key;
+  float inv_keep;
+};
+template <int FL3, bool DROP>
+__global__ __launch_bounds__(256) void combine_fwd_v2_kernel(CombineFwdV2Args a) {
+  __shared__ float cst[4 * V2_C];
+  const int tid = threadIdx.x, vc = tid & 31, rq = tid >> 5, c0 = vc * 8;
+  const int b = blockIdx.x / a.parts, part = blockIdx.x % a.parts;
+  {
+    float s, h;
+    bn_scale_shift(a.actS, V2_C, tid, s, h);
+    cst[tid] = s; cst[V2_C + tid] = h;
+    s = 1.f; h = 0.f;
+    if (FL3 & 1) bn_scale_shift(a.act3, V2_C, tid, s, h);
+    cst[2 * V2_C + tid] = s; cst[3 * V2_C + tid] = h;
+  }
+  float g[8];
+  {
+    const float4 g0 = *reinterpret_cast<const float4*>(a.gate + (size_t)b * V2_C + c0);
+    const float4 g1 = *reinterpret_cast<const float4*>(a.gate + (size_t)b * V2_C + c0 + 4);
+    g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+  }
+  __syncthreads();
+  float scS[8], shS[8], sc3[8], sh3[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    scS[i] = cst[c0 + i]; shS[i] = cst[V2_C + c0 + i]; sc3[i] = cst[2 * V2_C + c0 + i]; sh3[i] = cst[3 * V2_C + c0 + i];
+    if (DROP) { scS[i] *= a.inv_keep; shS[i] *= a.inv_keep; g[i] *= a.inv_keep; }   // relu(k x) = k relu(x), k > 0
+  }
+  const int per = (a.T + a.parts - 1) / a.parts;
+  const int t0 = part * per, t1 = min(a.T, t0 + per);
+  const uint32_t dkey3 = a.act3.drop_key, dthr3 = a.act3.drop_thr;
+  constexpr int U = 4;
+  for (int tb = t0 + rq; tb < t1; tb += 8 * U) {
+    uint4 rs[U], ry[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = tb + 8 * u;
+      if (t < t1) {
+        const size_t o = ((size_t)b * a.T + t) * V2_C + c0;
+        rs[u] = *reinterpret_cast<const uint4*>(a.S + o);
+        ry[u] = *reinterpret_cast<const uint4*>(a.Y3 + o);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = tb + 8 * u;
+      if (t < t1) {
+        const uint32_t row = (uint32_t)b * a.T + t;
+        float s[8], y[8], o[8];
+        unpack8(rs[u], s);
+        unpack8(ry[u], y);
+        act8_t<FL3>(y, sc3, sh3, dkey3, dthr3, row, c0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = fmaxf(fmaf(s[q], scS[q], fmaf(g[q], y[q], shS[q])), 0.f);
+        if (DROP) tn_drop8(o, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, a.drop_key, a.drop_thr);
+        store8(a.OUT + (size_t)row * V2_C + c0, o);
+      }
+    }
+  }
+}
+inline int launch_combine_fwd_v2(const CombineFwdV2Args& a, int B, hipStream_t st) {
+  const int fl3 = (a.act3.mode != 0 ? 1 : 0) | (a.act3.relu ? 2 : 0) | (a.act3.drop_thr ? 4 : 0);
+  const dim3 grid(B * a.parts), blk(256);
+  if (fl3 == 7 && a.drop_thr) hipLaunchKernelGGL((combine_fwd_v2_kernel<7, true>), grid, blk, 0, st, a);
+  else if (fl3 == 3 && !a.drop_thr) hipLaunchKernelGGL((combine_fwd_v2_kernel<3, false>), grid, blk, 0, st, a);
+  else return -1000;      // caller falls back to the generic kernel
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// se_squeeze_v2: m = mean_T act3(Y3); h = relu(W1 m); g = sigmoid(W2 h) for hidden = 256, bf16, Hr = 16
+// (reference src/modules.py:173-189).  One workgroup (512 threads = 32 channel vectors x 16 row phases) per
+// utterance; constants in registers, 4 rows in flight per thread, and the two tiny weight matrices are fetched
+// BEFORE the streaming loop so that the serial mat-vec tail does not wait on HBM.
+// ------------------------------------------------------------------------------------------
+struct SeSqueezeV2Args {
+  const bf16_t* Y; BnAct act;
+  const float* W1;     // [16][256]
+  const float* W2;     // [256][16]
+  float* m_out; float* h_out; float* g_out;
+  int T;
+};
+template <int FL>
+__global__ __launch_bounds__(512) void se_squeeze_v2_kernel(SeSqueezeV2Args a) {
+  constexpr int HR = 16;
+  __shared__ float cst[2 * V2_C];
+  __shared__ float part[16][V2_C];
+  __shared__ float mean[V2_C];
+  __shared__ float hbuf[HR];
+  const int tid = threadIdx.x, vc = tid & 31, tg = tid >> 5, c0 = vc * 8, b = blockIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  // weights of the tail, in flight during the streaming loop
+  float w1a[4], w1b[4];      // W1 rows wave and wave + 8, columns lane + 64 k
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { w1a[k] = a.W1[(size_t)wave * V2_C + lane + 64 * k]; w1b[k] = a.W1[(size_t)(wave + 8) * V2_C + lane + 64 * k]; }
+  float4 w2[4];              // W2 row tid (tid < 256)
+  if (tid < V2_C) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w2[k] = *reinterpret_cast<const float4*>(a.W2 + (size_t)tid * HR + 4 * k);
+  }
+  if (tid < V2_C) {
+    float s = 1.f, h = 0.f;
+    if (FL & 1) bn_scale_shift(a.act, V2_C, tid, s, h);
+    cst[tid] = s; cst[V2_C + tid] = h;
+  }
+  __syncthreads();
+  float sc[8], sh[8], acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { sc[i] = cst[c0 + i]; sh[i] = cst[V2_C + c0 + i]; acc[i] = 0.f; }
+  const uint32_t dkey = a.act.drop_key, dthr = a.act.drop_thr;
+  constexpr int U = 4;
+  for (int tb = tg; tb < a.T; tb += 16 * U) {
+    uint4 ry[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = tb + 16 * u;
+      if (t < a.T) ry[u] = *reinterpret_cast<const uint4*>(a.Y + ((size_t)b * a.T + t) * V2_C + c0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = tb + 16 * u;
+      if (t < a.T) {
+        float v[8];
+        unpack8(ry[u], v);
+        act8_t<FL>(v, sc, sh, dkey, dthr, (uint32_t)b * a.T + t, c0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += v[i];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) part[tg][c0 + i] = acc[i];
+  __syncthreads();
+  if (tid < V2_C) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += part[k][tid];
+    s *= 1.f / (float)a.T;
+    mean[tid] = s;
+    a.m_out[(size_t)b * V2_C + tid] = s;
+  }
+  __syncthreads();
+  {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s0 = fmaf(w1a[k], mean[lane + 64 * k], s0); s1 = fmaf(w1b[k], mean[lane + 64 * k], s1); }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if (lane == 0) {
+      s0 = fmaxf(s0, 0.f); s1 = fmaxf(s1, 0.f);
+      hbuf[wave] = s0; hbuf[wave + 8] = s1;
+      a.h_out[(size_t)b * HR + wave] = s0;
+      a.h_out[(size_t)b * HR + wave + 8] = s1;
+    }
+  }
+  __syncthreads();
+  if (tid < V2_C) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s = fmaf(w2[k].x, hbuf[4 * k], s); s = fmaf(w2[k].y, hbuf[4 * k + 1], s);
+      s = fmaf(w2[k].z, hbuf[4 * k + 2], s); s = fmaf(w2[k].w, hbuf[4 * k + 3], s);
+    }
+    a.g_out[(size_t)b * V2_C + tid] = 1.f / (1.f + __expf(-s));
+  }
+}
+inline int launch_se_squeeze_v2(const SeSqueezeV2Args& a, int B, hipStream_t st) {
+  const int fl = (a.act.mode != 0 ? 1 : 0) | (a.act.relu ? 2 : 0) | (a.act.drop_thr ? 4 : 0);
+  if (fl == 7) hipLaunchKernelGGL((se_squeeze_v2_kernel<7>), dim3(B), dim3(512), 0, st, a);
+  else if (fl == 3) hipLaunchKernelGGL((se_squeeze_v2_kernel<3>), dim3(B), dim3(512), 0, st, a);
+  else return -1000;
+  return (int)hipGetLastError();
+}
