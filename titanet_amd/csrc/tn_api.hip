@@ -9,6 +9,7 @@
 #include "tn_gemm.h"
 #include "tn_internal.h"
 #include "tn_v2_kernels.h"
+#include "tn_v2_wide_kernels.h"
 
 // =============================================================================================
 // model layout == reference state_dict (reference src/models.py:370-384, :432-455, :504-513,
@@ -164,7 +165,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   {
     const char* e = getenv("TN_V2");
     // TN_V2 = bit mask (debug / A-B): 1 forward sub-block, 2 forward skip conv, 4 batched weight gradients, 8 fused data-gradient kernel; default all
-    const int mask = e ? atoi(e) : 15;
+    const int mask = e ? atoi(e) : 31;   // 16: wide (1536-channel) decoder-side kernels
     p->use_v2 = (precision == TN_PREC_BF16 && m->cfg.hidden == 256 && m->cfg.kernel == 3) ? mask : 0;
     const char* pe = getenv("TN_PARTS");
     if (pe && atoi(pe) > 0) p->combine_parts = atoi(pe);
@@ -506,24 +507,51 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   }
   // ---- epilog 1x1 conv (reference src/models.py:384, :404)
   {
-    GemmShape g{M, D, H, wsel<AT>(p, m->epi_w, p->wepi)};
-    ProdPlain::Args pa{xin, H, actx};
-    EpiStoreArgs ea{ws + p->E, D, params + m->epi_b, statp(m->epi_bn)};
-    int rc = gemm_store<AT, ProdPlain>(g, pa, ea, 0, st);
-    if (rc) return rc;
+    const bool wide = sizeof(AT) == 2 && (p->use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128;
+    if (wide && actx.mode == 0 && !actx.relu && !actx.drop_thr) {
+      WideOutArgs wa;
+      memset(&wa, 0, sizeof(wa));
+      wa.X = (const bf16_t*)xin; wa.W = (const bf16_t*)wsel<AT>(p, m->epi_w, p->wepi); wa.bias = params + m->epi_b;
+      wa.Y = (bf16_t*)(ws + p->E); wa.stats = statp(m->epi_bn); wa.M = M; wa.N = D;
+      int rc = launch_wide_out_v2<256, 0>(wa, 256, st);
+      if (rc) return rc;
+    } else {
+      GemmShape g{M, D, H, wsel<AT>(p, m->epi_w, p->wepi)};
+      ProdPlain::Args pa{xin, H, actx};
+      EpiStoreArgs ea{ws + p->E, D, params + m->epi_b, statp(m->epi_bn)};
+      int rc = gemm_store<AT, ProdPlain>(g, pa, ea, 0, st);
+      if (rc) return rc;
+    }
   }
   BnAct acte = make_act(p, m->epi_bn, M, training, 1, 0.f, seed, 0);
   // ---- attentive statistics pooling (reference src/models.py:553-584)
   {
-    GemmShape g1{M, A, D, wsel<AT>(p, m->asp_win, p->wwin)};
-    ProdPlain::Args pa1{ws + p->E, D, acte};
-    EpiStoreArgs ea1{ws + p->HID, A, params + m->asp_bin, nullptr};
-    int rc = gemm_store<AT, ProdPlain, EpiStoreTanh>(g1, pa1, ea1, 0, st);
+    int rc;
+    if (sizeof(AT) == 2 && (p->use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128) {
+      WideInArgs wa;
+      memset(&wa, 0, sizeof(wa));
+      wa.A = (const bf16_t*)(ws + p->E); wa.act = acte; wa.W = (const bf16_t*)wsel<AT>(p, m->asp_win, p->wwin);
+      wa.bias = params + m->asp_bin; wa.Y = (bf16_t*)(ws + p->HID); wa.M = M; wa.KW = D;
+      rc = launch_wide_in_v2<0>(wa, 256, st);
+    } else {
+      GemmShape g1{M, A, D, wsel<AT>(p, m->asp_win, p->wwin)};
+      ProdPlain::Args pa1{ws + p->E, D, acte};
+      EpiStoreArgs ea1{ws + p->HID, A, params + m->asp_bin, nullptr};
+      rc = gemm_store<AT, ProdPlain, EpiStoreTanh>(g1, pa1, ea1, 0, st);
+    }
     if (rc) return rc;
-    GemmShape g2{M, D, A, wsel<AT>(p, m->asp_wout, p->wwout)};
-    ProdPlain::Args pa2{ws + p->HID, A, identity_act()};
-    EpiStoreArgs ea2{ws + p->EN, D, params + m->asp_bout, nullptr};
-    rc = gemm_store<AT, ProdPlain>(g2, pa2, ea2, 0, st);
+    if (sizeof(AT) == 2 && (p->use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128) {
+      WideOutArgs wa;
+      memset(&wa, 0, sizeof(wa));
+      wa.X = (const bf16_t*)(ws + p->HID); wa.W = (const bf16_t*)wsel<AT>(p, m->asp_wout, p->wwout); wa.bias = params + m->asp_bout;
+      wa.Y = (bf16_t*)(ws + p->EN); wa.M = M; wa.N = D;
+      rc = launch_wide_out_v2<128, 0>(wa, 256, st);
+    } else {
+      GemmShape g2{M, D, A, wsel<AT>(p, m->asp_wout, p->wwout)};
+      ProdPlain::Args pa2{ws + p->HID, A, identity_act()};
+      EpiStoreArgs ea2{ws + p->EN, D, params + m->asp_bout, nullptr};
+      rc = gemm_store<AT, ProdPlain>(g2, pa2, ea2, 0, st);
+    }
     if (rc) return rc;
     hipLaunchKernelGGL(asp_pool_fwd_kernel<AT>, dim3(B, (D + 511) / 512), dim3(256), 0, st, (const AT*)(ws + p->E), acte,
                        (const AT*)(ws + p->EN), T, D, 1e-6f, (float*)(ws + p->pooled), (float*)(ws + p->smax),

@@ -7,6 +7,7 @@
 #include "tn_bwd_kernels.h"
 #include "tn_internal.h"
 #include "tn_v2_bwd_kernels.h"
+#include "tn_v2_wide_kernels.h"
 
 namespace {
 
@@ -125,10 +126,19 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     }
     // d hid_pre = (dEN * W_out) .* (1 - hid^2)
     {
-      GemmShape g{M, A, D, wt(p->wwout)};
-      ProdPlain::Args pa{ws + p->dE, D, identity_act()};
-      EpiTanhBwd::Args ea{ws + p->dHP, A, ws + p->HID, grads + m->asp_bin};
-      int rc = gemm_any<AT, ProdPlain, EpiTanhBwd>(g, pa, ea, st);
+      int rc;
+      if (sizeof(AT) == 2 && (p->use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128) {
+        WideInArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        wa.A = (const bf16_t*)(ws + p->dE); wa.W = (const bf16_t*)wt(p->wwout); wa.H = (const bf16_t*)(ws + p->HID);
+        wa.colsum = grads + m->asp_bin; wa.Y = (bf16_t*)(ws + p->dHP); wa.M = M; wa.KW = D;
+        rc = launch_wide_in_v2<1>(wa, 256, st);
+      } else {
+        GemmShape g{M, A, D, wt(p->wwout)};
+        ProdPlain::Args pa{ws + p->dE, D, identity_act()};
+        EpiTanhBwd::Args ea{ws + p->dHP, A, ws + p->HID, grads + m->asp_bin};
+        rc = gemm_any<AT, ProdPlain, EpiTanhBwd>(g, pa, ea, st);
+      }
       if (rc) return rc;
     }
     // d W_in[a][c] = sum_r dHP[r][a] * x[r][c],  x = act(E)
@@ -140,10 +150,19 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     }
     // d x = dHP * W_in + direct term; through the epilog relu -> dEbn (+ BN backward sums)
     {
-      GemmShape g{M, D, A, wt(p->wwin)};
-      ProdPlain::Args pa{ws + p->dHP, A, identity_act()};
-      EpiAddMaskStore::Args ea{ws + p->dEbn, D, ws + p->E, acte, bsum(m->epi_bn)};
-      int rc = gemm_any<AT, ProdPlain, EpiAddMaskStore>(g, pa, ea, st);
+      int rc;
+      if (sizeof(AT) == 2 && (p->use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128) {
+        WideOutArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        wa.X = (const bf16_t*)(ws + p->dHP); wa.W = (const bf16_t*)wt(p->wwin); wa.Y = (bf16_t*)(ws + p->dEbn);
+        wa.RAW = (const bf16_t*)(ws + p->E); wa.actR = acte; wa.bsums = bsum(m->epi_bn); wa.M = M; wa.N = D;
+        rc = launch_wide_out_v2<128, 2>(wa, 256, st);
+      } else {
+        GemmShape g{M, D, A, wt(p->wwin)};
+        ProdPlain::Args pa{ws + p->dHP, A, identity_act()};
+        EpiAddMaskStore::Args ea{ws + p->dEbn, D, ws + p->E, acte, bsum(m->epi_bn)};
+        rc = gemm_any<AT, ProdPlain, EpiAddMaskStore>(g, pa, ea, st);
+      }
       if (rc) return rc;
     }
   }
