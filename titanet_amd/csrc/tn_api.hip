@@ -186,7 +186,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   //      loss.backward(retain_graph=True) twice): BN-backward sums, split-K counters, depthwise accumulators
   p->bzero_begin = b.take(0);
   for (int i = 0; i < m->n_bn; ++i) p->bsums[i] = b.take((size_t)TN_NREP * 2 * m->all_bn[i].C * sizeof(float));
-  p->wg2_count = b.take(sizeof(int) * (size_t)(c.n_mega_blocks * (c.n_sub_blocks + 1) + 1));
+  p->wg2_count = b.take(sizeof(int) * (size_t)(c.n_mega_blocks * (c.n_sub_blocks + 1) + D / 256 + 1));
   p->dw_gacc = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * TN_NREP * (c.kernel + 1) * H * sizeof(float));
   p->bzero_bytes = ((b.off + 255) & ~(size_t)255) - p->bzero_begin;
   b.off = p->bzero_begin + p->bzero_bytes;
@@ -249,6 +249,9 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   }
   if (p->use_v2) {
     p->wg2_layers = c.n_mega_blocks * (c.n_sub_blocks + 1);
+    // the epilog conv's weight gradient rides along as D / 256 slabs of 256 output channels
+    p->wg2_epi_slabs = (c.n_mega_blocks > 0 && D % 256 == 0 && (p->use_v2 & 16)) ? (int)(D / 256) : 0;
+    p->wg2_layers += p->wg2_epi_slabs;
     p->wg2_grid = 256;
     const int chunks = (p->M + 31) / 32;
     const long total = (long)p->wg2_layers * chunks;

@@ -176,8 +176,10 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     ProdDy::Args pa{ws + p->dEbn, ws + p->E, D, make_bnbwd(p, m->epi_bn, M, training)};
     {
       ProdPlain::Args qa{x_last, H, act_last};
-      int rc = launch_wgrad<AT, ProdDy, ProdPlain>(M, D, H, pa, qa, 0, slabs, p->slab_bytes, grads + m->epi_w, st);
-      if (rc) return rc;
+      if (!(batched_wgrad && p->wg2_epi_slabs > 0)) {
+        int rc = launch_wgrad<AT, ProdDy, ProdPlain>(M, D, H, pa, qa, 0, slabs, p->slab_bytes, grads + m->epi_w, st);
+        if (rc) return rc;
+      }
     }
     GemmShape g{M, H, D, wt(p->wepi)};
     EpiStoreArgs ea{ws + p->dA[cur], H, nullptr, nullptr};
@@ -433,6 +435,7 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
       d.drop_layer = drop_layer;
       d.wdw = wdw >= 0 ? p->params + wdw : nullptr;
       d.bdw = bdw >= 0 ? p->params + bdw : nullptr;
+      d.ldp = 256; d.statC = 256; d.chan0 = 0;
       d.slabs = (float*)(p->ws + p->wg2_slabs) + wd.size() * slab_stride;
       WgradV2Out o{d.slabs, p->grads + wout};
       wd.push_back(d);
@@ -451,6 +454,14 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
         add(bw.dY[j], bw.Y[j], mb.sub[j].bn, sin, asin, i * (nsub + 1) + j - 1, mb.sub[j].wdw, mb.sub[j].bdw, mb.sub[j].wpw);
       }
     }
+    // epilog conv: d W[s*256 .. +256][256] = BN-backward(dEbn, E)[:, slab s]^T * x_last   (x_last = last block output, stored activated)
+    for (int sl = 0; sl < p->wg2_epi_slabs; ++sl) {
+      const int D = c.enc_out;
+      add(p->dEbn + (size_t)sl * 256 * sizeof(bf16_t), p->E + (size_t)sl * 256 * sizeof(bf16_t), m->epi_bn,
+          (const void*)(p->ws + p->blk[c.n_mega_blocks - 1].OUT), identity_act(), 0, -1, -1, m->epi_w + (int64_t)sl * 256 * 256);
+      wd.back().ldp = D; wd.back().statC = D; wd.back().chan0 = sl * 256;
+    }
+    if ((int)wd.size() != p->wg2_layers) return TN_E_STATE;
     if (sizeof(WgradV2Desc) > 256 || sizeof(WgradV2Out) > 16) return TN_E_STATE;
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_desc, wd.data(), wd.size() * sizeof(WgradV2Desc), hipMemcpyHostToDevice, st));
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_out, wo.data(), wo.size() * sizeof(WgradV2Out), hipMemcpyHostToDevice, st));

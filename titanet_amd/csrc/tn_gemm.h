@@ -256,16 +256,23 @@ struct ProdIm2col {
     constexpr int BK = CW, BKP = PITCH, BM = ROWS;
     struct { int M, K; } g{M, K};
     const int pad = (a.KP - 1) / 2;
-    // consecutive threads -> consecutive rows (t) for coalesced reads of the T-contiguous input
-    for (int i = tid; i < BM * BK; i += NT) {
-      const int r = i % BM, kk = i / BM;
-      const int gr = r0 + r, k = kc + kk;
+    // consecutive threads -> consecutive rows (t) for coalesced reads of the T-contiguous input.  The row of a
+    // thread is the same for all its elements (NT is a multiple of BM), so the row -> (utterance, frame) division
+    // happens once per call; k -> (mel, tap) uses a constant divisor for the reference's prolog kernel size 3.
+    static_assert(NT % BM == 0, "thread count must be a multiple of the tile rows");
+    const int r = tid % BM, gr = r0 + r;
+    const bool row_ok = gr < g.M;
+    const int b = row_ok ? gr / a.T : 0, t = row_ok ? gr - b * a.T : 0;
+    const float* xb = a.x + (size_t)b * a.n_mels * a.T;
+    for (int kk = tid / BM; kk < BK; kk += NT / BM) {
+      const int k = kc + kk;
       float v = 0.f;
-      if (gr < g.M && k < g.K) {
-        const int b = gr / a.T, t = gr % a.T;
-        const int ci = k / a.KP, j = k % a.KP;
+      if (row_ok && k < g.K) {
+        int ci, j;
+        if (a.KP == 3) { ci = (int)((unsigned)k / 3u); j = k - 3 * ci; }
+        else { ci = k / a.KP; j = k - ci * a.KP; }
         const int tt = t + j - pad;
-        if (tt >= 0 && tt < a.T) v = a.x[((size_t)b * a.n_mels + ci) * a.T + tt];
+        if (tt >= 0 && tt < a.T) v = xb[(size_t)ci * a.T + tt];
       }
       As[r * BKP + kk] = Elem<AT>::from_f(v);
     }

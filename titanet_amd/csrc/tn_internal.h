@@ -112,7 +112,7 @@ struct tn_plan {
   size_t bwd_table, bwd_table_eval, se_table;
   size_t wg2_desc, wg2_out, wg2_count, wg2_slabs;   // batched weight-gradient launch (v2)
   size_t dw_gacc, dw_table;                         // depthwise gradient accumulators [layer][NREP][KD+1][256] + finalize table
-  int wg2_layers = 0, wg2_maxparts = 0, wg2_units_per_wg = 0, wg2_grid = 0;
+  int wg2_layers = 0, wg2_maxparts = 0, wg2_units_per_wg = 0, wg2_grid = 0, wg2_epi_slabs = 0;
   size_t bwd_table_bytes = 0;
   // per-kernel event timing (tn_profile_*)
   int prof_class = 0;

@@ -48,6 +48,8 @@ struct WgradV2Desc {
   const float* bdw;
   float* slabs;          // [max_parts][256*256] partial sums of this layer
   int drop_layer;        // dropout stream id of actX (key = tn_layer_key(seed, drop_layer)), set per step on device
+  int ldp;               // row stride (elements) of dZ / Y: 256, or the full width when the layer is a 256-channel slab of a wider tensor
+  int statC, chan0;      // channel count of the BN statistics arrays and this slab's first channel in them
 };
 
 
@@ -85,8 +87,8 @@ __device__ __forceinline__ void wg2_chunks(const WgradV2Desc& d, const WgSeg& sg
     for (int q = 0; q < 2; ++q) {
       const int gr = r0 + rq + 16 * q;
       if (gr < M) {
-        pz[q] = *reinterpret_cast<const uint4*>(d.dZ + (size_t)gr * V2_C + c0);
-        py[q] = *reinterpret_cast<const uint4*>(d.Y + (size_t)gr * V2_C + c0);
+        pz[q] = *reinterpret_cast<const uint4*>(d.dZ + (size_t)gr * d.ldp + c0);
+        py[q] = *reinterpret_cast<const uint4*>(d.Y + (size_t)gr * d.ldp + c0);
       } else {
         pz[q] = make_uint4(0, 0, 0, 0); py[q] = make_uint4(0, 0, 0, 0);
       }
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(V2_NT, 2) void wgrad_batched_v2_kernel(const WgradV
       BnBwd bb;
       bb.fstats = d.fstats; bb.bsums = d.bsums; bb.gamma = d.gamma; bb.inv_n = d.inv_n; bb.eps = d.eps; bb.batch = d.batch;
       float k0, k1, k2, s, h;
-      bn_bwd_coefs(bb, V2_C, tid, k0, k1, k2);
+      bn_bwd_coefs(bb, d.statC, d.chan0 + tid, k0, k1, k2);
       bn_scale_shift(d.actX, V2_C, tid, s, h);
       cst[tid] = k0; cst[V2_C + tid] = k1; cst[2 * V2_C + tid] = k2; cst[3 * V2_C + tid] = s; cst[4 * V2_C + tid] = h;
       cst[5 * V2_C + tid] = dw ? d.bdw[tid] : 0.f;
