@@ -29,8 +29,8 @@ ALG_BYTES_PER_UTT_BF16 = 70.66e6   # 7,065,600 elements x 5 pa
 
 PROF_CLASSES = {1: "fwd_subblock_gemm", 2: "bwd_pointwise_wgrad", 3: "bwd_pointwise_dgrad", 4: "bwd_depthwise"}
 # kernel behind each class on the headline shape (for the PMC traffic lookup)
-PROF_KERNELS = {1: "sub_fwd_v2_kernel<3, true>", 2: "wgrad_batched_v2_kernel<3>", 3: "sub_bwd_v2_kernel<1, false>",
-                4: "dw_bwd_v3_kernel<3>"}
+PROF_KERNELS = {1: "sub_fwd_v4_kernel<3, true, 7>", 2: "wgrad_batched_v2_kernel<3>", 3: "dgrad_v2_kernel<64>",
+                4: "dw_bwd_v4_kernel<3, 7>"}
 
 
 def pmc_traffic(cls):
@@ -186,10 +186,11 @@ def main():
         esz = 2 if args.precision == "bf16" else 4
         rows = args.batch * T
         kbytes = kernel_algorithmic_bytes(dom, rows, 256, esz)
-        # the v2 weight-gradient kernel covers all 17 x (3 sub-blocks + skip) pointwise layers in one launch
+        # the v2 weight-gradient kernel covers all 17 x (3 sub-blocks + skip) pointwise layers plus the 6 256-channel
+        # slabs of the epilog conv in ONE launch (each unit reads dZ, Y and the layer input once: 3t)
         per_step = cnt.value / max(args.steps, 1)
         if dom == 2 and per_step < 17 * 3:
-            kbytes = int(kbytes * (17 * 4) / max(per_step, 1))
+            kbytes = int(kbytes * (17 * 4 + 6) / max(per_step, 1))
         avg_s = (ms.value / 1e3) / max(cnt.value, 1)
         achieved = kbytes / avg_s / 1e9
         value = args.batch * world * args.steps / dt
