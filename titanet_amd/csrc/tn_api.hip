@@ -455,7 +455,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
         if (p->use_v2 & 1) {
           SubFwdV2Args va{(const bf16_t*)cur, acur, params + sb.wdw, params + sb.bdw, (const bf16_t*)(ws + bw.wpw[j].w),
                           params + sb.bpw, (bf16_t*)(ws + bw.Y[j]), statp(sb.bn), M, T, 0};
-          rc = launch_sub_fwd_v4<3, true>(va, 256, st);
+          rc = launch_sub_fwd_v5<3, true>(va, 256, st);
         } else {
           rc = gemm_store<AT, ProdDw>(g, pa, ea, c.kernel, st);
         }

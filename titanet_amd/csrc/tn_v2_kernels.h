@@ -711,3 +711,269 @@ inline int launch_se_squeeze_v2(const SeSqueezeV2Args& a, int B, hipStream_t st)
   else return -1000;
   return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------
+// sub_fwd_v5: PRODUCER / CONSUMER wave specialisation of the forward sub-block.
+// With one 512-thread workgroup per CU every wave used to sit in the same barrier-separated phase
+// (activation -> stencil -> MFMA -> epilogue -> store), so VALU, LDS and MFMA time ADDED up.  Here waves 0-3
+// (one per SIMD) are producers: they turn the prefetched raw rows of tile i+1 into the MFMA operand tile
+// (BatchNorm + ReLU + dropout on load, depthwise stencil), while waves 4-7 (the other wave of each SIMD) are
+// consumers of tile i: pointwise GEMM with the whole 256 x 256 weight in THEIR registers (64 output channels
+// = 128 VGPRs per wave), epilogue, coalesced store, BN statistics.  A SIMD therefore always has one VALU-bound
+// and one MFMA-bound wave to pick from, the operand tile is double buffered, and only two workgroup barriers
+// per tile remain.  The B-operand LDS reads halve (4 consumer waves instead of 8 re-read the tile).
+// ------------------------------------------------------------------------------------------
+template <int KD, bool DW, int FL>
+__global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
+  constexpr int PADR = DW ? (KD - 1) / 2 : 0;
+  constexpr int OUTR = DW ? V2_R - (KD - 1) : V2_R;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);     // [64][264] output staging (consumers)
+  bf16_t* As0 = Cs + V2_R * V2_AP;                  // [2][64][264] MFMA B operand, double buffered
+  bf16_t* Xa = As0 + 2 * V2_R * V2_AP;              // [64][256] activated input rows (producers)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave < 4;
+  const int ltid = tid & 255;                        // thread index inside the team
+  const int vc = ltid & 31, rq = ltid >> 5, c0 = vc * 8;   // 32 channel vectors x 8 row phases
+  const int half = lane >> 5, cw = wave & 3;         // consumer: 64 output channels cw*64 ..
+  const uint32_t dkey = a.act.drop_key, dthr = a.act.drop_thr;
+  const int stride = gridDim.x;
+  const int first = blockIdx.x;
+  if (first >= a.ntiles) return;
+
+  // ---- per-thread constants through LDS (cooperative: one channel per thread)
+  float sc[8], sh[8], wd[DW ? KD : 1][8], bd[8];
+  {
+    float* tmp = reinterpret_cast<float*>(As0);
+    if (tid < V2_C) {
+      float s = 1.f, h = 0.f;
+      if (FL & 1) bn_scale_shift(a.act, V2_C, tid, s, h);
+      tmp[tid] = s;
+      tmp[V2_C + tid] = h;
+      if (DW) {
+        tmp[2 * V2_C + tid] = a.bdw[tid];
+#pragma unroll
+        for (int k = 0; k < KD; ++k) tmp[(3 + k) * V2_C + tid] = a.wdw[(size_t)tid * KD + k];
+      }
+    }
+    __syncthreads();
+    if (producer) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        sc[i] = tmp[c0 + i];
+        sh[i] = tmp[V2_C + c0 + i];
+        if (DW) {
+          bd[i] = tmp[2 * V2_C + c0 + i];
+#pragma unroll
+          for (int k = 0; k < KD; ++k) wd[k][i] = tmp[(3 + k) * V2_C + c0 + i];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // The two roles run in DISJOINT code regions (each with its own copy of the tile loop and the same number of
+  // workgroup barriers), so that the register allocator sees max(producer, consumer) live values, not their sum.
+  if (producer) {
+    // ---- producer: raw rows of the next tile (8 rows per thread) -> activated rows -> stencil -> operand tile
+    uint4 pf[8];
+    auto prefetch = [&](int tile) {
+      const int raw0 = tile * OUTR - PADR;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int gr = raw0 + rq + 8 * q;
+        if (tile < a.ntiles && gr >= 0 && gr < a.M) pf[q] = *reinterpret_cast<const uint4*>(a.X + (size_t)gr * V2_C + c0);
+        else pf[q] = make_uint4(0, 0, 0, 0);
+      }
+    };
+    auto produce_act = [&](int tile, bf16_t* As) {
+      const int raw0 = tile * OUTR - PADR;
+      const bool interior = raw0 >= 0 && raw0 + V2_R <= a.M;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int r = rq + 8 * q, gr = raw0 + r;
+        float v[8];
+        unpack8(pf[q], v);
+        if (interior || (gr >= 0 && gr < a.M)) act8_t<FL>(v, sc, sh, dkey, dthr, (uint32_t)gr, c0);
+        if (DW) store8(Xa + r * V2_C + c0, v);
+        else store8(As + r * V2_AP + c0, v);
+      }
+      prefetch(tile + stride);
+    };
+    auto produce_stencil = [&](int tile, bf16_t* As) {
+      const int out0 = tile * OUTR, raw0 = out0 - PADR;
+      const bool one_utt = raw0 >= 0 && raw0 + V2_R <= a.M && (raw0 % a.T) + V2_R <= a.T;
+#pragma unroll
+      for (int grp = 0; grp < 2; ++grp) {
+        const int o0 = grp * 32 + rq * 4;
+        float win[KD + 3][8];
+#pragma unroll
+        for (int j = 0; j < KD + 3; ++j) {
+          if (o0 + j < V2_R) load8(Xa + (o0 + j) * V2_C + c0, win[j]);
+          else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) win[j][i] = 0.f;
+          }
+        }
+        if (one_utt) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = fmaf(wd[0][i], win[q][i], bd[i]);
+#pragma unroll
+            for (int k = 1; k < KD; ++k)
+#pragma unroll
+              for (int i = 0; i < 8; ++i) acc[i] = fmaf(wd[k][i], win[q + k][i], acc[i]);
+            store8(As + (o0 + q) * V2_AP + c0, acc);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int o = o0 + q;
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = bd[i];
+            if (o < OUTR) {
+              const int t = (out0 + o) % a.T;
+#pragma unroll
+              for (int k = 0; k < KD; ++k) {
+                const int tt = t + k - PADR;
+                if (tt >= 0 && tt < a.T) {
+#pragma unroll
+                  for (int i = 0; i < 8; ++i) acc[i] = fmaf(wd[k][i], win[q + k][i], acc[i]);
+                }
+              }
+            }
+            store8(As + o * V2_AP + c0, acc);
+          }
+        }
+      }
+    };
+    prefetch(first);
+    produce_act(first, As0);
+    __syncthreads();
+    if (DW) produce_stencil(first, As0);
+    __syncthreads();
+    int buf = 0;
+    for (int tile = first; tile < a.ntiles; tile += stride) {
+      const int nxt = tile + stride;
+      bf16_t* Anxt = As0 + (buf ^ 1) * V2_R * V2_AP;
+      if (nxt < a.ntiles) produce_act(nxt, Anxt);
+      __syncthreads();
+      if (DW && nxt < a.ntiles) produce_stencil(nxt, Anxt);
+      __syncthreads();
+      buf ^= 1;
+    }
+    if (a.stats) __syncthreads();
+  } else {
+    // ---- consumer: weights of 64 output channels as MFMA A fragments, bias, statistics
+    bf16x8_t wf[2][16];
+    float biasr[2][16];
+    float st_s[8], st_q[8];
+#pragma unroll
+    for (int cbk = 0; cbk < 2; ++cbk) {
+      const int co = cw * 64 + cbk * 32 + (lane & 31);
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks)
+        wf[cbk][ks] = *reinterpret_cast<const bf16x8_t*>(a.W + (size_t)co * V2_C + ks * 16 + half * 8);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) biasr[cbk][4 * g + j] = a.bias[cw * 64 + cbk * 32 + 8 * g + 4 * half + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
+    __syncthreads();      // (pipeline fill: producers' activation)
+    __syncthreads();      // (pipeline fill: producers' stencil)
+    int buf = 0;
+    for (int tile = first; tile < a.ntiles; tile += stride) {
+      const bf16_t* As = As0 + buf * V2_R * V2_AP;
+      {
+        f32x16_t acc[2][2];    // [channel block][row block]
+#pragma unroll
+        for (int cbk = 0; cbk < 2; ++cbk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc[cbk][0][r] = biasr[cbk][r]; acc[cbk][1][r] = biasr[cbk][r]; }
+        const bf16_t* brow = As + (lane & 31) * V2_AP + half * 8;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(brow + ks * 16);
+          const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(brow + 32 * V2_AP + ks * 16);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], b0, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], b1, acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][ks], b0, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][ks], b1, acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int cbk = 0; cbk < 2; ++cbk)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int co = cw * 64 + cbk * 32 + 8 * g + 4 * half;
+            uint2 w0, w1;
+            w0.x = f2bf_pk(acc[cbk][0][4 * g], acc[cbk][0][4 * g + 1]); w0.y = f2bf_pk(acc[cbk][0][4 * g + 2], acc[cbk][0][4 * g + 3]);
+            w1.x = f2bf_pk(acc[cbk][1][4 * g], acc[cbk][1][4 * g + 1]); w1.y = f2bf_pk(acc[cbk][1][4 * g + 2], acc[cbk][1][4 * g + 3]);
+            *reinterpret_cast<uint2*>(Cs + (lane & 31) * V2_AP + co) = w0;
+            *reinterpret_cast<uint2*>(Cs + (32 + (lane & 31)) * V2_AP + co) = w1;
+          }
+      }
+      __syncthreads();
+      {
+        const int out0 = tile * OUTR;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int o = rq + 8 * q, gr = out0 + o;
+          if (o < OUTR && gr < a.M) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(Cs + o * V2_AP + c0);
+            *reinterpret_cast<uint4*>(a.Y + (size_t)gr * V2_C + c0) = raw;
+            float y[8];
+            unpack8(raw, y);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { st_s[i] += y[i]; st_q[i] = fmaf(y[i], y[i], st_q[i]); }
+          }
+        }
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+    if (a.stats) {
+      float* red = reinterpret_cast<float*>(smem);      // [8][2][256]
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        red[(rq * 2 + 0) * V2_C + c0 + i] = st_s[i];
+        red[(rq * 2 + 1) * V2_C + c0 + i] = st_q[i];
+      }
+      __syncthreads();
+    }
+  }
+  if (a.stats) {
+    const float* red = reinterpret_cast<const float*>(smem);
+    const int rep = blockIdx.x % TN_NREP;
+    const int which = tid >> 8, c = tid & 255;
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v += red[(r * 2 + which) * V2_C + c];
+    atomic_add_f32(&a.stats[(size_t)(rep * 2 + which) * V2_C + c], v);
+  }
+}
+
+template <int KD, bool DW, int FL>
+inline int launch_sub_fwd_v5_t(SubFwdV2Args a, int grid, size_t smem, hipStream_t st) {
+  auto kern = sub_fwd_v5_kernel<KD, DW, FL>;
+  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
+  return (int)hipGetLastError();
+}
+template <int KD, bool DW>
+inline int launch_sub_fwd_v5(SubFwdV2Args a, int resident_wgs, hipStream_t st) {
+  constexpr int OUTR = DW ? V2_R - (KD - 1) : V2_R;
+  a.ntiles = (a.M + OUTR - 1) / OUTR;
+  const int grid = a.ntiles < resident_wgs ? a.ntiles : resident_wgs;
+  const size_t smem = (size_t)(3 * V2_R * V2_AP + V2_R * V2_C) * sizeof(bf16_t);
+  const int fl = (a.act.mode != 0 ? 1 : 0) | (a.act.relu ? 2 : 0) | (a.act.drop_thr ? 4 : 0);
+  switch (fl) {
+    case 0: return launch_sub_fwd_v5_t<KD, DW, 0>(a, grid, smem, st);
+    case 3: return launch_sub_fwd_v5_t<KD, DW, 3>(a, grid, smem, st);
+    case 7: return launch_sub_fwd_v5_t<KD, DW, 7>(a, grid, smem, st);
+    default: return launch_sub_fwd_v2<KD, DW>(a, resident_wgs, st);
+  }
+}

@@ -38,6 +38,13 @@ int main(int argc, char** argv) {
   CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
   CK(hipEventElapsedTime(&ms, e0, e1));
   printf("sub_fwd_v4<3,dw> B=%d grid=%d: %.2f us/launch  (%.2f TB/s algorithmic)\n", B, grid, ms * 1e3 / N, 2.0 * M * C * 2 / (ms * 1e-3 / N) / 1e12);
+  for (int it = 0; it < 3; ++it) launch_sub_fwd_v5<3, true>(a, grid, 0);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  for (int it = 0; it < N; ++it) launch_sub_fwd_v5<3, true>(a, grid, 0);
+  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("sub_fwd_v5<3,dw> B=%d grid=%d: %.2f us/launch  (%.2f TB/s algorithmic)\n", B, grid, ms * 1e3 / N, 2.0 * M * C * 2 / (ms * 1e-3 / N) / 1e12);
   a.act.mode = 0; a.act.relu = 0; a.act.drop_thr = 0;
   for (int it = 0; it < 3; ++it) launch_sub_fwd_v4<1, false>(a, grid, 0);
   CK(hipDeviceSynchronize());
@@ -46,6 +53,13 @@ int main(int argc, char** argv) {
   CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
   CK(hipEventElapsedTime(&ms, e0, e1));
   printf("sub_fwd_v4<1,plain> identity act B=%d grid=%d: %.2f us/launch\n", B, grid, ms * 1e3 / N);
+  for (int it = 0; it < 3; ++it) launch_sub_fwd_v5<1, false>(a, grid, 0);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  for (int it = 0; it < N; ++it) launch_sub_fwd_v5<1, false>(a, grid, 0);
+  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("sub_fwd_v5<1,plain> identity act B=%d grid=%d: %.2f us/launch\n", B, grid, ms * 1e3 / N);
   for (int it = 0; it < 3; ++it) launch_sub_fwd_v2<1, false>(a, grid, 0);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0, 0));
