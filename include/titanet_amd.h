@@ -60,6 +60,8 @@ typedef struct tn_config {
   int32_t has_scale;     /* margin loss: 0 => scale = ||x|| (reference scale=None) */
   float dropout;         /* p of every Dropout / F.dropout in the mega blocks */
   float scale, m1, m2, m3, loss_eps; /* margin loss: s, m1, m2, m3, eps (1e-6) */
+  int32_t simple_pool;   /* Decoder(simple_pool=True), reference src/models.py:497-502: mean over time -> Linear(D, 2D)
+                            instead of attentive statistics pooling + BatchNorm (state_dict keys decoder.pool.2.*) */
 } tn_config;
 
 typedef struct tn_model tn_model; /* parameter layout for one architecture */

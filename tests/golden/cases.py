@@ -34,4 +34,7 @@ CASES = {
                           "encoder.mega_blocks.8.sub_blocks.1.conv_block.0.conv.1.bias",
                           "encoder.mega_blocks.16.sub_blocks.3.excitation.2.weight",
                           "decoder.linear.0.bias", "encoder.epilog.conv_block.1.weight"), buffers=()),
+    # Decoder(simple_pool=True): mean over time -> Linear(D, 2D) (reference src/models.py:497-502)
+    "tiny_simple_pool": dict(cfg=dict(_TINY, n_mega_blocks=1), simple_pool=True, batch=4, frames=29, n_classes=9, seed=5,
+                             inter=False, losses=("ce", "arc"), grads="all", buffers=()),
 }

@@ -45,7 +45,7 @@ def build_reference(case, loss_name, dtype):
         n_mels=cfg["n_mels"], n_mega_blocks=cfg["n_mega_blocks"], n_sub_blocks=3,
         encoder_hidden_size=cfg["hidden"], encoder_output_size=cfg["enc_out"], embedding_size=cfg["emb"],
         mega_block_kernel_size=cfg["kernel"], attention_hidden_size=cfg["attn_hidden"],
-        loss_function=loss_fn, dropout=0.0)
+        simple_pool=bool(case.get("simple_pool", False)), loss_function=loss_fn, dropout=0.0)
     sd = model.state_dict()
     vals = detgen.fill_state_dict({k: tuple(v.shape) for k, v in sd.items()}, seed=case["seed"])
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vals.items()})

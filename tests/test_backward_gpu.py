@@ -42,7 +42,7 @@ def _check_grads(model, g, prefix, tol, floor_rel=2e-4, x_grad=None):
     return worst
 
 
-@pytest.mark.parametrize("name", ["tiny_k3", "tiny_k7", "tiny_k11_short", "mid_k3", "s17_b8"])
+@pytest.mark.parametrize("name", ["tiny_k3", "tiny_k7", "tiny_k11_short", "mid_k3", "tiny_simple_pool", "s17_b8"])
 def test_backward_fp32_vs_reference_golden(name):
     case, g = CASES[name], load_golden(name)
     for loss in case["losses"]:
@@ -63,7 +63,7 @@ def test_backward_fp32_vs_reference_golden(name):
         assert cos > 0.9995, cos
 
 
-@pytest.mark.parametrize("name,p", [("tiny_k3", 0.25), ("mid_k3", 0.1)])
+@pytest.mark.parametrize("name,p", [("tiny_k3", 0.25), ("mid_k3", 0.1), ("tiny_simple_pool", 0.2)])
 def test_backward_with_dropout_vs_oracle(name, p):
     case = CASES[name]
     m = build(case, "ce", dropout=p).train()
@@ -88,7 +88,7 @@ def test_backward_with_dropout_vs_oracle(name, p):
     assert rel_err(a, b) < 3e-2, rel_err(a, b)
 
 
-@pytest.mark.parametrize("name", ["tiny_k3", "mid_k3", "s17_b8"])
+@pytest.mark.parametrize("name", ["tiny_k3", "mid_k3", "tiny_simple_pool", "s17_b8"])
 def test_backward_bf16_direction(name):
     """bf16 is the throughput mode: gradients must point the same way as the float64 reference."""
     case, g = CASES[name], load_golden(name)

@@ -48,6 +48,16 @@ def test_layout_is_reference_state_dict(loss):
         assert p.untyped_storage().data_ptr() == base.untyped_storage().data_ptr(), n
 
 
+def test_simple_pool_layout_is_reference_state_dict():
+    """Decoder(simple_pool=True), reference src/models.py:497-502: keys decoder.pool.2.{weight,bias}, no pool BatchNorm"""
+    from titanet_amd import TitaNet
+    m = TitaNet.get_titanet(n_mega_blocks=1, model_size="s", simple_pool=True)
+    sd = m.state_dict()
+    want = O.state_dict_shapes(O.OracleConfig.titanet("s", n_mega_blocks=1, simple_pool=True))
+    assert list(sd.keys()) == list(want.keys())
+    assert tuple(sd["decoder.pool.2.weight"].shape) == (3072, 1536) and "decoder.pool.1.weight" not in sd
+
+
 def test_param_counts_match_reference_known_answers():
     from titanet_amd import LOSSES, TitaNet
     sizing = load_golden("sizing")

@@ -29,8 +29,8 @@ def build(case, loss, precision="fp32", dropout=0.0):
         lf = LOSSES["sphere"](c["emb"], case["n_classes"], device="cuda", margin=4)
     m = TitaNet(n_mels=c["n_mels"], n_mega_blocks=c["n_mega_blocks"], n_sub_blocks=3, encoder_hidden_size=c["hidden"],
                 encoder_output_size=c["enc_out"], embedding_size=c["emb"], mega_block_kernel_size=c["kernel"],
-                attention_hidden_size=c["attn_hidden"], loss_function=lf, dropout=dropout, device="cuda",
-                precision=precision)
+                attention_hidden_size=c["attn_hidden"], simple_pool=bool(case.get("simple_pool", False)), loss_function=lf,
+                dropout=dropout, device="cuda", precision=precision)
     sd = case_state_dict(case, loss, torch.float32)
     m.load_state_dict(sd)
     return m
@@ -104,7 +104,7 @@ def test_eval_forward_bf16(name):
     assert err < BF16_TOL, err
 
 
-@pytest.mark.parametrize("name,p", [("tiny_k3", 0.25), ("tiny_k7", 0.1), ("mid_k3", 0.1)])
+@pytest.mark.parametrize("name,p", [("tiny_k3", 0.25), ("tiny_k7", 0.1), ("mid_k3", 0.1), ("tiny_simple_pool", 0.2)])
 def test_train_forward_with_dropout_vs_oracle(name, p):
     """Dropout masks are counter-based (oracle/rng.py restates the generator): same seed -> the CPU
     oracle reproduces the exact masks, so the full train-mode forward is comparable element-wise."""

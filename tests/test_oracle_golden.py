@@ -8,7 +8,7 @@ from oracle import titanet_oracle as O
 from tests.golden.cases import CASES
 from tests.util import LOSS_KW, case_inputs, case_state_dict, load_golden, oracle_cfg, rel_err
 
-FAST = ["tiny_k3", "tiny_k7", "tiny_k11_short", "mid_k3"]
+FAST = ["tiny_k3", "tiny_k7", "tiny_k11_short", "mid_k3", "tiny_simple_pool"]
 
 
 @pytest.mark.parametrize("name", FAST + ["s17_b8"])

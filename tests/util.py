@@ -19,7 +19,7 @@ def oracle_cfg(case, dropout=0.0):
     c = case["cfg"]
     return O.OracleConfig(n_mels=c["n_mels"], n_mega_blocks=c["n_mega_blocks"], hidden=c["hidden"],
                           enc_out=c["enc_out"], emb=c["emb"], kernel=c["kernel"], attn_hidden=c["attn_hidden"],
-                          dropout=dropout)
+                          dropout=dropout, simple_pool=bool(case.get("simple_pool", False)))
 
 
 def case_state_dict(case, loss=None, dtype=torch.float64):

@@ -27,7 +27,7 @@ class TnConfig(C.Structure):
         ("epilog_kernel", C.c_int32), ("attn_hidden", C.c_int32), ("se_reduction", C.c_int32),
         ("loss_type", C.c_int32), ("n_classes", C.c_int32), ("has_scale", C.c_int32),
         ("dropout", C.c_float), ("scale", C.c_float), ("m1", C.c_float), ("m2", C.c_float), ("m3", C.c_float),
-        ("loss_eps", C.c_float),
+        ("loss_eps", C.c_float), ("simple_pool", C.c_int32),
     ]
 
 

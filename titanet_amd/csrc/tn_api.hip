@@ -102,11 +102,17 @@ extern "C" int tn_model_create(const tn_config* cfg, tn_model** out) {
   m->epi_w = L.add("encoder.epilog.conv_block.0.weight", TN_KIND_PARAM, {D, H, 1});
   m->epi_b = L.add("encoder.epilog.conv_block.0.bias", TN_KIND_PARAM, {D});
   m->epi_bn = L.bn("encoder.epilog.conv_block.1", D);
-  m->asp_win = L.add("decoder.pool.0.in_linear.weight", TN_KIND_PARAM, {cfg->attn_hidden, D});
-  m->asp_bin = L.add("decoder.pool.0.in_linear.bias", TN_KIND_PARAM, {cfg->attn_hidden});
-  m->asp_wout = L.add("decoder.pool.0.out_linear.weight", TN_KIND_PARAM, {D, cfg->attn_hidden});
-  m->asp_bout = L.add("decoder.pool.0.out_linear.bias", TN_KIND_PARAM, {D});
-  m->pool_bn = L.bn("decoder.pool.1", 2 * D);
+  if (cfg->simple_pool) {
+    // reference src/models.py:497-502: nn.Sequential(AdaptiveAvgPool1d(1), Squeeze(-1), Linear(D, 2D)) -> keys decoder.pool.2.*
+    m->pool2_w = L.add("decoder.pool.2.weight", TN_KIND_PARAM, {2 * D, D});
+    m->pool2_b = L.add("decoder.pool.2.bias", TN_KIND_PARAM, {2 * D});
+  } else {
+    m->asp_win = L.add("decoder.pool.0.in_linear.weight", TN_KIND_PARAM, {cfg->attn_hidden, D});
+    m->asp_bin = L.add("decoder.pool.0.in_linear.bias", TN_KIND_PARAM, {cfg->attn_hidden});
+    m->asp_wout = L.add("decoder.pool.0.out_linear.weight", TN_KIND_PARAM, {D, cfg->attn_hidden});
+    m->asp_bout = L.add("decoder.pool.0.out_linear.bias", TN_KIND_PARAM, {D});
+    m->pool_bn = L.bn("decoder.pool.1", 2 * D);
+  }
   m->lin_w = L.add("decoder.linear.0.weight", TN_KIND_PARAM, {cfg->emb, 2 * D});
   m->lin_b = L.add("decoder.linear.0.bias", TN_KIND_PARAM, {cfg->emb});
   m->lin_bn = L.bn("decoder.linear.1", cfg->emb);
@@ -239,6 +245,8 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   p->dEbn = b.take(M * D * e);
   p->dHP = b.take(M * A * e);
   p->dpooled = b.take((size_t)batch * 2 * D * 4);
+  p->mu = b.take((size_t)batch * D * 4);
+  p->dmu = b.take((size_t)batch * D * 4);
   p->dlin = b.take((size_t)batch * c.emb * 4);
   p->demb = b.take((size_t)batch * c.emb * 4);
   // split-K slabs for weight gradients: sized for the largest weight (see tn_bwd.hip)
@@ -324,8 +332,10 @@ extern "C" int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbu
   };
   add(m->prolog_w, p->wprolog, c.hidden, c.n_mels * c.prolog_kernel, false);
   add(m->epi_w, p->wepi, c.enc_out, c.hidden, true);
-  add(m->asp_win, p->wwin, c.attn_hidden, c.enc_out, true);
-  add(m->asp_wout, p->wwout, c.enc_out, c.attn_hidden, true);
+  if (!c.simple_pool) {
+    add(m->asp_win, p->wwin, c.attn_hidden, c.enc_out, true);
+    add(m->asp_wout, p->wwout, c.enc_out, c.attn_hidden, true);
+  }
   for (int i = 0; i < c.n_mega_blocks; ++i) {
     for (int j = 0; j < c.n_sub_blocks; ++j) add(m->blocks[i].sub[j].wpw, p->blk[i].wpw[j], c.hidden, c.hidden, true);
     add(m->blocks[i].wskip, p->blk[i].wskip, c.hidden, c.hidden, true);
@@ -527,6 +537,16 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
     }
   }
   BnAct acte = make_act(p, m->epi_bn, M, training, 1, 0.f, seed, 0);
+  if (c.simple_pool) {
+    // ---- simple pool (reference src/models.py:497-502): mean over time, then Linear(D, 2D) in f32
+    hipLaunchKernelGGL(mean_pool_fwd_kernel<AT>, dim3(B, (D + 511) / 512), dim3(256), 0, st, (const AT*)(ws + p->E), acte, T, D,
+                       (float*)(ws + p->mu));
+    GemmShape gp{B, 2 * D, D, params + m->pool2_w};
+    ProdPlain::Args pap{ws + p->mu, D, identity_act()};
+    EpiStoreArgs eap{ws + p->pooled, 2 * D, params + m->pool2_b, nullptr};
+    int rc = gemm_store<float, ProdPlain>(gp, pap, eap, 0, st);
+    if (rc) return rc;
+  } else
   // ---- attentive statistics pooling (reference src/models.py:553-584)
   {
     int rc;
@@ -562,7 +582,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   }
   // ---- decoder tail + loss head (reference src/models.py:504-513, src/losses.py)
   {
-    BnAct actp = make_act(p, m->pool_bn, B, training, 0, 0.f, seed, 0);
+    BnAct actp = c.simple_pool ? identity_act() : make_act(p, m->pool_bn, B, training, 0, 0.f, seed, 0);
     hipLaunchKernelGGL(tail_linear_fwd_kernel, dim3((B + 3) / 4, (c.emb + 63) / 64), dim3(256), (size_t)4 * 2 * D * sizeof(float), st,
                        (const float*)(ws + p->pooled), actp, B, 2 * D, c.emb, params + m->lin_w, params + m->lin_b,
                        (float*)(ws + p->lin), statp(m->lin_bn));

@@ -90,7 +90,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   // ================= decoder tail =================
   {
     BnAct actL = make_act(p, m->lin_bn, B, training, 0, 0.f, seed, 0);
-    BnAct actP = make_act(p, m->pool_bn, B, training, 0, 0.f, seed, 0);
+    BnAct actP = c.simple_pool ? identity_act() : make_act(p, m->pool_bn, B, training, 0, 0.f, seed, 0);
     const float* demb = (const float*)(ws + p->demb);
     float* dlin = (float*)(ws + p->dlin);
     float* dpool = (float*)(ws + p->dpooled);
@@ -105,13 +105,31 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     // d pbn -> (in place) d pooled
     hipLaunchKernelGGL(tail_bwd_dp_kernel, dim3((K2 + 255) / 256, B), dim3(256), 0, st, (const float*)dlin, params + m->lin_w, B, K2,
                        c.emb, dpool);
-    hipLaunchKernelGGL(rows_bn_bwd_sums_kernel, dim3((K2 + 255) / 256, (B + 15) / 16), dim3(256), 0, st, (const float*)dpool, pooled, actP, B, K2,
-                       bsum(m->pool_bn));
-    hipLaunchKernelGGL(rows_bn_bwd_apply_kernel, dim3((B * K2 + 255) / 256), dim3(256), 0, st, (const float*)dpool, pooled,
-                       make_bnbwd(p, m->pool_bn, B, training), B, K2, dpool);
+    if (!c.simple_pool) {
+      hipLaunchKernelGGL(rows_bn_bwd_sums_kernel, dim3((K2 + 255) / 256, (B + 15) / 16), dim3(256), 0, st, (const float*)dpool, pooled, actP, B, K2,
+                         bsum(m->pool_bn));
+      hipLaunchKernelGGL(rows_bn_bwd_apply_kernel, dim3((B * K2 + 255) / 256), dim3(256), 0, st, (const float*)dpool, pooled,
+                         make_bnbwd(p, m->pool_bn, B, training), B, K2, dpool);
+    }
   }
   // ================= attentive statistics pooling =================
   BnAct acte = make_act(p, m->epi_bn, M, training, 1, 0.f, seed, 0);
+  if (c.simple_pool) {
+    // ================= simple pool: Linear(D, 2D) over B rows, then the mean over time =================
+    const float* dpool = (const float*)(ws + p->dpooled);
+    const float* mu = (const float*)(ws + p->mu);
+    {
+      ProdPlain::Args pa{dpool, 2 * D, identity_act()};
+      ProdPlain::Args qa{mu, D, identity_act()};
+      int rc = launch_wgrad<float, ProdPlain, ProdPlain>(B, 2 * D, D, pa, qa, 0, slabs, p->slab_bytes, grads + m->pool2_w, st);
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(rows_colsum_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, st, dpool, B, 2 * D, grads + m->pool2_b);
+    hipLaunchKernelGGL(rows_matmul_nn_kernel, dim3((D + 255) / 256, (B + 7) / 8), dim3(256), 0, st, dpool, params + m->pool2_w, B, 2 * D,
+                       D, (float*)(ws + p->dmu));
+    hipLaunchKernelGGL(mean_pool_bwd_kernel<AT>, dim3(B, (D + 511) / 512), dim3(256), 0, st, (const float*)(ws + p->dmu),
+                       (const AT*)(ws + p->E), acte, T, D, (AT*)(ws + p->dEbn), bsum(m->epi_bn));
+  } else
   {
     hipLaunchKernelGGL(asp_bwd_de_kernel<AT>, dim3(B, (D + 511) / 512), dim3(256), 0, st, (const AT*)(ws + p->E), acte,
                        (const AT*)(ws + p->EN), T, D, 1e-6f, (const float*)(ws + p->pooled), (const float*)(ws + p->qv),

@@ -1024,3 +1024,82 @@ __global__ __launch_bounds__(256) void prolog_input_grad_kernel(const AT* __rest
     dx[i] = s;
   }
 }
+
+
+// ------------------------------------------------------------------------------------------
+// Decoder(simple_pool=True) backward (reference src/models.py:497-502 under autograd)
+// ------------------------------------------------------------------------------------------
+// out[b][n] = sum_k in[b][k] * W[k][n]   (d mean = d pooled * W_pool: an "NN" product over B rows)
+__global__ __launch_bounds__(256) void rows_matmul_nn_kernel(const float* __restrict__ in, const float* __restrict__ W, int B, int K,
+                                                             int N, float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, b0 = blockIdx.y * 8;
+  if (n >= N) return;
+  float acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float w = W[(size_t)k * N + n];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (b0 + q < B) acc[q] = fmaf(in[(size_t)(b0 + q) * K + k], w, acc[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    if (b0 + q < B) out[(size_t)(b0 + q) * N + n] = acc[q];
+}
+// out[n] = sum_b in[b][n]
+__global__ void rows_colsum_kernel(const float* __restrict__ in, int B, int N, float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += in[(size_t)b * N + n];
+  out[n] = s;
+}
+// d(epilog BN output)[b][t][c] = [BN(E) > 0] * dmu[b][c] / T, with the BatchNorm backward sums of the epilog BN
+template <typename AT>
+__global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const float* __restrict__ dmu, const AT* __restrict__ E, BnAct actE,
+                                                            int T, int D, AT* __restrict__ dEbn, float* __restrict__ bsums) {
+  constexpr int CVB = 64, TG = 4;
+  __shared__ float red[TG][2][CVB * 8];
+  __shared__ float par[4][CVB * 8];      // sc, sh, mean, rstd
+  const int tid = threadIdx.x, b = blockIdx.x, cbase = blockIdx.y * CVB * 8;
+  for (int c = tid; c < CVB * 8; c += 256) {
+    float sc = 1.f, sh = 0.f, mean = 0.f, rstd = 1.f;
+    if (cbase + c < D) { bn_scale_shift(actE, D, cbase + c, sc, sh); bn_mean_rstd(actE, D, cbase + c, mean, rstd); }
+    par[0][c] = sc; par[1][c] = sh; par[2][c] = mean; par[3][c] = rstd;
+  }
+  __syncthreads();
+  const int vc = tid % CVB, tg = tid / CVB, c0 = cbase + vc * 8;
+  float s1[8], s2[8], g[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; g[i] = 0.f; }
+  if (c0 < D) {
+    const float invT = 1.f / (float)T;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = dmu[(size_t)b * D + c0 + i] * invT;
+    for (int t = tg; t < T; t += TG) {
+      const size_t o = ((size_t)b * T + t) * D + c0;
+      float y[8], d[8];
+      load8(E + o, y);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float z = y[i] * par[0][vc * 8 + i] + par[1][vc * 8 + i];
+        const float v = (z > 0.f) ? g[i] : 0.f;
+        d[i] = v;
+        s1[i] += v;
+        s2[i] += v * (y[i] - par[2][vc * 8 + i]) * par[3][vc * 8 + i];
+      }
+      store8(dEbn + o, d);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { red[tg][0][vc * 8 + i] = s1[i]; red[tg][1][vc * 8 + i] = s2[i]; }
+  __syncthreads();
+  const int rep = b % TN_NREP;
+  for (int i = tid; i < 2 * CVB * 8; i += 256) {
+    const int which = i / (CVB * 8), c = i % (CVB * 8);
+    if (cbase + c < D)
+      atomic_add_f32(&bsums[(size_t)(rep * 2 + which) * D + cbase + c],
+                     red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c]);
+  }
+}

@@ -455,3 +455,43 @@ __global__ void bn_running_update_kernel(const BnUpdateDesc* descs, float moment
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) nbt[blockIdx.y] += 1;
 }
+
+
+// ------------------------------------------------------------------------------------------
+// Decoder(simple_pool=True), reference src/models.py:497-502: AdaptiveAvgPool1d(1) over time of x = act(E)
+// (the Linear(D, 2D) that follows is a plain f32 GEMM over B rows).  Lane-local over time like the attentive pool.
+// ------------------------------------------------------------------------------------------
+template <typename AT>
+__global__ __launch_bounds__(256) void mean_pool_fwd_kernel(const AT* __restrict__ E, BnAct actE, int T, int D,
+                                                            float* __restrict__ mu) {
+  constexpr int CVB = 64, TG = 4;
+  __shared__ float red[TG][CVB * 8];
+  __shared__ float scs[CVB * 8], shs[CVB * 8];
+  const int tid = threadIdx.x, b = blockIdx.x, cbase = blockIdx.y * CVB * 8;
+  for (int c = tid; c < CVB * 8; c += 256) {
+    float sc = 1.f, sh = 0.f;
+    if (cbase + c < D) bn_scale_shift(actE, D, cbase + c, sc, sh);
+    scs[c] = sc; shs[c] = sh;
+  }
+  __syncthreads();
+  const int vc = tid % CVB, tg = tid / CVB, c0 = cbase + vc * 8;
+  float s[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = 0.f;
+  if (c0 < D) {
+    for (int t = tg; t < T; t += TG) {
+      const uint32_t row = (uint32_t)b * T + t;
+      float x[8];
+      load8(E + (size_t)row * D + c0, x);
+      act8(x, scs + vc * 8, shs + vc * 8, actE, row, D, c0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] += x[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[tg][vc * 8 + i] = s[i];
+  __syncthreads();
+  for (int c = tid; c < CVB * 8; c += 256) {
+    if (cbase + c < D) mu[(size_t)b * D + cbase + c] = (red[0][c] + red[1][c] + red[2][c] + red[3][c]) / (float)T;
+  }
+}

@@ -44,7 +44,8 @@ struct tn_model {
   std::vector<MegaBlockRef> blocks;
   int64_t epi_w, epi_b;
   BnRef epi_bn;
-  int64_t asp_win, asp_bin, asp_wout, asp_bout;
+  int64_t asp_win = -1, asp_bin = -1, asp_wout = -1, asp_bout = -1;
+  int64_t pool2_w = -1, pool2_b = -1;   // Decoder(simple_pool=True): Linear(D, 2D) after the mean over time
   BnRef pool_bn;
   int64_t lin_w, lin_b;
   BnRef lin_bn;
@@ -107,6 +108,7 @@ struct tn_plan {
   size_t dEbn;         // rows x enc_out AT
   size_t dHP;          // rows x attn AT
   size_t dpooled, dlin, demb;   // float
+  size_t mu, dmu;               // float [B][D]: mean over time of the encoder output and its gradient (simple_pool)
   size_t slabs;        // split-K partial weight gradients
   size_t slab_bytes = 0;
   size_t bwd_table, bwd_table_eval, se_table;

@@ -91,8 +91,6 @@ class TitaNet(nn.Module):
         precision="fp32",
     ):
         super().__init__()
-        if simple_pool:
-            raise NotImplementedError("simple_pool=True is not part of the MI355X hot path yet (SURVEY.md §8f rank 4)")
         assert isinstance(loss_function, losses.MetricLearningLoss) or loss_function is None, "Unsupported loss function"
         self.precision = precision
         self._lib = _lib.load()
@@ -102,6 +100,7 @@ class TitaNet(nn.Module):
         cfg.kernel, cfg.prolog_kernel, cfg.epilog_kernel = mega_block_kernel_size, prolog_kernel_size, epilog_kernel_size
         cfg.attn_hidden, cfg.se_reduction = attention_hidden_size, se_reduction
         cfg.dropout = float(dropout)
+        cfg.simple_pool = 1 if simple_pool else 0
         cfg.loss_type, cfg.n_classes = _lib.TN_LOSS_NONE, 0
         cfg.has_scale, cfg.scale, cfg.m1, cfg.m2, cfg.m3, cfg.loss_eps = 1, 1.0, 1.0, 0.0, 0.0, 1e-6
         if loss_function is not None:
