@@ -121,6 +121,19 @@ int tn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
                  float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_mult,
                  void* stream);
 
+/* ---- device-resident step state: one hipGraph per training step (new; the reference dispatches ~400 eager ops per step,
+ * reference src/learn.py:88-135) -----------------------------------------------------------------------------------------
+ * Everything that changes from step to step and used to be a kernel argument — the dropout stream and the Adam step
+ * count — can instead live in the plan's workspace: tn_plan_step_tick advances a device counter and derives the
+ * per-step dropout word from it (added to every layer's key(seed, layer); the word is 0 until the first tick, so plain
+ * tn_forward calls keep the documented key(seed, layer) streams), and tn_adam_step_plan reads its bias-correction step
+ * from the same counter.  A capture of { tn_plan_step_tick; tn_forward(seed fixed); tn_backward; tn_adam_step_plan } on
+ * one stream is then replayable as a single hipGraph with no per-step host arguments (titanet_amd/trainer.py). */
+int tn_plan_step_tick(tn_plan* p, void* stream);
+int tn_plan_step_set(tn_plan* p, int64_t step, void* stream);   /* step 0 = word 0 (the ungraphed convention) */
+int tn_adam_step_plan(tn_plan* p, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, float grad_mult, void* stream);
+
 /* ---- mel front end: MelSpectrogram.__call__ (reference src/transforms.py:158-203) -----------------------
  * Spectrogram(n_fft, win_length, hop_length, power=None) -> |.|^2 -> MelScale(n_mels, sample_rate) ->
  * AmplitudeToDB() -> F.normalize(dim=1) -> SpecAugment frequency/time masks, for a batch of equal-length

@@ -16,7 +16,8 @@ EXPORTS = [
     "tn_model_create", "tn_model_destroy", "tn_model_param_floats", "tn_model_buffer_floats", "tn_model_num_bn",
     "tn_model_num_tensors", "tn_model_tensor_info", "tn_plan_create", "tn_plan_destroy", "tn_plan_workspace_bytes",
     "tn_plan_bind", "tn_forward", "tn_backward", "tn_adam_step", "tn_debug_fetch", "tn_version", "tn_profile_begin",
-    "tn_profile_read", "tn_mel_create", "tn_mel_destroy", "tn_mel_num_frames", "tn_mel_forward",
+    "tn_profile_read", "tn_mel_create", "tn_mel_destroy", "tn_mel_num_frames", "tn_mel_forward", "tn_plan_step_tick",
+    "tn_plan_step_set", "tn_adam_step_plan",
 ]
 
 
@@ -71,6 +72,9 @@ def load():
     lib.tn_forward.argtypes = [vp, vp, vp, i32, C.c_uint64, vp, vp, vp, vp]
     lib.tn_backward.argtypes = [vp, f32, vp, vp, vp, vp]
     lib.tn_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]
+    lib.tn_plan_step_tick.argtypes = [vp, vp]
+    lib.tn_plan_step_set.argtypes = [vp, i64, vp]
+    lib.tn_adam_step_plan.argtypes = [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp]
     lib.tn_debug_fetch.argtypes = [vp, C.c_char_p, vp, i64, vp]
     lib.tn_profile_begin.argtypes = [vp, i32]
     lib.tn_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]

@@ -196,6 +196,8 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   p->dw_gacc = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * TN_NREP * (c.kernel + 1) * H * sizeof(float));
   p->bzero_bytes = ((b.off + 255) & ~(size_t)255) - p->bzero_begin;
   b.off = p->bzero_begin + p->bzero_bytes;
+  // ---- device-resident step state {uint64 step; uint32 word; ...}: cleared once at bind, advanced by tn_plan_step_tick
+  p->step_state = b.take(64);
   // ---- compute-precision weights
   auto wc = [&](size_t n, size_t k) { WcRef r; r.w = b.take(n * k * e); r.wt = b.take(n * k * e); return r; };
   p->wprolog = wc(H, (size_t)c.n_mels * c.prolog_kernel);
@@ -316,6 +318,7 @@ extern "C" int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbu
   if (workspace_bytes < p->ws_bytes) return TN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   p->params = params; p->grads = grads; p->bnbuf = bnbuf; p->nbt = nbt; p->ws = (char*)workspace;
+  TN_CHECK_HIP(hipMemsetAsync(p->ws + p->step_state, 0, 64, st));
   const tn_model* m = p->model;
   const tn_config& c = m->cfg;
   // cast table: bf16 needs the straight copy + the transpose; fp32 reads the masters directly and
@@ -386,6 +389,7 @@ BnAct make_act(const tn_plan* p, const BnRef& bn, int rows, int training, int re
     a.drop_thr = (uint32_t)lrintf(drop_p * 65536.f);
     a.drop_key = tn_layer_key(seed, (uint32_t)layer);
     a.inv_keep = 1.f / (1.f - drop_p);
+    a.key_add = p->ws ? (const uint32_t*)(p->ws + p->step_state) + 2 : nullptr;
   }
   return a;
 }
@@ -505,6 +509,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
         ca.S = (const bf16_t*)(ws + bw.S); ca.actS = acts; ca.Y3 = (const bf16_t*)cur; ca.act3 = acur;
         ca.gate = (const float*)(ws + bw.g); ca.OUT = (bf16_t*)(ws + bw.OUT); ca.T = T; ca.parts = p->combine_parts;
         ca.drop_thr = thr; ca.drop_key = key; ca.inv_keep = ik;
+        ca.key_add = (const uint32_t*)(ws + p->step_state) + 2;
         rc2 = launch_combine_fwd_v2(ca, B, st);
         if (rc2 > 0) return rc2;
       }
@@ -512,7 +517,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
         const int rpb = 64;
         hipLaunchKernelGGL(combine_fwd_kernel<AT>, dim3((M + rpb - 1) / rpb), dim3(256), (size_t)4 * H * sizeof(float), st,
                            (const AT*)(ws + bw.S), acts, (const AT*)cur, acur, (const float*)(ws + bw.g), (AT*)(ws + bw.OUT), M,
-                           T, H, rpb, thr, key, ik);
+                           T, H, rpb, thr, key, ik, (const uint32_t*)(ws + p->step_state) + 2);
       }
     }
     xin = ws + bw.OUT;
@@ -678,6 +683,48 @@ extern "C" int tn_adam_step(float* params, const float* grads, float* exp_avg, f
 }
 
 // =============================================================================================
+// device-resident step state: lets forward + backward + Adam replay as ONE hipGraph (nothing that changes from
+// step to step is a kernel argument any more: the dropout word and the Adam step live in the workspace)
+// =============================================================================================
+__global__ void step_tick_kernel(uint64_t* st, uint64_t set_to, int do_set) {
+  const uint64_t s = do_set ? set_to : st[0] + 1;
+  st[0] = s;
+  reinterpret_cast<uint32_t*>(st)[2] = s ? tn_mix32((uint32_t)s * 0x9E3779B9u + (uint32_t)(s >> 32) + 0x85ebca6bu) : 0u;
+}
+extern "C" int tn_plan_step_tick(tn_plan* p, void* stream) {
+  if (!p || !p->bound) return TN_E_STATE;
+  hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (uint64_t*)(p->ws + p->step_state), (uint64_t)0, 0);
+  return (int)hipGetLastError();
+}
+extern "C" int tn_plan_step_set(tn_plan* p, int64_t step, void* stream) {
+  if (!p || !p->bound || step < 0) return TN_E_STATE;
+  hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (uint64_t*)(p->ws + p->step_state), (uint64_t)step, 1);
+  return (int)hipGetLastError();
+}
+__global__ void adam_dev_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                     int64_t n, float lr, float b1, float b2, float eps, float wd, const uint64_t* __restrict__ st,
+                                     float gmul) {
+  const float step = (float)st[0];
+  const float bc1 = 1.f - powf(b1, step), bc2 = sqrtf(1.f - powf(b2, step));
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gmul;
+    if (wd != 0.f) gi += wd * p[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2 + eps);
+  }
+}
+extern "C" int tn_adam_step_plan(tn_plan* p, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay, float grad_mult, void* stream) {
+  if (!p || !p->bound || !params || !grads || !exp_avg || !exp_avg_sq || n <= 0) return TN_E_BADARG;
+  int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(adam_dev_step_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr,
+                     beta1, beta2, eps, weight_decay, (const uint64_t*)(p->ws + p->step_state), grad_mult);
+  return (int)hipGetLastError();
+}
+
+// =============================================================================================
 // debug fetch (tests): internal rows-x-channels tensors -> float32 reference layout
 // =============================================================================================
 template <typename AT>
@@ -688,7 +735,7 @@ __global__ void fetch_bct_kernel(const AT* __restrict__ src, BnAct act, int M, i
     float v = Elem<AT>::to_f(src[i]);
     if (act.mode != 0) { float sc, sh; bn_scale_shift(act, C, c, sc, sh); v = v * sc + sh; }
     if (act.relu) v = fmaxf(v, 0.f);
-    if (act.drop_thr && !tn_keep_elem((uint32_t)i, act.drop_key, act.drop_thr)) v = 0.f;   // (1/(1-p) is in sc, sh)
+    if (act.drop_thr && !tn_keep_elem((uint32_t)i, tn_act_key(act), act.drop_thr)) v = 0.f;   // (1/(1-p) is in sc, sh)
     const int b = row / T, t = row % T;
     dst[((size_t)b * C + c) * T + t] = v;
   }

@@ -163,6 +163,8 @@ struct BnAct {
   int relu;             // apply max(.,0)
   uint32_t drop_thr;    // 0 = no dropout; else round(p * 65536)
   uint32_t drop_key;    // tn_layer_key(seed, layer)
+  const uint32_t* key_add;   // device word added to drop_key (the plan's per-step word: 0 unless tn_plan_step_tick drives the
+                             // step from device memory, which is what lets a whole training step replay as ONE hipGraph); or null
   float inv_keep;       // 1 / (1 - p)
 };
 
@@ -186,6 +188,8 @@ __device__ __forceinline__ void bn_scale_shift(const BnAct& a, int C, int c, flo
   if (a.drop_thr) { sc *= a.inv_keep; sh *= a.inv_keep; }
 }
 
+__device__ __forceinline__ uint32_t tn_act_key(const BnAct& a) { return a.key_add ? a.drop_key + *a.key_add : a.drop_key; }
+
 // apply act to 8 consecutive channels of row `row` (element index = row*C + c0 + i)
 __device__ __forceinline__ void act8(float v[8], const float* sc, const float* sh, const BnAct& a,
                                      uint32_t row, int C, int c0) {
@@ -197,7 +201,7 @@ __device__ __forceinline__ void act8(float v[8], const float* sc, const float* s
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
   }
-  if (a.drop_thr) tn_drop8(v, (row * (uint32_t)C + (uint32_t)c0) >> 3, a.drop_key, a.drop_thr);
+  if (a.drop_thr) tn_drop8(v, (row * (uint32_t)C + (uint32_t)c0) >> 3, tn_act_key(a), a.drop_thr);
 }
 // mask-only variant for the backward pass: given the raw value's post-BN sign and the keep
 // bits, returns the multiplier d(act)/d(bn output) for each of the 8 channels.
@@ -209,7 +213,7 @@ __device__ __forceinline__ void act8_grad_mask(const float raw[8], float m[8], c
     float z = (a.mode != 0) ? raw[i] * sc[i] + sh[i] : raw[i];     // (sc, sh carry the 1/(1-p) factor: sign unchanged)
     m[i] = (!a.relu || z > 0.f) ? on : 0.f;
   }
-  if (a.drop_thr) tn_drop8(m, (row * (uint32_t)C + (uint32_t)c0) >> 3, a.drop_key, a.drop_thr);
+  if (a.drop_thr) tn_drop8(m, (row * (uint32_t)C + (uint32_t)c0) >> 3, tn_act_key(a), a.drop_thr);
 }
 
 // ------------------------------------------------------------------------------------------

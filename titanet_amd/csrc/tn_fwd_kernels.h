@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(const AT* __restrict__
                                                           const AT* __restrict__ Y3, BnAct act3,
                                                           const float* __restrict__ gate, AT* __restrict__ OUT, int M,
                                                           int T, int C, int rows_per_block, uint32_t drop_thr,
-                                                          uint32_t drop_key, float inv_keep) {
+                                                          uint32_t drop_key, float inv_keep, const uint32_t* key_add) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* scS = reinterpret_cast<float*>(smem);
   float* shS = scS + C;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(const AT* __restrict__
     if (drop_thr) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) o[q] *= inv_keep;
-      tn_drop8(o, ((uint32_t)row * (uint32_t)C + (uint32_t)c0) >> 3, drop_key, drop_thr);
+      tn_drop8(o, ((uint32_t)row * (uint32_t)C + (uint32_t)c0) >> 3, key_add ? drop_key + *key_add : drop_key, drop_thr);
     }
     store8(OUT + (size_t)row * C + c0, o);
   }

@@ -89,6 +89,7 @@ struct tn_plan {
   size_t zero_begin, zero_bytes;        // region cleared at the start of every forward
   int combine_parts = 4;                // row parts per utterance of the v2 element-wise kernels (env TN_PARTS)
   size_t bzero_begin, bzero_bytes;      // region cleared at the start of every backward
+  size_t step_state = 0;                // {uint64 step; uint32 word}: device-resident step counter / dropout word (hipGraph replay)
   std::vector<size_t> stats;            // per BN id: forward sums  float[NREP][2][C]
   std::vector<size_t> bsums;            // per BN id: backward sums float[NREP][2][C]
   size_t loss_acc;

@@ -69,7 +69,7 @@ __device__ __forceinline__ void wg2_act8(float v[8], const float* sc, const floa
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
   }
-  if (FL & 4) tn_drop8(v, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, a.drop_key, a.drop_thr);
+  if (FL & 4) tn_drop8(v, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, tn_act_key(a), a.drop_thr);
 }
 
 template <int KD, bool DW, int FL>
@@ -581,7 +581,7 @@ __device__ __forceinline__ void act4_reg(float v[4], const float sc[4], const fl
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
   }
-  if (a.drop_thr) tn_drop4(v, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, (uint32_t)(c0 >> 2) & 1u, a.drop_key, a.drop_thr);
+  if (a.drop_thr) tn_drop4(v, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, (uint32_t)(c0 >> 2) & 1u, tn_act_key(a), a.drop_thr);
 }
 
 template <int KD>
@@ -799,7 +799,7 @@ __global__ __launch_bounds__(512, 2) void dw_bwd_v4_kernel(DwBwdV3Args a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, strip = tid >> 6, c0 = lane * 4;
   const float mscale = (FL & 4) ? a.actX.inv_keep : 1.f;
-  const uint32_t dkey = a.actX.drop_key, dthr = a.actX.drop_thr;
+  const uint32_t dkey = tn_act_key(a.actX), dthr = a.actX.drop_thr;
 
   if (tid < V2_C) {
     float s = 1.f, h = 0.f, mean = 0.f, rstd = 1.f;
@@ -1126,7 +1126,7 @@ __global__ __launch_bounds__(512) void combine_bwd2_v2_kernel(CombineBwd2V2Args 
     sc[i] = cst[c0 + i]; sh[i] = cst[V2_C + c0 + i]; g[i] = gS[c0 + i]; dm[i] = dmT[c0 + i]; s1[i] = 0.f; s2[i] = 0.f;
   }
   const float on = (FL3 & 4) ? a.act3.inv_keep : 1.f;
-  const uint32_t dkey = a.act3.drop_key, dthr = a.act3.drop_thr;
+  const uint32_t dkey = tn_act_key(a.act3), dthr = a.act3.drop_thr;
   for (int tb = t0 + tg; tb < t1; tb += 16 * U) {
     uint4 cd[U], cy[U];
 #pragma unroll

@@ -49,7 +49,7 @@ __device__ __forceinline__ void act8_reg(float v[8], const float sc[8], const fl
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
   }
-  if (a.drop_thr) tn_drop8(v, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, a.drop_key, a.drop_thr);
+  if (a.drop_thr) tn_drop8(v, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, tn_act_key(a), a.drop_thr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v4_kernel(SubFwdV2Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vc = tid & 31, rq = tid >> 5;          // this thread's channel vector and row phase (rows rq + 16 q)
   const int c0 = vc * 8;
-  const uint32_t dkey = a.act.drop_key, dthr = a.act.drop_thr;
+  const uint32_t dkey = tn_act_key(a.act), dthr = a.act.drop_thr;
 
   // ---- per-thread constants: BN scale/shift and depthwise taps of the thread's 8 channels.
   // Computed cooperatively (one channel per thread, 18 loads) and redistributed through LDS: having
@@ -539,6 +539,7 @@ struct CombineFwdV2Args {
   int T, parts;
   uint32_t drop_thr, drop_key;
   float inv_keep;
+  const uint32_t* key_add;   // see BnAct::key_add
 };
 template <int FL3, bool DROP>
 __global__ __launch_bounds__(256) void combine_fwd_v2_kernel(CombineFwdV2Args a) {
@@ -568,7 +569,8 @@ __global__ __launch_bounds__(256) void combine_fwd_v2_kernel(CombineFwdV2Args a)
   }
   const int per = (a.T + a.parts - 1) / a.parts;
   const int t0 = part * per, t1 = min(a.T, t0 + per);
-  const uint32_t dkey3 = a.act3.drop_key, dthr3 = a.act3.drop_thr;
+  const uint32_t dkey3 = tn_act_key(a.act3), dthr3 = a.act3.drop_thr;
+  const uint32_t okey = a.key_add ? a.drop_key + *a.key_add : a.drop_key;
   constexpr int U = 4;
   for (int tb = t0 + rq; tb < t1; tb += 8 * U) {
     uint4 rs[U], ry[U];
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(256) void combine_fwd_v2_kernel(CombineFwdV2Args a)
         act8_t<FL3>(y, sc3, sh3, dkey3, dthr3, row, c0);
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] = fmaxf(fmaf(s[q], scS[q], fmaf(g[q], y[q], shS[q])), 0.f);
-        if (DROP) tn_drop8(o, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, a.drop_key, a.drop_thr);
+        if (DROP) tn_drop8(o, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, okey, a.drop_thr);
         store8(a.OUT + (size_t)row * V2_C + c0, o);
       }
     }
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(512) void se_squeeze_v2_kernel(SeSqueezeV2Args a) {
   float sc[8], sh[8], acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { sc[i] = cst[c0 + i]; sh[i] = cst[V2_C + c0 + i]; acc[i] = 0.f; }
-  const uint32_t dkey = a.act.drop_key, dthr = a.act.drop_thr;
+  const uint32_t dkey = tn_act_key(a.act), dthr = a.act.drop_thr;
   constexpr int U = 4;
   for (int tb = tg; tb < a.T; tb += 16 * U) {
     uint4 ry[U];
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
   const int ltid = tid & 255;                        // thread index inside the team
   const int vc = ltid & 31, rq = ltid >> 5, c0 = vc * 8;   // 32 channel vectors x 8 row phases
   const int half = lane >> 5, cw = wave & 3;         // consumer: 64 output channels cw*64 ..
-  const uint32_t dkey = a.act.drop_key, dthr = a.act.drop_thr;
+  const uint32_t dkey = tn_act_key(a.act), dthr = a.act.drop_thr;
   const int stride = gridDim.x;
   const int first = blockIdx.x;
   if (first >= a.ntiles) return;

@@ -337,7 +337,7 @@ class TitaNet(nn.Module):
         self._plans[key] = plan
         return plan
 
-    def _native_forward(self, spectrograms, speakers):
+    def _native_forward(self, spectrograms, speakers, fixed_seed=False):
         if spectrograms.dim() != 3 or spectrograms.shape[1] != self._cfg.n_mels:
             raise ValueError(f"expected spectrograms of shape [B, {self._cfg.n_mels}, T], got {tuple(spectrograms.shape)}")
         if not spectrograms.is_cuda:
@@ -356,8 +356,11 @@ class TitaNet(nn.Module):
             y = speakers.detach().to(device=dev, dtype=torch.int64).contiguous()
             preds = torch.empty(B, dtype=torch.int64, device=dev)
             loss = torch.empty((), dtype=torch.float32, device=dev)
-        seed = (self._seed_base + self._step * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
-        self._step += 1
+        if fixed_seed:      # the per-step variation comes from the plan's device-resident step word (trainer graph mode)
+            seed = self._seed_base & 0xFFFFFFFFFFFFFFFF
+        else:
+            seed = (self._seed_base + self._step * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+            self._step += 1
         stream = torch.cuda.current_stream(dev).cuda_stream
         check(self._lib.tn_forward(plan.handle, _ptr(x), _ptr(y), 1 if self.training else 0, C.c_uint64(seed), _ptr(emb),
                                    _ptr(preds), _ptr(loss), C.c_void_p(stream)), "tn_forward")

@@ -11,6 +11,11 @@ batch sharded contiguously over ranks, BatchNorm statistics local to each rank (
 flat float32 gradient buffer summed with RCCL (``torch.distributed`` backend "nccl" == RCCL on ROCm)
 in a few large buckets sized for the xGMI links (fewer, larger collectives), the 1/world factor folded
 into the fused Adam kernel.  The collective runs on a side stream ordered by events.
+
+``use_graph=True`` (single GPU): the whole step — ~470 kernel launches for TitaNet-S — is captured once per input shape
+into ONE hipGraph and replayed; the per-step state that used to be kernel arguments (dropout stream, Adam step count)
+lives in device memory (``tn_plan_step_tick`` / ``tn_adam_step_plan``, include/titanet_amd.h).  Small batches are
+launch-bound (batch 8: the reference's own parameters.yml batch), which is where this pays.
 """
 import ctypes as C
 
@@ -68,11 +73,15 @@ class FlatAllReducer:
 class Trainer:
     """``step(spectrograms, speakers)`` == one iteration of reference src/learn.py:88-135."""
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, n_buckets=4, group=None):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, n_buckets=4, group=None,
+                 use_graph=False, graph_warmup=2):
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.reducer = FlatAllReducer(n_buckets, group)
         self.step_count = 0
+        self.use_graph = bool(use_graph) and self.reducer.world == 1
+        self.graph_warmup = graph_warmup
+        self._graphs = {}          # (B, T) -> dict(graph, x, y, out, eager_steps)
         flat = model.flat_parameters()
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
@@ -103,7 +112,54 @@ class Trainer:
               "tn_adam_step")
 
     def step(self, spectrograms, speakers):
+        if self.use_graph:
+            return self._graph_step(spectrograms, speakers)
         out = self.forward_backward(spectrograms, speakers)
         self.reducer.all_reduce_(self.model.flat_gradients())
         self.optimizer_step()
         return out
+
+    # ------------------------------------------------------------------ one hipGraph per step
+    def _device_step(self, x, y):
+        """tick -> forward -> backward -> Adam, with the step count and the dropout word in device memory"""
+        m = self.model
+        vp = C.c_void_p
+        plan = m._get_plan(x.shape[0], x.shape[2])
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        check(m._lib.tn_plan_step_tick(plan.handle, vp(stream)), "tn_plan_step_tick")
+        emb, preds, loss, plan = m._native_forward(x, y, fixed_seed=True)
+        check(m._lib.tn_backward(plan.handle, C.c_float(1.0), vp(0), vp(0), vp(0), vp(stream)), "tn_backward")
+        flat, grads = m.flat_parameters(), m.flat_gradients()
+        check(m._lib.tn_adam_step_plan(plan.handle, vp(flat.data_ptr()), vp(grads.data_ptr()), vp(self.exp_avg.data_ptr()),
+                                       vp(self.exp_avg_sq.data_ptr()), flat.numel(), self.lr, self.betas[0], self.betas[1],
+                                       self.eps, self.weight_decay, 1.0, vp(stream)), "tn_adam_step_plan")
+        return emb, preds, loss, plan
+
+    def _graph_step(self, spectrograms, speakers):
+        key = (tuple(spectrograms.shape), spectrograms.device.index)
+        st = self._graphs.get(key)
+        if st is None:
+            st = self._graphs[key] = {"graph": None, "eager": 0,
+                                      "x": torch.empty_like(spectrograms), "y": torch.empty_like(speakers)}
+        st["x"].copy_(spectrograms)
+        st["y"].copy_(speakers)
+        self.step_count += 1
+        if st["graph"] is not None and self.model._plans.get(st["plan"].key) is not st["plan"]:
+            st["graph"], st["eager"] = None, 0          # the plan was evicted from the model's cache: capture again
+        if st["graph"] is None:
+            if st["eager"] == 0:
+                # the plan's device step counter continues this trainer's count
+                plan = self.model._get_plan(st["x"].shape[0], st["x"].shape[2])
+                stream = torch.cuda.current_stream(st["x"].device).cuda_stream
+                check(self.model._lib.tn_plan_step_set(plan.handle, self.step_count - 1, C.c_void_p(stream)), "tn_plan_step_set")
+            if st["eager"] < self.graph_warmup:
+                st["eager"] += 1
+                return self._device_step(st["x"], st["y"])[:3]
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                out = self._device_step(st["x"], st["y"])
+            st["out"], st["plan"], st["graph"] = out[:3], out[3], g
+            # the capture itself does not execute: run the captured step for this call
+        st["graph"].replay()
+        return st["out"]
