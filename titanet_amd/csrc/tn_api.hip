@@ -171,8 +171,10 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   {
     const char* e = getenv("TN_V2");
     // TN_V2 = bit mask (debug / A-B): 1 forward sub-block, 2 forward skip conv, 4 batched weight gradients, 8 fused data-gradient kernel; default all
-    const int mask = e ? atoi(e) : 31;   // 16: wide (1536-channel) decoder-side kernels
+    const int mask = e ? atoi(e) : 63;   // 16: wide (1536-channel) decoder-side kernels
     p->use_v2 = (precision == TN_PREC_BF16 && m->cfg.hidden == 256 && m->cfg.kernel == 3) ? mask : 0;
+    // 32: keep the depthwise outputs for the batched weight gradients (needs 1 and 4)
+    p->save_q = (p->use_v2 & 1) && (p->use_v2 & 4) && (p->use_v2 & 32);
     const char* pe = getenv("TN_PARTS");
     if (pe && atoi(pe) > 0) p->combine_parts = atoi(pe);
   }
@@ -209,6 +211,8 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   p->blk.resize(c.n_mega_blocks);
   for (auto& bw : p->blk) {
     for (int j = 0; j < c.n_sub_blocks; ++j) { bw.Y.push_back(b.take(M * H * e)); bw.wpw.push_back(wc(H, H)); }
+    if (p->save_q)
+      for (int j = 0; j < c.n_sub_blocks; ++j) bw.Q.push_back(b.take(M * H * e));
     bw.wskip = wc(H, H);
     bw.S = b.take(M * H * e);
     bw.OUT = b.take(M * H * e);
@@ -468,7 +472,8 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
         ProfScope ps(p, TN_PROF_FWD_SUBBLOCK, st);
         if (p->use_v2 & 1) {
           SubFwdV2Args va{(const bf16_t*)cur, acur, params + sb.wdw, params + sb.bdw, (const bf16_t*)(ws + bw.wpw[j].w),
-                          params + sb.bpw, (bf16_t*)(ws + bw.Y[j]), statp(sb.bn), M, T, 0};
+                          params + sb.bpw, (bf16_t*)(ws + bw.Y[j]), statp(sb.bn), M, T, 0,
+                          (p->save_q && training) ? (bf16_t*)(ws + bw.Q[j]) : nullptr};
           rc = launch_sub_fwd_v5<3, true>(va, 256, st);
         } else {
           rc = gemm_store<AT, ProdDw>(g, pa, ea, c.kernel, st);

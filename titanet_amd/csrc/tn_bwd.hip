@@ -469,7 +469,10 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
       for (int j = 0; j < nsub; ++j) {
         const void* sin = j > 0 ? (const void*)(p->ws + bw.Y[j - 1]) : xin;
         BnAct asin = j > 0 ? make_act(p, mb.sub[j - 1].bn, M, 1, 1, pd, 0, 0) : actx;
-        add(bw.dY[j], bw.Y[j], mb.sub[j].bn, sin, asin, i * (nsub + 1) + j - 1, mb.sub[j].wdw, mb.sub[j].bdw, mb.sub[j].wpw);
+        if (p->save_q)   // the forward kept the depthwise output: a plain operand, no activation / stencil recompute
+          add(bw.dY[j], bw.Y[j], mb.sub[j].bn, (const void*)(p->ws + bw.Q[j]), identity_act(), 0, -1, -1, mb.sub[j].wpw);
+        else
+          add(bw.dY[j], bw.Y[j], mb.sub[j].bn, sin, asin, i * (nsub + 1) + j - 1, mb.sub[j].wdw, mb.sub[j].bdw, mb.sub[j].wpw);
       }
     }
     // epilog conv: d W[s*256 .. +256][256] = BN-backward(dEbn, E)[:, slab s]^T * x_last   (x_last = last block output, stored activated)

@@ -61,6 +61,7 @@ struct WcRef {
 
 struct BlockWs {
   std::vector<size_t> Y;   // raw sub-block outputs
+  std::vector<size_t> Q;   // saved depthwise outputs (operand of the pointwise GEMM) for the batched weight gradients, or empty
   size_t S, OUT;
   size_t m, h, g;          // SE: mean [B][C], hidden [B][Hr], gate [B][C]  (float)
   std::vector<WcRef> wpw;
@@ -87,6 +88,7 @@ struct tn_plan {
   bool bound = false;
   // workspace layout (byte offsets)
   size_t zero_begin, zero_bytes;        // region cleared at the start of every forward
+  bool save_q = false;                  // forward stores the depthwise outputs (bf16 v2 path with batched weight gradients)
   int combine_parts = 4;                // row parts per utterance of the v2 element-wise kernels (env TN_PARTS)
   size_t bzero_begin, bzero_bytes;      // region cleared at the start of every backward
   size_t step_state = 0;                // {uint64 step; uint32 word}: device-resident step counter / dropout word (hipGraph replay)

@@ -66,6 +66,8 @@ struct SubFwdV2Args {
   bf16_t* Y;            // [M][256]
   float* stats;         // [TN_NREP][2][256] or null
   int M, T, ntiles;
+  bf16_t* Q;            // [M][256] or null: the depthwise output (the pointwise GEMM's operand) is ALSO stored, so that the
+                        // batched weight-gradient launch reads it instead of recomputing activation + stencil (sub_fwd_v5 only)
 };
 
 template <int KD, bool DW>
@@ -827,6 +829,7 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
 #pragma unroll
               for (int i = 0; i < 8; ++i) acc[i] = fmaf(wd[k][i], win[q + k][i], acc[i]);
             store8(As + (o0 + q) * V2_AP + c0, acc);
+            if (a.Q && o0 + q < OUTR && out0 + o0 + q < a.M) store8(a.Q + (size_t)(out0 + o0 + q) * V2_C + c0, acc);
           }
         } else {
 #pragma unroll
@@ -847,6 +850,7 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
               }
             }
             store8(As + o * V2_AP + c0, acc);
+            if (a.Q && o < OUTR && out0 + o < a.M) store8(a.Q + (size_t)(out0 + o) * V2_C + c0, acc);
           }
         }
       }
