@@ -301,248 +301,6 @@ __global__ void wgrad_v2_reduce_kernel(const WgradV2Out* __restrict__ outs, cons
 }
 
 // ==========================================================================================
-// Backward of one sub-block's data path in ONE persistent kernel:
-//   dY  = BatchNorm-backward-on-load(dZ, Y)                       (this layer's BN)
-//   dD  = dY * W_pw                                               (pointwise data gradient, MFMA,
-//                                                                  W^T resident in registers)
-//   dA  = depthwise^T(dD)  [+ ADD]                                (transposed stencil over time)
-//   OUT = dA * d act / d bn (X)                                   (-> d loss / d BN-output of the
-//                                                                  previous layer) + its BN sums
-//   d w_dw, d b_dw                                                (depthwise parameter gradients)
-// DW = false: plain 1x1 conv data gradient (skip connection): OUT = dD.
-// Row tiles overlap by KD-1 rows (the stencil needs dD of the neighbouring rows, so the GEMM is
-// evaluated on 64 rows and 64-(KD-1) rows are emitted).  MFMA roles are swapped (A = weights,
-// B = activation rows) so each lane ends up with 4 CONSECUTIVE channels of one row: the dD tile goes
-// to LDS with 8-byte writes instead of 2-byte ones.
-// ==========================================================================================
-struct SubBwdV2Args {
-  const bf16_t* dZ;
-  const bf16_t* Y;
-  BnBwd bn;
-  const bf16_t* Wt;       // [256 in-channels][256 out-channels] bf16 (transposed pointwise weight)
-  const bf16_t* X;        // raw input of the layer
-  BnAct actX;
-  const float* wdw;       // [256][KD]
-  float* g_wdw;           // [256][KD]  (atomic accumulate; pre-zeroed)
-  float* g_bdw;           // [256]
-  const bf16_t* ADD;      // [M][256] or null
-  float* bsumsX;          // [TN_NREP][2][256] or null
-  bf16_t* OUT;            // [M][256]
-  int M, T, ntiles;
-};
-
-template <int KD, bool DW>
-__global__ __launch_bounds__(V2_NT, 2) void sub_bwd_v2_kernel(SubBwdV2Args a) {
-  constexpr int PADR = DW ? (KD - 1) / 2 : 0;
-  constexpr int OUTR = DW ? V2_R - (KD - 1) : V2_R;
-  constexpr int NC = 7 + (DW ? KD : 1);
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* Pt = reinterpret_cast<bf16_t*>(smem);      // [64][264] dY rows (MFMA B operand)
-  bf16_t* Dt = Pt + V2_R * V2_AP;                     // [64][264] dD rows
-  bf16_t* Xa = Dt + V2_R * V2_AP;                     // [64][256] activated input rows
-  bf16_t* Xr = Xa + V2_R * V2_C;                      // [64][256] raw input rows
-  float* cst = reinterpret_cast<float*>(Xr + V2_R * V2_C);   // k0,k1,k2,sc,sh,mean,rstd,wd[KD] : [NC][256]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int vc = tid & 31, rq = tid >> 5, c0 = vc * 8;
-  const bool has_mask = DW && (a.actX.mode != 0 || a.actX.relu || a.actX.drop_thr);
-
-  if (tid < V2_C) {
-    float k0, k1, k2;
-    bn_bwd_coefs(a.bn, V2_C, tid, k0, k1, k2);
-    cst[tid] = k0; cst[V2_C + tid] = k1; cst[2 * V2_C + tid] = k2;
-    if (DW) {
-      float s = 1.f, h = 0.f, mean = 0.f, rstd = 1.f;
-      if (a.actX.mode != 0) {
-        bn_scale_shift(a.actX, V2_C, tid, s, h);
-        bn_mean_rstd(a.actX, V2_C, tid, mean, rstd);
-      }
-      cst[3 * V2_C + tid] = s; cst[4 * V2_C + tid] = h; cst[5 * V2_C + tid] = mean; cst[6 * V2_C + tid] = rstd;
-#pragma unroll
-      for (int k = 0; k < KD; ++k) cst[(7 + k) * V2_C + tid] = a.wdw[(size_t)tid * KD + k];
-    }
-  }
-  // W^T rows of this wave's 32 input channels as MFMA A fragments (resident)
-  const int half = lane >> 5;
-  bf16x8_t wf[16];
-  {
-    const int ci = wave * 32 + (lane & 31);
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
-      wf[ks] = *reinterpret_cast<const bf16x8_t*>(a.Wt + (size_t)ci * V2_C + ks * 16 + half * 8);
-  }
-  float gw[DW ? KD : 1][8], gb[8], s1[8], s2[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    gb[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f;
-#pragma unroll
-    for (int k = 0; k < (DW ? KD : 1); ++k) gw[k][i] = 0.f;
-  }
-
-  uint4 pz[4], py[4], px[4], pa[4];
-  auto prefetch = [&](int tile) {
-    const int raw0 = tile * OUTR - PADR;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int gr = raw0 + rq + 16 * q;
-      const bool ok = gr >= 0 && gr < a.M;
-      const size_t o = (size_t)gr * V2_C + c0;
-      pz[q] = ok ? *reinterpret_cast<const uint4*>(a.dZ + o) : make_uint4(0, 0, 0, 0);
-      py[q] = ok ? *reinterpret_cast<const uint4*>(a.Y + o) : make_uint4(0, 0, 0, 0);
-      if (DW) px[q] = ok ? *reinterpret_cast<const uint4*>(a.X + o) : make_uint4(0, 0, 0, 0);
-      if (DW && a.ADD) {
-        // the addend is needed on OUTPUT rows: output row o = rq + 16 q  <->  global row tile*OUTR + o
-        const int go = tile * OUTR + rq + 16 * q;
-        pa[q] = (rq + 16 * q < OUTR && go < a.M) ? *reinterpret_cast<const uint4*>(a.ADD + (size_t)go * V2_C + c0)
-                                                 : make_uint4(0, 0, 0, 0);
-      }
-    }
-  };
-  int tile = blockIdx.x;
-  if (tile < a.ntiles) prefetch(tile);
-  for (; tile < a.ntiles; tile += gridDim.x) {
-    const int out0 = tile * OUTR, raw0 = out0 - PADR;
-    __syncthreads();   // (1) previous tile fully consumed; constants visible
-    uint4 addv[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = rq + 16 * q, gr = raw0 + r;
-      const bool ok = gr >= 0 && gr < a.M;
-      float z[8], y[8];
-      unpack8(pz[q], z);
-      unpack8(py[q], y);
-      if (ok) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) z[i] = cst[c0 + i] * z[i] + cst[V2_C + c0 + i] * y[i] + cst[2 * V2_C + c0 + i];
-      }
-      store8(Pt + r * V2_AP + c0, z);
-      if (DW) {
-        *reinterpret_cast<uint4*>(Xr + r * V2_C + c0) = px[q];
-        float v[8];
-        unpack8(px[q], v);
-        if (ok) act8(v, cst + 3 * V2_C + c0, cst + 4 * V2_C + c0, a.actX, (uint32_t)gr, V2_C, c0);
-        store8(Xa + r * V2_C + c0, v);
-        addv[q] = pa[q];
-      }
-    }
-    if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
-    __syncthreads();   // (2)
-    // ---- dD^T = W^T-rows x dY-rows^T : A = weights (registers), B = dY rows (LDS)
-    f32x16_t acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const bf16_t* brow = Pt + (lane & 31) * V2_AP + half * 8;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(brow + ks * 16);
-      const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(brow + 32 * V2_AP + ks * 16);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b1, acc1, 0, 0, 0);
-    }
-    // lane: row n = lane&31 (+32 for acc1); regs 4g..4g+3 = channels 32*wave + 8g + 4*half + 0..3
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int ci = wave * 32 + 8 * g + 4 * half;
-      uint2 w0, w1;
-      w0.x = f2bf_pk(acc0[4 * g], acc0[4 * g + 1]); w0.y = f2bf_pk(acc0[4 * g + 2], acc0[4 * g + 3]);
-      w1.x = f2bf_pk(acc1[4 * g], acc1[4 * g + 1]); w1.y = f2bf_pk(acc1[4 * g + 2], acc1[4 * g + 3]);
-      *reinterpret_cast<uint2*>(Dt + (lane & 31) * V2_AP + ci) = w0;
-      *reinterpret_cast<uint2*>(Dt + (32 + (lane & 31)) * V2_AP + ci) = w1;
-    }
-    __syncthreads();   // (3)
-    if (!DW) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int o = rq + 16 * q, gr = out0 + o;
-        if (gr < a.M) *reinterpret_cast<uint4*>(a.OUT + (size_t)gr * V2_C + c0) = *reinterpret_cast<const uint4*>(Dt + o * V2_AP + c0);
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int o = rq + 16 * q, gr = out0 + o;
-        if (o >= OUTR || gr >= a.M) continue;
-        const int t = gr % a.T;
-        float dA[8], dc[8];
-        load8(Dt + (o + PADR) * V2_AP + c0, dc);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { dA[i] = 0.f; gb[i] += dc[i]; }
-#pragma unroll
-        for (int k = 0; k < KD; ++k) {
-          const int tb = t - k + PADR;
-          if (tb >= 0 && tb < a.T) {
-            float v[8];
-            load8(Dt + (o + 2 * PADR - k) * V2_AP + c0, v);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dA[i] = fmaf(cst[(7 + k) * V2_C + c0 + i], v[i], dA[i]);
-          }
-          const int tf = t + k - PADR;
-          if (tf >= 0 && tf < a.T) {
-            float v[8];
-            load8(Xa + (o + k) * V2_C + c0, v);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) gw[k][i] = fmaf(dc[i], v[i], gw[k][i]);
-          }
-        }
-        if (a.ADD) {
-          float ad[8];
-          unpack8(addv[q], ad);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) dA[i] += ad[i];
-        }
-        if (has_mask) {
-          float y[8], m[8];
-          load8(Xr + (o + PADR) * V2_C + c0, y);
-          act8_grad_mask(y, m, cst + 3 * V2_C + c0, cst + 4 * V2_C + c0, a.actX, (uint32_t)gr, V2_C, c0);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            dA[i] *= m[i];
-            s1[i] += dA[i];
-            s2[i] += dA[i] * (y[i] - cst[5 * V2_C + c0 + i]) * cst[6 * V2_C + c0 + i];
-          }
-        }
-        store8(a.OUT + (size_t)gr * V2_C + c0, dA);
-      }
-    }
-  }
-  if (DW) {
-    // ---- per-channel reductions: across the 16 row-phases through LDS atomics, then once to HBM
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);    // [KD + 3][256]
-    for (int i = tid; i < (KD + 3) * V2_C; i += V2_NT) red[i] = 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-      for (int k = 0; k < KD; ++k) atomicAdd(&red[k * V2_C + c0 + i], gw[k][i]);
-      atomicAdd(&red[KD * V2_C + c0 + i], gb[i]);
-      atomicAdd(&red[(KD + 1) * V2_C + c0 + i], s1[i]);
-      atomicAdd(&red[(KD + 2) * V2_C + c0 + i], s2[i]);
-    }
-    __syncthreads();
-    const int rep = blockIdx.x % TN_NREP;
-    for (int i = tid; i < (KD + 3) * V2_C; i += V2_NT) {
-      const int k = i / V2_C, c = i % V2_C;
-      const float v = red[i];
-      if (k < KD) atomic_add_f32(&a.g_wdw[(size_t)c * KD + k], v);
-      else if (k == KD) atomic_add_f32(&a.g_bdw[c], v);
-      else if (a.bsumsX && has_mask) atomic_add_f32(&a.bsumsX[(size_t)(rep * 2 + (k - KD - 1)) * V2_C + c], v);
-    }
-  }
-}
-
-template <int KD, bool DW>
-inline int launch_sub_bwd_v2(SubBwdV2Args a, int resident_wgs, hipStream_t st) {
-  constexpr int OUTR = DW ? V2_R - (KD - 1) : V2_R;
-  constexpr int NC = 7 + (DW ? KD : 1);
-  a.ntiles = (a.M + OUTR - 1) / OUTR;
-  const int grid = a.ntiles < resident_wgs ? a.ntiles : resident_wgs;
-  const size_t smem = (size_t)(2 * V2_R * V2_AP + 2 * V2_R * V2_C) * sizeof(bf16_t) + (size_t)NC * V2_C * sizeof(float);
-  auto kern = sub_bwd_v2_kernel<KD, DW>;
-  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
-  return (int)hipGetLastError();
-}
-
-// ==========================================================================================
 // Depthwise backward, streaming version (no MFMA in this kernel, so no resident weight fragments:
 // the registers go to the per-channel constants, a 3-row sliding window and the accumulators).
 //   dA[r]  = sum_k w[c][k] dD[r - k + pad]  (+ ADD[r])

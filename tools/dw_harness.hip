@@ -1,4 +1,4 @@
-// standalone timing harness for dw_bwd_v3_kernel / sub_bwd_v2 (tuning only)
+// standalone timing harness for dw_bwd_v3_kernel / dw_bwd_v4_kernel (tuning only)
 #include "../titanet_amd/csrc/tn_v2_bwd_kernels.h"
 #include <string.h>
 #include <vector>
