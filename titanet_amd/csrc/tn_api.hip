@@ -175,6 +175,9 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     p->use_v2 = (precision == TN_PREC_BF16 && m->cfg.hidden == 256 && m->cfg.kernel == 3) ? mask : 0;
     // 32: keep the depthwise outputs for the batched weight gradients (needs 1 and 4)
     p->save_q = (p->use_v2 & 1) && (p->use_v2 & 4) && (p->use_v2 & 32);
+    // generic template path (fp32 parity plans, TitaNet-M / -L): same idea, the forward GEMM's depthwise producer stores its tile
+    const char* sq = getenv("TN_SAVEQ");
+    if (!p->use_v2 && !(sq && atoi(sq) == 0)) p->save_q = true;
     const char* pe = getenv("TN_PARTS");
     if (pe && atoi(pe) > 0) p->combine_parts = atoi(pe);
   }
@@ -465,7 +468,8 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
     for (int j = 0; j < c.n_sub_blocks; ++j) {
       const SubBlockRef& sb = mb.sub[j];
       GemmShape g{M, H, H, wsel<AT>(p, sb.wpw, bw.wpw[j])};
-      ProdDw::Args pa{cur, H, acur, params + sb.wdw, params + sb.bdw, c.kernel, T};
+      ProdDw::Args pa{cur, H, acur, params + sb.wdw, params + sb.bdw, c.kernel, T,
+                      (p->save_q && training) ? (void*)(ws + bw.Q[j]) : nullptr};
       EpiStoreArgs ea{ws + bw.Y[j], H, params + sb.bpw, statp(sb.bn)};
       int rc;
       {

@@ -273,9 +273,16 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       BnAct asin = j > 0 ? make_act(p, mb.sub[j - 1].bn, M, training, 1, pd, seed, i * (nsub + 1) + j - 1) : actx;
       ProdDy::Args pa{ws + bw.dY[j], ws + bw.Y[j], H, make_bnbwd(p, sb.bn, M, training)};
       if (!batched_wgrad) {
-        ProdDw::Args qa{sin, H, asin, params + sb.wdw, params + sb.bdw, c.kernel, T};
-        int rc = launch_wgrad<AT, ProdDy, ProdDw>(M, H, H, pa, qa, c.kernel, slabs, p->slab_bytes, grads + sb.wpw, st, p,
-                                                  TN_PROF_BWD_WGRAD);
+        int rc;
+        if (p->save_q && training) {
+          // the forward kept the depthwise output (the pointwise GEMM's operand): plain operand, no activation / stencil recompute
+          ProdPlain::Args qa{ws + bw.Q[j], H, identity_act()};
+          rc = launch_wgrad<AT, ProdDy, ProdPlain>(M, H, H, pa, qa, 0, slabs, p->slab_bytes, grads + sb.wpw, st, p, TN_PROF_BWD_WGRAD);
+        } else {
+          ProdDw::Args qa{sin, H, asin, params + sb.wdw, params + sb.bdw, c.kernel, T, nullptr};
+          rc = launch_wgrad<AT, ProdDy, ProdDw>(M, H, H, pa, qa, c.kernel, slabs, p->slab_bytes, grads + sb.wpw, st, p,
+                                                TN_PROF_BWD_WGRAD);
+        }
         if (rc) return rc;
       }
       if (v2_bwd) {

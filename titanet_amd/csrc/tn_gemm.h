@@ -168,6 +168,9 @@ struct ProdDw {
     const float* bdw;   // [C]
     int KD;
     int T;              // frames per utterance
+    void* Qout;         // [M][ldx] AT or null: the produced tile (the depthwise output) is also stored by the workgroups of
+                        // the first output-column block, so that the weight-gradient pass reads it instead of recomputing
+                        // activation + stencil (forward GEMM only; the wgrad producers pass null)
   };
   float* sc;
   float* sh;
@@ -237,6 +240,7 @@ struct ProdDw {
         }
       }
       store8_lds(As + r * BKP + vc * 8, o);
+      if (a.Qout && blockIdx.y == 0 && gr < g.M && k < g.K) store8(reinterpret_cast<AT*>(a.Qout) + (size_t)gr * a.ldx + k, o);
     }
   }
 };
