@@ -33,7 +33,8 @@ template <typename AT>
 int launch_dw_bwd(const DwBwdArgs& a, int KD, hipStream_t st) {
   DwBwdArgs args = a;
   const int row_tiles = (a.M + 63) / 64;
-  args.tiles_per_wg = std::max(1, std::min(8, row_tiles / 128));
+  // ~512 workgroups: each one pays a serial reduction epilogue, so more tiles per workgroup for wide models
+  args.tiles_per_wg = std::max(1, std::min(16, row_tiles * ((a.C + 63) / 64) / 512));
   dim3 grid((row_tiles + args.tiles_per_wg - 1) / args.tiles_per_wg, (a.C + 63) / 64);
   switch (KD) {
 #define TN_DW_CASE(K) \
