@@ -1,0 +1,63 @@
+"""Differential fuzz: the specialised bf16 kernels (TN_V2 default) vs the generic templates (TN_V2=0) on random shapes,
+dropout rates, heads and modes.  Both paths share the same counter-based dropout masks, so embeddings / loss / the whole
+gradient must agree to bf16 noise.  Usage: python tools/fuzz_paths.py [n_cases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from titanet_amd import LOSSES, TitaNet
+
+
+def run(mask, cfg):
+    if mask is None:
+        os.environ.pop("TN_V2", None)
+    else:
+        os.environ["TN_V2"] = mask
+    torch.manual_seed(cfg["wseed"])
+    if cfg["head"] == "ce":
+        lf = LOSSES["ce"](192, cfg["ncls"], device="cuda")
+    else:
+        lf = LOSSES["arc"](192, cfg["ncls"], device="cuda", scale=30, margin=0.2)
+    m = TitaNet.get_titanet(n_mega_blocks=cfg["blocks"], model_size="s", loss_function=lf, dropout=cfg["p"], device="cuda",
+                            precision="bf16", simple_pool=cfg["simple"])
+    m._seed_base, m._step = 777, 0
+    g = torch.Generator().manual_seed(cfg["xseed"])
+    x = (torch.randn(cfg["B"], 80, cfg["T"], generator=g) * 0.11 - 0.1).cuda()
+    y = torch.randint(0, cfg["ncls"], (cfg["B"],), generator=g).cuda()
+    if cfg["train"]:
+        m.train()
+        emb, preds, loss = m(x, speakers=y)
+        loss.backward()
+        grad = torch.cat([p.grad.flatten() for p in m.parameters()]).float().cpu()
+        return emb.detach().float().cpu(), float(loss), grad
+    m.eval()
+    with torch.no_grad():
+        emb = m(x)
+    return emb.float().cpu(), 0.0, None
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    worst = 0.0
+    for i in range(n):
+        cfg = dict(B=int(rng.integers(3, 40)), T=int(rng.choice([33, 64, 65, 100, 151, 201, 300, 301, 417])),
+                   p=float(rng.choice([0.0, 0.1, 0.3])), head=str(rng.choice(["ce", "arc"])), blocks=int(rng.integers(1, 4)),
+                   ncls=int(rng.integers(5, 60)), simple=bool(rng.random() < 0.2), train=bool(rng.random() < 0.8),
+                   wseed=int(rng.integers(1 << 30)), xseed=int(rng.integers(1 << 30)))
+        e0, l0, g0 = run("0", cfg)
+        e1, l1, g1 = run(None, cfg)
+        er = float((e1 - e0).norm() / e0.norm())
+        msg = f"{i:3d} {cfg}  emb rel {er:.2e}"
+        ok = er < 5e-2
+        if cfg["train"]:
+            cos = float((g0 @ g1) / (g0.norm() * g1.norm()))
+            msg += f"  dloss {abs(l1 - l0):.2e}  grad cos {cos:.4f}"
+            ok = ok and abs(l1 - l0) < 5e-2 * max(1.0, abs(l0)) and cos > (0.97 if cfg["B"] * cfg["T"] >= 1500 else 0.9)
+        worst = max(worst, er)
+        print(("ok  " if ok else "FAIL") + msg, flush=True)
+    print("worst emb rel", worst)
+
+
+if __name__ == "__main__":
+    main()
