@@ -254,6 +254,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   p->dEbn = b.take(M * D * e);
   p->dHP = b.take(M * A * e);
   p->dpooled = b.take((size_t)batch * 2 * D * 4);
+  p->wepi_swz = b.take(D * H * 2);
   p->mu = b.take((size_t)batch * D * 4);
   p->dmu = b.take((size_t)batch * D * 4);
   p->dlin = b.take((size_t)batch * c.emb * 4);

@@ -200,9 +200,18 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         if (rc) return rc;
       }
     }
-    GemmShape g{M, H, D, wt(p->wepi)};
-    EpiStoreArgs ea{ws + p->dA[cur], H, nullptr, nullptr};
-    int rc = gemm_any<AT, ProdDy, EpiStore>(g, pa, ea, st);
+    int rc;
+    if (sizeof(AT) == 2 && (p->use_v2 & 16) && H == 256 && D % 256 == 0) {
+      DgradWideArgs da;
+      memset(&da, 0, sizeof(da));
+      da.dZ = (const bf16_t*)(ws + p->dEbn); da.Y = (const bf16_t*)(ws + p->E); da.bn = pa.bn;
+      da.Wt = (const bf16_t*)wt(p->wepi); da.Wswz = (const uint4*)(ws + p->wepi_swz); da.OUT = (bf16_t*)(ws + p->dA[cur]); da.M = M; da.KW = D;
+      rc = launch_dgrad_wide_v2(da, 256, st);
+    } else {
+      GemmShape g{M, H, D, wt(p->wepi)};
+      EpiStoreArgs ea{ws + p->dA[cur], H, nullptr, nullptr};
+      rc = gemm_any<AT, ProdDy, EpiStore>(g, pa, ea, st);
+    }
     if (rc) return rc;
   }
   // ================= mega blocks, last to first =================

@@ -111,6 +111,7 @@ struct tn_plan {
   size_t dEbn;         // rows x enc_out AT
   size_t dHP;          // rows x attn AT
   size_t dpooled, dlin, demb;   // float
+  size_t wepi_swz;              // epilog weight in MFMA-fragment order (dgrad_wide_v2)
   size_t mu, dmu;               // float [B][D]: mean over time of the encoder output and its gradient (simple_pool)
   size_t slabs;        // split-K partial weight gradients
   size_t slab_bytes = 0;

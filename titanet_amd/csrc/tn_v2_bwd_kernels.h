@@ -1051,3 +1051,124 @@ inline int launch_dgrad_v2(DgradV2Args a, int max_wgs, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
   return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------
+// dgrad_wide_v2: data gradient of a 1x1 conv whose OUTPUT side is the 1536-wide tensor (the epilog conv):
+//   dX[M][256] = BatchNorm-backward-on-load(dZ, Y)[M][KW] * W^T        (K = KW = 1536 = 6 slabs of 256)
+// dgrad_v2's skeleton with a slab loop inside every 64-row tile: the accumulators live across the slabs, the
+// 256 x 256 weight slab of the NEXT step is prefetched into registers beside the current one (they stream from L2),
+// the BN-backward coefficients of all KW channels sit in LDS.  dZ / Y rows are read exactly once.
+// ------------------------------------------------------------------------------------------
+struct DgradWideArgs {
+  const bf16_t* dZ; const bf16_t* Y; BnBwd bn;     // [M][KW]
+  const bf16_t* Wt;      // [256][KW] bf16: row = input channel of the conv (output of this product), K contiguous
+  const uint4* Wswz;     // the same weights in MFMA-fragment order [KW/256 slabs][8 waves][16 k-steps][64 lanes] x 16 bytes
+  bf16_t* OUT;           // [M][256]
+  int M, KW, ntiles;
+};
+__global__ void dgrad_wide_swizzle_kernel(const bf16_t* __restrict__ Wt, int KW, uint4* __restrict__ out) {
+  const int n = (KW / V2_C) * 8 * 16 * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int lane = i & 63, ks = (i >> 6) & 15, wave = (i >> 10) & 7, slab = i >> 13;
+    out[i] = *reinterpret_cast<const uint4*>(Wt + (size_t)(wave * 32 + (lane & 31)) * KW + slab * V2_C + ks * 16 + (lane >> 5) * 8);
+  }
+}
+__global__ __launch_bounds__(V2_NT, 2) void dgrad_wide_v2_kernel(DgradWideArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* Pt = reinterpret_cast<bf16_t*>(smem);      // [64][264] dY slab rows (MFMA B operand)
+  bf16_t* Dt = Pt + V2_R * V2_AP;                     // [64][264] output staging
+  float* cst = reinterpret_cast<float*>(Dt + V2_R * V2_AP);   // k0, k1, k2 : [3][KW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int vc = tid & 31, rq = tid >> 5, c0 = vc * 8;
+  const int ns = a.KW / V2_C;
+  for (int c = tid; c < a.KW; c += V2_NT) {
+    float k0, k1, k2;
+    bn_bwd_coefs(a.bn, a.KW, c, k0, k1, k2);
+    cst[c] = k0; cst[a.KW + c] = k1; cst[2 * a.KW + c] = k2;
+  }
+  const int first = blockIdx.x, stride = gridDim.x;
+  if (first >= a.ntiles) return;
+  const int nsteps = ((a.ntiles - first + stride - 1) / stride) * ns;     // (tile, slab) steps of this workgroup
+  bf16x8_t wf[16], wfn[16];
+  uint4 pz[4], py[4];
+  auto fetch = [&](int step) {            // weights of the step's slab + dZ / Y rows of its (tile, slab)
+    if (step >= nsteps) return;
+    const int tile = first + (step / ns) * stride, slab = step % ns;
+    // fragment-ordered weights (dgrad_wide_swizzle_kernel): one fully coalesced 1 KB read per wave and k-step.  Reading the
+    // fragments straight from the [256][KW] matrix touches 32 rows x 32 B per instruction and thrashes L1 (4x the L2 traffic).
+    const uint4* wsrc = a.Wswz + ((size_t)(slab * 8 + wave) * 16) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) wfn[ks] = __builtin_bit_cast(bf16x8_t, wsrc[ks * 64]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int gr = tile * V2_R + rq + 16 * q;
+      const bool ok = gr < a.M;
+      const size_t o = (size_t)gr * a.KW + slab * V2_C + c0;
+      pz[q] = ok ? *reinterpret_cast<const uint4*>(a.dZ + o) : make_uint4(0, 0, 0, 0);
+      py[q] = ok ? *reinterpret_cast<const uint4*>(a.Y + o) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  fetch(0);
+  __syncthreads();                        // constants visible
+  f32x16_t acc0, acc1;
+  for (int step = 0; step < nsteps; ++step) {
+    const int tile = first + (step / ns) * stride, slab = step % ns;
+    const int out0 = tile * V2_R;
+    __syncthreads();                      // previous step's MFMA is done with Pt (and the previous tile's Dt rows are stored)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = rq + 16 * q;
+      float z[8], y[8];
+      unpack8(pz[q], z);
+      unpack8(py[q], y);
+      if (out0 + r < a.M) {
+        const float* kk = cst + slab * V2_C + c0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) z[i] = kk[i] * z[i] + kk[a.KW + i] * y[i] + kk[2 * a.KW + i];
+      }
+      store8(Pt + r * V2_AP + c0, z);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) wf[ks] = wfn[ks];
+    fetch(step + 1);
+    __syncthreads();
+    if (slab == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    }
+    const bf16_t* brow = Pt + (lane & 31) * V2_AP + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(brow + ks * 16);
+      const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(brow + 32 * V2_AP + ks * 16);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b1, acc1, 0, 0, 0);
+    }
+    if (slab == ns - 1) {                 // workgroup-uniform
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ci = wave * 32 + 8 * g + 4 * half;
+        uint2 w0, w1;
+        w0.x = f2bf_pk(acc0[4 * g], acc0[4 * g + 1]); w0.y = f2bf_pk(acc0[4 * g + 2], acc0[4 * g + 3]);
+        w1.x = f2bf_pk(acc1[4 * g], acc1[4 * g + 1]); w1.y = f2bf_pk(acc1[4 * g + 2], acc1[4 * g + 3]);
+        *reinterpret_cast<uint2*>(Dt + (lane & 31) * V2_AP + ci) = w0;
+        *reinterpret_cast<uint2*>(Dt + (32 + (lane & 31)) * V2_AP + ci) = w1;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int o = rq + 16 * q, gr = out0 + o;
+        if (gr < a.M) *reinterpret_cast<uint4*>(a.OUT + (size_t)gr * V2_C + c0) = *reinterpret_cast<const uint4*>(Dt + o * V2_AP + c0);
+      }
+    }
+  }
+}
+inline int launch_dgrad_wide_v2(DgradWideArgs a, int max_wgs, hipStream_t st) {
+  a.ntiles = (a.M + V2_R - 1) / V2_R;
+  const int grid = a.ntiles < max_wgs ? a.ntiles : max_wgs;
+  const size_t smem = (size_t)2 * V2_R * V2_AP * sizeof(bf16_t) + (size_t)3 * a.KW * sizeof(float);
+  hipLaunchKernelGGL(dgrad_wide_swizzle_kernel, dim3(192), dim3(256), 0, st, a.Wt, a.KW, const_cast<uint4*>(a.Wswz));
+  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(dgrad_wide_v2_kernel, dim3(grid), dim3(V2_NT), smem, st, a);
+  return (int)hipGetLastError();
+}

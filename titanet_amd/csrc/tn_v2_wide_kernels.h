@@ -407,3 +407,4 @@ inline int launch_wide_in_v2(WideInArgs a, int max_wgs, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
   return (int)hipGetLastError();
 }
+
