@@ -204,7 +204,11 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   // ---- device-resident step state {uint64 step; uint32 word; ...}: cleared once at bind, advanced by tn_plan_step_tick
   p->step_state = b.take(64);
   // ---- compute-precision weights
-  auto wc = [&](size_t n, size_t k) { WcRef r; r.w = b.take(n * k * e); r.wt = b.take(n * k * e); return r; };
+  auto wc = [&](size_t n, size_t k) {
+    WcRef r; r.w = b.take(n * k * e); r.wt = b.take(n * k * e);
+    if (p->use_v2 && n == 256 && k == 256) { r.sw = b.take(n * k * e); r.swt = b.take(n * k * e); }
+    return r;
+  };
   p->wprolog = wc(H, (size_t)c.n_mels * c.prolog_kernel);
   p->wepi = wc(D, H);
   p->wwin = wc(A, D);
@@ -281,6 +285,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     p->dw_table = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * 32);
   }
   p->cast_table = b.take(sizeof(CastDesc) * (8 + (size_t)c.n_mega_blocks * (c.n_sub_blocks + 1)));
+  p->swz_table = b.take(sizeof(SwzDesc) * 2 * (size_t)c.n_mega_blocks * (c.n_sub_blocks + 1) + 16);
   p->bn_table = b.take(sizeof(BnUpdateDesc) * m->n_bn);
   p->stats_ptr_table = b.take(sizeof(float*) * m->n_bn);
   p->bwd_table_bytes = (size_t)m->n_bn * 128;   // >= sizeof(BnGradDesc) each (checked at upload)
@@ -350,6 +355,20 @@ extern "C" int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbu
   for (int i = 0; i < c.n_mega_blocks; ++i) {
     for (int j = 0; j < c.n_sub_blocks; ++j) add(m->blocks[i].sub[j].wpw, p->blk[i].wpw[j], c.hidden, c.hidden, true);
     add(m->blocks[i].wskip, p->blk[i].wskip, c.hidden, c.hidden, true);
+  }
+  {
+    std::vector<SwzDesc> sd;
+    auto adds = [&](const WcRef& r) {
+      if (!r.sw) return;
+      sd.push_back(SwzDesc{(const bf16_t*)(p->ws + r.w), (uint4*)(p->ws + r.sw)});
+      sd.push_back(SwzDesc{(const bf16_t*)(p->ws + r.wt), (uint4*)(p->ws + r.swt)});
+    };
+    for (int i = 0; i < c.n_mega_blocks; ++i) {
+      for (int j = 0; j < c.n_sub_blocks; ++j) adds(p->blk[i].wpw[j]);
+      adds(p->blk[i].wskip);
+    }
+    p->n_swz = (int)sd.size();
+    if (p->n_swz) TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->swz_table, sd.data(), sd.size() * sizeof(SwzDesc), hipMemcpyHostToDevice, st));
   }
   p->n_cast = (int)cd.size();
   TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->cast_table, cd.data(), cd.size() * sizeof(CastDesc), hipMemcpyHostToDevice, st));
@@ -430,6 +449,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   TN_CHECK_HIP(hipMemsetAsync(ws + p->zero_begin, 0, p->zero_bytes, st));
   if (p->n_cast > 0) {
     hipLaunchKernelGGL(cast_params_kernel<AT>, dim3(64, p->n_cast), dim3(256), 0, st, (const CastDesc*)(ws + p->cast_table));
+    if (p->n_swz) hipLaunchKernelGGL(swizzle256_kernel<0>, dim3(8, p->n_swz), dim3(256), 0, st, (const SwzDesc*)(ws + p->swz_table));
   }
   if (!training) {
     // eval: BatchNorm uses the running statistics -> write the equivalent sums once for all layers
@@ -454,7 +474,8 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       int rc;
       if (p->use_v2 & 2) {
         SubFwdV2Args va{(const bf16_t*)xin, actx, nullptr, nullptr, (const bf16_t*)(ws + bw.wskip.w), params + mb.bskip,
-                        (bf16_t*)(ws + bw.S), statp(mb.bnskip), M, T, 0};
+                        (bf16_t*)(ws + bw.S), statp(mb.bnskip), M, T, 0,
+                        bw.wskip.sw ? (const uint4*)(ws + bw.wskip.sw) : nullptr, nullptr};
         rc = launch_sub_fwd_v4<1, false>(va, 256, st);
       } else {
         GemmShape g{M, H, H, wsel<AT>(p, mb.wskip, bw.wskip)};
@@ -478,6 +499,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
         if (p->use_v2 & 1) {
           SubFwdV2Args va{(const bf16_t*)cur, acur, params + sb.wdw, params + sb.bdw, (const bf16_t*)(ws + bw.wpw[j].w),
                           params + sb.bpw, (bf16_t*)(ws + bw.Y[j]), statp(sb.bn), M, T, 0,
+                          bw.wpw[j].sw ? (const uint4*)(ws + bw.wpw[j].sw) : nullptr,
                           (p->save_q && training) ? (bf16_t*)(ws + bw.Q[j]) : nullptr};
           rc = launch_sub_fwd_v5<3, true>(va, 256, st);
         } else {

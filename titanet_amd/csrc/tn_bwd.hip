@@ -268,6 +268,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         memset(&va, 0, sizeof(va));
         va.dZ = (const bf16_t*)(ws + bw.dZk); va.Y = (const bf16_t*)(ws + bw.S); va.bn = pa.bn;
         va.Wt = (const bf16_t*)(ws + bw.wskip.wt); va.OUT = (bf16_t*)(ws + p->dXs); va.M = M;
+        va.Wswz = bw.wskip.swt ? (const uint4*)(ws + bw.wskip.swt) : nullptr;
         rc = launch_dgrad_v2<64>(va, 256, st);
       } else {
         GemmShape g{M, H, H, wt(bw.wskip)};
@@ -301,6 +302,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         memset(&va, 0, sizeof(va));
         va.dZ = (const bf16_t*)(ws + bw.dY[j]); va.Y = (const bf16_t*)(ws + bw.Y[j]); va.bn = pa.bn;
         va.Wt = (const bf16_t*)(ws + bw.wpw[j].wt); va.OUT = (bf16_t*)(ws + p->dD); va.M = M;
+        va.Wswz = bw.wpw[j].swt ? (const uint4*)(ws + bw.wpw[j].swt) : nullptr;
         int rc;
         {
           ProfScope ps(p, TN_PROF_BWD_DGRAD, st);

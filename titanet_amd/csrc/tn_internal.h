@@ -57,6 +57,8 @@ struct tn_model {
 struct WcRef {
   size_t w = 0;    // [N][K]
   size_t wt = 0;   // [K][N]
+  size_t sw = 0;   // 256 x 256 bf16 only: w in MFMA-fragment order [8 row blocks][16 k-steps][64 lanes] x 16 bytes, or 0
+  size_t swt = 0;  // ... and wt in that order
 };
 
 struct BlockWs {
@@ -111,6 +113,7 @@ struct tn_plan {
   size_t dEbn;         // rows x enc_out AT
   size_t dHP;          // rows x attn AT
   size_t dpooled, dlin, demb;   // float
+  size_t swz_table = 0; int n_swz = 0;   // (src, dst) pairs of the fragment-order copies, refreshed after every parameter cast
   size_t wepi_swz;              // epilog weight in MFMA-fragment order (dgrad_wide_v2)
   size_t mu, dmu;               // float [B][D]: mean over time of the encoder output and its gradient (simple_pool)
   size_t slabs;        // split-K partial weight gradients

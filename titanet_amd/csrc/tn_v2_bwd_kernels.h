@@ -951,6 +951,7 @@ struct DgradV2Args {
   const bf16_t* Wt;    // [256 in-channels][256 out-channels]
   bf16_t* OUT;         // [M][256]
   int M, ntiles;
+  const uint4* Wswz;   // optional: Wt in MFMA-fragment order [8 waves][16 k-steps][64 lanes] x 16 bytes
 };
 
 template <int R>
@@ -972,7 +973,10 @@ __global__ __launch_bounds__(V2_NT, (R == 32 ? 4 : 2)) void dgrad_v2_kernel(Dgra
   {
     const int ci = wave * 32 + (lane & 31);
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) wf[ks] = *reinterpret_cast<const bf16x8_t*>(a.Wt + (size_t)ci * V2_C + ks * 16 + half * 8);
+    for (int ks = 0; ks < 16; ++ks) {
+      if (a.Wswz) wf[ks] = __builtin_bit_cast(bf16x8_t, a.Wswz[((size_t)wave * 16 + ks) * 64 + lane]);   // fragment order: coalesced
+      else wf[ks] = *reinterpret_cast<const bf16x8_t*>(a.Wt + (size_t)ci * V2_C + ks * 16 + half * 8);
+    }
   }
   uint4 pz[NQ], py[NQ];
   auto prefetch = [&](int tile) {

@@ -66,6 +66,8 @@ struct SubFwdV2Args {
   bf16_t* Y;            // [M][256]
   float* stats;         // [TN_NREP][2][256] or null
   int M, T, ntiles;
+  const uint4* Wswz;    // optional: W in MFMA-fragment order (swizzle256_kernel): the resident weight fragments then load with
+                        // fully coalesced 1 KB reads instead of 32 rows x 32 B per instruction
   bf16_t* Q;            // [M][256] or null: the depthwise output (the pointwise GEMM's operand) is ALSO stored, so that the
                         // batched weight-gradient launch reads it instead of recomputing activation + stencil (sub_fwd_v5 only)
 };
@@ -340,7 +342,8 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v4_kernel(SubFwdV2Args a) {
     const int co = wave * 32 + (lane & 31);
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
-      wf[ks] = *reinterpret_cast<const bf16x8_t*>(a.W + (size_t)co * V2_C + ks * 16 + half * 8);
+      wf[ks] = a.Wswz ? __builtin_bit_cast(bf16x8_t, a.Wswz[((size_t)wave * 16 + ks) * 64 + lane])
+                      : *reinterpret_cast<const bf16x8_t*>(a.W + (size_t)co * V2_C + ks * 16 + half * 8);
   }
   float biasr[16];   // bias of this lane's 16 output channels: 32*wave + 8g + 4*half + j
 #pragma unroll
@@ -881,7 +884,8 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
       const int co = cw * 64 + cbk * 32 + (lane & 31);
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks)
-        wf[cbk][ks] = *reinterpret_cast<const bf16x8_t*>(a.W + (size_t)co * V2_C + ks * 16 + half * 8);
+        wf[cbk][ks] = a.Wswz ? __builtin_bit_cast(bf16x8_t, a.Wswz[((size_t)(cw * 2 + cbk) * 16 + ks) * 64 + lane])
+                             : *reinterpret_cast<const bf16x8_t*>(a.W + (size_t)co * V2_C + ks * 16 + half * 8);
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -981,5 +985,18 @@ inline int launch_sub_fwd_v5(SubFwdV2Args a, int resident_wgs, hipStream_t st) {
     case 3: return launch_sub_fwd_v5_t<KD, DW, 3>(a, grid, smem, st);
     case 7: return launch_sub_fwd_v5_t<KD, DW, 7>(a, grid, smem, st);
     default: return launch_sub_fwd_v2<KD, DW>(a, resident_wgs, st);
+  }
+}
+
+
+// fragment-order copies of 256 x 256 bf16 weights (one launch for all of them, after every parameter cast):
+// dst[((rb * 16 + ks) * 64 + lane)] = 16 bytes of row rb*32 + (lane & 31), columns ks*16 + (lane >> 5)*8 .. +8
+struct SwzDesc { const bf16_t* src; uint4* dst; };
+template <int DUMMY>
+__global__ void swizzle256_kernel(const SwzDesc* __restrict__ tab) {
+  const SwzDesc d = tab[blockIdx.y];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 8 * 16 * 64; i += gridDim.x * blockDim.x) {
+    const int lane = i & 63, ks = (i >> 6) & 15, rb = i >> 10;
+    d.dst[i] = *reinterpret_cast<const uint4*>(d.src + (size_t)(rb * 32 + (lane & 31)) * V2_C + ks * 16 + (lane >> 5) * 8);
   }
 }

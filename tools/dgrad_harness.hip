@@ -26,5 +26,11 @@ int main(int argc, char** argv) {
   a.dZ = dZ; a.Y = Y; a.Wt = W; a.OUT = OUT; a.M = M; a.bn.fstats = stats; a.bn.bsums = bs; a.bn.gamma = gamma; a.bn.inv_n = 1.f / M; a.bn.eps = 1e-5f; a.bn.batch = 1.f;
   for (int g : {256, 512, 768, 1024}) printf("dgrad_v2<32> grid=%4d: %.2f us\n", g, run<32>(a, g));
   for (int g : {256, 512}) printf("dgrad_v2<64> grid=%4d: %.2f us\n", g, run<64>(a, g));
+  uint4* swz; CK(hipMalloc(&swz, C * C * 2));
+  hipLaunchKernelGGL(dgrad_wide_swizzle_kernel, dim3(32), dim3(256), 0, 0, W, C, swz);
+  a.Wswz = swz;
+  for (int g : {256}) printf("dgrad_v2<64> fragment-ordered weights grid=%4d: %.2f us\n", g, run<64>(a, g));
+  a.Wswz = nullptr;
+  for (int g : {256}) printf("dgrad_v2<64> row-major weights grid=%4d: %.2f us\n", g, run<64>(a, g));
   return 0;
 }
