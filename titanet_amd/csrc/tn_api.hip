@@ -206,7 +206,9 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   // ---- compute-precision weights
   auto wc = [&](size_t n, size_t k) {
     WcRef r; r.w = b.take(n * k * e); r.wt = b.take(n * k * e);
-    if (p->use_v2 && n == 256 && k == 256) { r.sw = b.take(n * k * e); r.swt = b.take(n * k * e); }
+    if (p->use_v2 && ((n == 256 && k == 256) || (n % 256 == 0 && (k == 256 || k == 128)) || (k % 256 == 0 && n == 128))) {
+      r.sw = b.take(n * k * e); r.swt = b.take(n * k * e);
+    }
     return r;
   };
   p->wprolog = wc(H, (size_t)c.n_mels * c.prolog_kernel);
@@ -285,7 +287,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     p->dw_table = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * 32);
   }
   p->cast_table = b.take(sizeof(CastDesc) * (8 + (size_t)c.n_mega_blocks * (c.n_sub_blocks + 1)));
-  p->swz_table = b.take(sizeof(SwzDesc) * 2 * (size_t)c.n_mega_blocks * (c.n_sub_blocks + 1) + 16);
+  p->swz_table = b.take(sizeof(SwzDesc) * (2 * (size_t)c.n_mega_blocks * (c.n_sub_blocks + 1) + 8));
   p->bn_table = b.take(sizeof(BnUpdateDesc) * m->n_bn);
   p->stats_ptr_table = b.take(sizeof(float*) * m->n_bn);
   p->bwd_table_bytes = (size_t)m->n_bn * 128;   // >= sizeof(BnGradDesc) each (checked at upload)
@@ -360,9 +362,15 @@ extern "C" int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbu
     std::vector<SwzDesc> sd;
     auto adds = [&](const WcRef& r) {
       if (!r.sw) return;
-      sd.push_back(SwzDesc{(const bf16_t*)(p->ws + r.w), (uint4*)(p->ws + r.sw)});
-      sd.push_back(SwzDesc{(const bf16_t*)(p->ws + r.wt), (uint4*)(p->ws + r.swt)});
+      sd.push_back(SwzDesc{(const bf16_t*)(p->ws + r.w), (uint4*)(p->ws + r.sw), 256, 256});
+      sd.push_back(SwzDesc{(const bf16_t*)(p->ws + r.wt), (uint4*)(p->ws + r.swt), 256, 256});
     };
+    // the wide kernels' weights: epilog conv [D][H], ASP energies [D][A], and W_in^T [D][A] for the backward
+    if (p->use_v2 && !c.simple_pool && c.hidden == 256 && c.enc_out % 256 == 0 && c.attn_hidden == 128) {
+      if (p->wepi.sw) sd.push_back(SwzDesc{(const bf16_t*)(p->ws + p->wepi.w), (uint4*)(p->ws + p->wepi.sw), c.enc_out, c.hidden});
+      if (p->wwout.sw) sd.push_back(SwzDesc{(const bf16_t*)(p->ws + p->wwout.w), (uint4*)(p->ws + p->wwout.sw), c.enc_out, c.attn_hidden});
+      if (p->wwin.swt) sd.push_back(SwzDesc{(const bf16_t*)(p->ws + p->wwin.wt), (uint4*)(p->ws + p->wwin.swt), c.enc_out, c.attn_hidden});
+    }
     for (int i = 0; i < c.n_mega_blocks; ++i) {
       for (int j = 0; j < c.n_sub_blocks; ++j) adds(p->blk[i].wpw[j]);
       adds(p->blk[i].wskip);
@@ -449,7 +457,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   TN_CHECK_HIP(hipMemsetAsync(ws + p->zero_begin, 0, p->zero_bytes, st));
   if (p->n_cast > 0) {
     hipLaunchKernelGGL(cast_params_kernel<AT>, dim3(64, p->n_cast), dim3(256), 0, st, (const CastDesc*)(ws + p->cast_table));
-    if (p->n_swz) hipLaunchKernelGGL(swizzle256_kernel<0>, dim3(8, p->n_swz), dim3(256), 0, st, (const SwzDesc*)(ws + p->swz_table));
+    if (p->n_swz) hipLaunchKernelGGL(swizzle256_kernel<0>, dim3(16, p->n_swz), dim3(256), 0, st, (const SwzDesc*)(ws + p->swz_table));
   }
   if (!training) {
     // eval: BatchNorm uses the running statistics -> write the equivalent sums once for all layers
@@ -562,6 +570,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       WideOutArgs wa;
       memset(&wa, 0, sizeof(wa));
       wa.X = (const bf16_t*)xin; wa.W = (const bf16_t*)wsel<AT>(p, m->epi_w, p->wepi); wa.bias = params + m->epi_b;
+      wa.Wswz = p->wepi.sw ? (const uint4*)(ws + p->wepi.sw) : nullptr;
       wa.Y = (bf16_t*)(ws + p->E); wa.stats = statp(m->epi_bn); wa.M = M; wa.N = D;
       int rc = launch_wide_out_v2<256, 0>(wa, 256, st);
       if (rc) return rc;
@@ -604,6 +613,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       WideOutArgs wa;
       memset(&wa, 0, sizeof(wa));
       wa.X = (const bf16_t*)(ws + p->HID); wa.W = (const bf16_t*)wsel<AT>(p, m->asp_wout, p->wwout); wa.bias = params + m->asp_bout;
+      wa.Wswz = p->wwout.sw ? (const uint4*)(ws + p->wwout.sw) : nullptr;
       wa.Y = (bf16_t*)(ws + p->EN); wa.M = M; wa.N = D;
       rc = launch_wide_out_v2<128, 0>(wa, 256, st);
     } else {

@@ -174,6 +174,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         WideOutArgs wa;
         memset(&wa, 0, sizeof(wa));
         wa.X = (const bf16_t*)(ws + p->dHP); wa.W = (const bf16_t*)wt(p->wwin); wa.Y = (bf16_t*)(ws + p->dEbn);
+        wa.Wswz = p->wwin.swt ? (const uint4*)(ws + p->wwin.swt) : nullptr;
         wa.RAW = (const bf16_t*)(ws + p->E); wa.actR = acte; wa.bsums = bsum(m->epi_bn); wa.M = M; wa.N = D;
         rc = launch_wide_out_v2<128, 2>(wa, 256, st);
       } else {

@@ -989,14 +989,16 @@ inline int launch_sub_fwd_v5(SubFwdV2Args a, int resident_wgs, hipStream_t st) {
 }
 
 
-// fragment-order copies of 256 x 256 bf16 weights (one launch for all of them, after every parameter cast):
-// dst[((rb * 16 + ks) * 64 + lane)] = 16 bytes of row rb*32 + (lane & 31), columns ks*16 + (lane >> 5)*8 .. +8
-struct SwzDesc { const bf16_t* src; uint4* dst; };
+// fragment-order copies of bf16 weight matrices [N][K] (N a multiple of 32, K of 16): one launch for all of them, after
+// every parameter cast.  dst[((rb * K/16 + ks) * 64 + lane)] = 16 bytes of row rb*32 + (lane & 31), columns
+// ks*16 + (lane >> 5)*8 .. +8  — i.e. exactly what lane `lane` of the wave owning row block rb feeds to MFMA k-step ks.
+struct SwzDesc { const bf16_t* src; uint4* dst; int N, K; };
 template <int DUMMY>
 __global__ void swizzle256_kernel(const SwzDesc* __restrict__ tab) {
   const SwzDesc d = tab[blockIdx.y];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 8 * 16 * 64; i += gridDim.x * blockDim.x) {
-    const int lane = i & 63, ks = (i >> 6) & 15, rb = i >> 10;
-    d.dst[i] = *reinterpret_cast<const uint4*>(d.src + (size_t)(rb * 32 + (lane & 31)) * V2_C + ks * 16 + (lane >> 5) * 8);
+  const int KS = d.K / 16, total = d.N * d.K / 8;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int lane = i & 63, q = i >> 6, ks = q % KS, rb = q / KS;
+    d.dst[i] = *reinterpret_cast<const uint4*>(d.src + (size_t)(rb * 32 + (lane & 31)) * d.K + ks * 16 + (lane >> 5) * 8);
   }
 }

@@ -15,6 +15,7 @@
 struct WideOutArgs {
   const bf16_t* X;      // [M][K] A operand (stored final: no activation on load)
   const bf16_t* W;      // [N][K] bf16, row = output channel
+  const uint4* Wswz;    // optional: W in MFMA-fragment order (swizzle256_kernel)
   const float* bias;    // [N] or null
   bf16_t* Y;            // [M][N]
   float* stats;         // EPI 0: [TN_NREP][2][N] sum / sum of squares of Y, or null
@@ -48,7 +49,9 @@ __global__ __launch_bounds__(V2_NT, 2) void wide_out_v2_kernel(WideOutArgs a) {
   auto fetch_w = [&](int slab) {
     const int co = slab * V2_C + wave * 32 + (lane & 31);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wfn[ks] = *reinterpret_cast<const bf16x8_t*>(a.W + (size_t)co * K + ks * 16 + half * 8);
+    for (int ks = 0; ks < KS; ++ks)
+      wfn[ks] = a.Wswz ? __builtin_bit_cast(bf16x8_t, a.Wswz[((size_t)(slab * 8 + wave) * KS + ks) * 64 + lane])
+                       : *reinterpret_cast<const bf16x8_t*>(a.W + (size_t)co * K + ks * 16 + half * 8);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
