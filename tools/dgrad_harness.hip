@@ -30,6 +30,7 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(dgrad_wide_swizzle_kernel, dim3(32), dim3(256), 0, 0, W, C, swz);
   a.Wswz = swz;
   for (int g : {256}) printf("dgrad_v2<64> fragment-ordered weights grid=%4d: %.2f us\n", g, run<64>(a, g));
+  for (int g : {256, 512, 768}) printf("dgrad_v2<32> fragment-ordered weights grid=%4d: %.2f us\n", g, run<32>(a, g));
   a.Wswz = nullptr;
   for (int g : {256}) printf("dgrad_v2<64> row-major weights grid=%4d: %.2f us\n", g, run<64>(a, g));
   return 0;
