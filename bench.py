@@ -29,7 +29,7 @@ ALG_BYTES_PER_UTT_BF16 = 70.66e6   # 7,065,600 elements x 5 pa
 
 PROF_CLASSES = {1: "fwd_subblock_gemm", 2: "bwd_pointwise_wgrad", 3: "bwd_pointwise_dgrad", 4: "bwd_depthwise"}
 # kernel behind each class on the headline shape (for the PMC traffic lookup)
-PROF_KERNELS = {1: "sub_fwd_v5_kernel<3, true, 7>", 2: "wgrad_batched_v2_kernel<3>", 3: "dgrad_v2_kernel<64>",
+PROF_KERNELS = {1: "sub_fwd_v5_kernel<3, true, 7>", 2: "wgrad_batched_v2_kernel<3, false>", 3: "dgrad_v2_kernel<64>",
                 4: "dw_bwd_v4_kernel<3, 7>"}
 
 

@@ -133,6 +133,28 @@ int tn_plan_step_tick(tn_plan* p, void* stream);
 int tn_plan_step_set(tn_plan* p, int64_t step, void* stream);   /* step 0 = word 0 (the ungraphed convention) */
 int tn_adam_step_plan(tn_plan* p, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                       float beta1, float beta2, float eps, float weight_decay, float grad_mult, void* stream);
+/* Schedulable learning rate for a captured step (reference src/learn.py:257-258 steps a CosineAnnealingLR): lr < 0 in
+ * tn_adam_step_plan means "read the plan's device lr word", which tn_plan_set_lr writes (a one-thread kernel enqueued
+ * OUTSIDE the captured graph, before each replay). */
+int tn_plan_set_lr(tn_plan* p, float lr, void* stream);
+
+/* ---- stand-alone loss heads: MetricLearningLoss.forward(inputs, targets) -> (normalised inputs, preds, loss)
+ * (reference src/losses.py:32-44 CELoss, :77-132 AngularMarginLoss) for callers that use a loss object outside
+ * TitaNet.forward.  loss_type: TN_LOSS_CE (fc_bias required) or TN_LOSS_MARGIN (fc_weight is row-normalised IN PLACE, as
+ * the reference does on .data, src/losses.py:86).  inputs: float32 [batch][emb]; targets int64 [batch];
+ * normalized: float32 [batch][emb]; preds int64 [batch]; loss float32 scalar (device).  save: tn_head_save_floats()
+ * floats of scratch that tn_head_backward reads (d logits, d scale, embeddings).  An out-of-range target poisons the
+ * loss with NaN (F.cross_entropy would raise; a kernel cannot). */
+size_t tn_head_save_floats(int32_t batch, int32_t emb, int32_t n_classes);
+int tn_head_forward(int32_t loss_type, int32_t batch, int32_t emb, int32_t n_classes, const float* inputs,
+                    const int64_t* targets, float* fc_weight, const float* fc_bias, int32_t has_scale, float scale, float m1,
+                    float m2, float m3, float eps, float* normalized, int64_t* preds, float* loss, float* save, void* stream);
+/* grad_scale * (*grad_loss_dev if given) = d out / d loss; grad_normalized (may be NULL) = upstream gradient on the
+ * returned normalised inputs.  Writes (overwrites) grad_inputs [batch][emb], grad_weight [n_classes][emb], grad_bias
+ * [n_classes] (CE; may be NULL). */
+int tn_head_backward(int32_t loss_type, int32_t batch, int32_t emb, int32_t n_classes, const float* fc_weight,
+                     const float* save, float grad_scale, const float* grad_loss_dev, const float* grad_normalized,
+                     float* grad_inputs, float* grad_weight, float* grad_bias, void* stream);
 
 /* ---- mel front end: MelSpectrogram.__call__ (reference src/transforms.py:158-203) -----------------------
  * Spectrogram(n_fft, win_length, hop_length, power=None) -> |.|^2 -> MelScale(n_mels, sample_rate) ->

@@ -89,3 +89,132 @@ def test_graph_mode_matches_eager_and_varies_dropout():
     assert all(torch.isfinite(e).all() for e in embs)
     d = [float((embs[i] - embs[i + 1]).abs().max()) for i in range(1, 4)]       # replays (lr = 0: weights frozen)
     assert min(d) > 1e-4, d
+
+
+def _small_model(p=0.0, seed=3, loss="ce", precision="fp32", n_classes=16):
+    from titanet_amd import LOSSES, TitaNet
+    torch.manual_seed(seed)
+    kw = {} if loss == "ce" else {"scale": 30, "margin": 0.2}
+    lf = LOSSES[loss](192, n_classes, device="cuda", **kw)
+    return TitaNet.get_titanet(n_mega_blocks=2, model_size="s", loss_function=lf, dropout=p, device="cuda",
+                               precision=precision).train()
+
+
+def test_fused_adam_matches_torch_optim_adam():
+    """tn_adam_step (inside the timed step of bench.py) against torch.optim.Adam (reference src/train.py:131-135) on the
+    same gradients: 5 steps, weight decay on and off, parameters within 1e-6."""
+    from titanet_amd.trainer import Trainer
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(8, 80, 100, generator=g) * 0.11 - 0.1).cuda()
+    y = torch.randint(0, 16, (8,), generator=g).cuda()
+    for wd in (0.0, 0.01):
+        m = _small_model()
+        tr = Trainer(m, lr=1e-3, weight_decay=wd)
+        ref_p = m.flat_parameters().clone().requires_grad_(True)
+        opt = torch.optim.Adam([ref_p], lr=1e-3, weight_decay=wd)
+        for _ in range(5):
+            tr.forward_backward(x, y)
+            ref_p.grad = m.flat_gradients().clone()
+            # keep the reference copy on the SAME trajectory: it sees the gradients of the fused path's weights
+            opt.step()
+            tr.optimizer_step()
+            torch.cuda.synchronize()
+            err = float((m.flat_parameters() - ref_p.detach()).abs().max())
+            assert err < 1e-6, (wd, err)
+
+
+def test_graph_mode_two_shapes_matches_eager_and_follows_lr():
+    """Alternating input shapes (three plans under RandomChunk) share ONE step counter, and a learning-rate schedule that
+    assigns trainer.lr is honoured by replayed graphs (per-plan counters drifted, lr was frozen at capture)."""
+    from titanet_amd.trainer import Trainer
+    g = torch.Generator().manual_seed(0)
+    xs = [(torch.randn(8, 80, T, generator=g) * 0.11 - 0.1).cuda() for T in (100, 140)]
+    y = torch.randint(0, 16, (8,), generator=g).cuda()
+    eager, graph = Trainer(_small_model()), Trainer(_small_model(), use_graph=True, graph_warmup=1)
+    for i in range(12):
+        lr = 1e-3 * (0.8 ** i)
+        eager.lr = graph.lr = lr
+        le = float(eager.step(xs[i % 2], y)[2])
+        lg = float(graph.step(xs[i % 2], y)[2])
+        assert abs(le - lg) < 2e-4 * max(1.0, abs(le)), (i, le, lg)
+    assert sum(v["graph"] is not None for v in graph._graphs.values()) == 2
+    torch.cuda.synchronize()
+    d = float((eager.model.flat_parameters() - graph.model.flat_parameters()).abs().max())
+    assert d < 1e-5, d
+
+
+def test_checkpoint_optimizer_state_is_adam_layout_and_resumes(tmp_path):
+    """reference src/learn.py:180-201: the checkpoint's "optimizer" loads into torch.optim.Adam(model.parameters()), and a
+    run resumed from the checkpoint continues exactly like the uninterrupted one."""
+    from titanet_amd import train
+    from titanet_amd.trainer import Trainer
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(8, 80, 100, generator=g) * 0.11 - 0.1).cuda()
+    y = torch.randint(0, 16, (8,), generator=g).cuda()
+    a = Trainer(_small_model())
+    for _ in range(3):
+        a.step(x, y)
+    ck = str(tmp_path / "epoch_3.pth")
+    train.save_checkpoint(a.model, a, 3, ck)
+    d = torch.load(ck, weights_only=False)
+    assert d["lr_scheduler"] == {} and d["epoch"] == 3
+    opt = torch.optim.Adam(a.model.parameters(), lr=1e-3)
+    opt.load_state_dict(d["optimizer"])                       # torch's own loader accepts the layout
+    st = opt.state_dict()["state"]
+    assert len(st) == len(list(a.model.parameters())) and float(st[0]["step"]) == 3.0
+    b = Trainer(_small_model(seed=99))                          # different init: everything must come from the checkpoint
+    epoch, _ = train.load_checkpoint(b.model, b, ck)
+    assert epoch == 3 and b.step_count == 3
+    b.model._step = a.model._step                               # same dropout stream position (dropout is 0 here anyway)
+    for _ in range(2):
+        la, lb = float(a.step(x, y)[2]), float(b.step(x, y)[2])
+        assert abs(la - lb) < 1e-5 * max(1.0, abs(la)), (la, lb)
+
+
+@pytest.mark.parametrize("loss", ["ce", "arc"])
+def test_standalone_loss_head_matches_oracle(loss):
+    """CELoss / ArcFaceLoss called as ``loss(inputs, targets)`` (reference src/losses.py:32-44, :77-132) outside
+    TitaNet.forward: values and gradients against the float64 oracle restatement."""
+    from oracle import titanet_oracle as O
+    from titanet_amd import LOSSES
+    torch.manual_seed(5)
+    B, E, NC = 32, 192, 50
+    kw = {} if loss == "ce" else {"scale": 30, "margin": 0.2}
+    head = LOSSES[loss](E, NC, device="cuda", **kw)
+    x = torch.randn(B, E, device="cuda", requires_grad=True)
+    y = torch.randint(0, NC, (B,), device="cuda")
+    w0 = head.fc.weight.detach().clone()
+    norm, preds, lv = head(x, y)
+    (lv * 2.0).backward()
+    torch.cuda.synchronize()
+    xo = x.detach().cpu().double().requires_grad_(True)
+    wo = w0.cpu().double().requires_grad_(True)
+    sd = {"loss_function.fc.weight": wo}
+    if loss == "ce":
+        bo = head.fc.bias.detach().cpu().double().requires_grad_(True)
+        sd["loss_function.fc.bias"] = bo
+        o_norm, o_preds, o_loss, _ = O.ce_loss(xo, y.cpu(), sd)
+    else:
+        o_norm, o_preds, o_loss, _, w_after = O.angular_margin_loss(xo, y.cpu(), sd, **O.margin_kwargs("arc", scale=30, margin=0.2))
+        assert float((head.fc.weight.detach().cpu().double() - w_after.detach()).abs().max()) < 1e-6     # in-place row normalisation
+    (o_loss * 2.0).backward()
+    assert abs(float(lv) - float(o_loss)) < 1e-4 * max(1.0, abs(float(o_loss)))
+    assert torch.equal(preds.cpu(), o_preds)
+    assert float((norm.detach().cpu().double() - o_norm.detach()).abs().max()) < 1e-5
+    ex = float((x.grad.cpu().double() - xo.grad).norm() / xo.grad.norm())
+    ew = float((head.fc.weight.grad.cpu().double() - wo.grad).norm() / wo.grad.norm())
+    assert ex < 1e-4 and ew < 1e-4, (ex, ew)
+    if loss == "ce":
+        eb = float((head.fc.bias.grad.cpu().double() - bo.grad).norm() / bo.grad.norm())
+        assert eb < 1e-4, eb
+
+
+def test_out_of_range_target_poisons_the_loss():
+    """F.cross_entropy raises on a bad label; the fused head cannot raise from a kernel: the loss becomes NaN (so the
+    trainers' finite-loss guard, reference src/learn.py:110-112, stops the run) and no access leaves the logits row."""
+    import math
+    m = _small_model()
+    x = (torch.randn(4, 80, 64) * 0.1).cuda()
+    y = torch.tensor([0, 3, 16, 2], device="cuda")          # 16 == n_classes
+    _, _, lv = m(x, speakers=y)
+    assert math.isnan(float(lv))

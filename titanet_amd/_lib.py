@@ -17,7 +17,7 @@ EXPORTS = [
     "tn_model_num_tensors", "tn_model_tensor_info", "tn_plan_create", "tn_plan_destroy", "tn_plan_workspace_bytes",
     "tn_plan_bind", "tn_forward", "tn_backward", "tn_adam_step", "tn_debug_fetch", "tn_version", "tn_profile_begin",
     "tn_profile_read", "tn_mel_create", "tn_mel_destroy", "tn_mel_num_frames", "tn_mel_forward", "tn_plan_step_tick",
-    "tn_plan_step_set", "tn_adam_step_plan",
+    "tn_plan_step_set", "tn_adam_step_plan", "tn_plan_set_lr", "tn_head_save_floats", "tn_head_forward", "tn_head_backward",
 ]
 
 
@@ -75,6 +75,11 @@ def load():
     lib.tn_plan_step_tick.argtypes = [vp, vp]
     lib.tn_plan_step_set.argtypes = [vp, i64, vp]
     lib.tn_adam_step_plan.argtypes = [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp]
+    lib.tn_plan_set_lr.argtypes = [vp, f32, vp]
+    lib.tn_head_save_floats.argtypes = [i32, i32, i32]
+    lib.tn_head_save_floats.restype = C.c_size_t
+    lib.tn_head_forward.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp]
+    lib.tn_head_backward.argtypes = [i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp]
     lib.tn_debug_fetch.argtypes = [vp, C.c_char_p, vp, i64, vp]
     lib.tn_profile_begin.argtypes = [vp, i32]
     lib.tn_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]

@@ -15,8 +15,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 SOURCES = ["tn_api.hip", "tn_bwd.hip", "tn_mel.hip"]
-HEADERS = ["tn_common.h", "tn_gemm.h", "tn_fwd_kernels.h", "tn_bwd_kernels.h", "tn_v2_kernels.h", "tn_v2_bwd_kernels.h", "tn_internal.h",
-           "../../include/titanet_amd.h"]
+# every header next to the sources feeds the rebuild digest (a stale .so must never ship: it travels prebuilt)
+HEADERS = sorted(f for f in os.listdir(HERE) if f.endswith(".h")) + ["../../include/titanet_amd.h"]
 OUT = os.path.join(PKG, "libtitanet_amd.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable"]

@@ -694,6 +694,39 @@ extern "C" int tn_backward(tn_plan* p, float grad_scale, const float* grad_scale
 }
 
 // =============================================================================================
+// Stand-alone loss heads: MetricLearningLoss.forward(inputs, targets) (reference src/losses.py:32-44, :77-132)
+// =============================================================================================
+extern "C" size_t tn_head_save_floats(int32_t batch, int32_t emb, int32_t n_classes) {
+  return (size_t)batch * ((size_t)n_classes + 1 + 2 * (size_t)emb);
+}
+extern "C" int tn_head_forward(int32_t loss_type, int32_t batch, int32_t emb, int32_t n_classes, const float* inputs,
+                               const int64_t* targets, float* fc_weight, const float* fc_bias, int32_t has_scale, float scale,
+                               float m1, float m2, float m3, float eps, float* normalized, int64_t* preds, float* loss,
+                               float* save, void* stream) {
+  if (!inputs || !targets || !fc_weight || !normalized || !preds || !loss || !save) return TN_E_BADARG;
+  if (batch <= 0 || emb <= 0 || n_classes <= 0) return TN_E_BADARG;
+  if (loss_type != TN_LOSS_CE && loss_type != TN_LOSS_MARGIN) return TN_E_BADARG;
+  if (loss_type == TN_LOSS_CE && !fc_bias) return TN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  HeadArgs ha;
+  memset(&ha, 0, sizeof(ha));
+  ha.lin = inputs; ha.actL = identity_act();
+  ha.B = batch; ha.E = emb; ha.NC = n_classes; ha.loss_type = loss_type;
+  ha.W = fc_weight; ha.bias = fc_bias; ha.targets = targets;
+  ha.scale = scale; ha.has_scale = has_scale; ha.m1 = m1; ha.m2 = m2; ha.m3 = m3; ha.eps = eps;
+  ha.dlogits = save;
+  ha.dscale = save + (size_t)batch * n_classes;
+  ha.emb = ha.dscale + batch;
+  ha.emb_norm = ha.emb + (size_t)batch * emb;
+  ha.emb_user = normalized; ha.preds = preds; ha.loss = loss; ha.logits = nullptr;
+  TN_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
+  if (loss_type == TN_LOSS_MARGIN)
+    hipLaunchKernelGGL(row_normalize_kernel, dim3((n_classes + 3) / 4), dim3(256), 0, st, fc_weight, n_classes, emb);
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(batch), dim3(256), (size_t)(emb + n_classes) * sizeof(float), st, ha);
+  return (int)hipGetLastError();
+}
+
+// =============================================================================================
 // Adam (torch.optim.Adam semantics, reference src/train.py:131-135)
 // =============================================================================================
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -743,10 +776,17 @@ extern "C" int tn_plan_step_set(tn_plan* p, int64_t step, void* stream) {
   hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (uint64_t*)(p->ws + p->step_state), (uint64_t)step, 1);
   return (int)hipGetLastError();
 }
+__global__ void set_lr_kernel(float* lr_word, float lr) { *lr_word = lr; }
+extern "C" int tn_plan_set_lr(tn_plan* p, float lr, void* stream) {
+  if (!p || !p->bound || !(lr >= 0.f)) return TN_E_STATE;
+  hipLaunchKernelGGL(set_lr_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (float*)(p->ws + p->step_state) + 3, lr);
+  return (int)hipGetLastError();
+}
 __global__ void adam_dev_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                      int64_t n, float lr, float b1, float b2, float eps, float wd, const uint64_t* __restrict__ st,
                                      float gmul) {
   const float step = (float)st[0];
+  if (lr < 0.f) lr = reinterpret_cast<const float*>(st)[3];   // schedulable: the plan's device lr word (tn_plan_set_lr)
   const float bc1 = 1.f - powf(b1, step), bc2 = sqrtf(1.f - powf(b2, step));
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float gi = g[i] * gmul;

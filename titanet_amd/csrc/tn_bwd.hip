@@ -391,7 +391,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   if (batched_wgrad) {
     const int chunks = (M + 31) / 32;
     const size_t smem = (size_t)(2 * WG2_RK * WG2_PITCH + (WG2_RK + 2) * V2_C) * sizeof(bf16_t) + (size_t)(6 + 3) * V2_C * sizeof(float);
-    auto kern = wgrad_batched_v2_kernel<3>;
+    auto kern = p->save_q ? wgrad_batched_v2_kernel<3, false> : wgrad_batched_v2_kernel<3, true>;
     TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     {
       ProfScope ps(p, TN_PROF_BWD_WGRAD, st);
@@ -520,6 +520,28 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
   }
   TN_CHECK_HIP(hipStreamSynchronize(st));
   return 0;
+}
+
+// MetricLearningLoss.forward's autograd (reference src/losses.py:32-44, :77-132): backward of tn_head_forward from its `save`
+extern "C" int tn_head_backward(int32_t loss_type, int32_t batch, int32_t emb, int32_t n_classes, const float* fc_weight,
+                                const float* save, float grad_scale, const float* grad_loss_dev, const float* grad_normalized,
+                                float* grad_inputs, float* grad_weight, float* grad_bias, void* stream) {
+  if (!fc_weight || !save || !grad_inputs || !grad_weight) return TN_E_BADARG;
+  if (batch <= 0 || emb <= 0 || n_classes <= 0) return TN_E_BADARG;
+  if (loss_type != TN_LOSS_CE && loss_type != TN_LOSS_MARGIN) return TN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  HeadBwdArgs ha;
+  memset(&ha, 0, sizeof(ha));
+  ha.B = batch; ha.E = emb; ha.NC = n_classes; ha.loss_type = loss_type;
+  ha.dlogits = save;
+  ha.dscale = save + (size_t)batch * n_classes;
+  ha.emb = ha.dscale + batch;
+  ha.emb_norm = ha.emb + (size_t)batch * emb;
+  ha.W = fc_weight; ha.gs = grad_scale; ha.gs_dev = grad_loss_dev; ha.g_embnorm = grad_normalized;
+  ha.g_W = grad_weight; ha.g_bias = grad_bias; ha.demb = grad_inputs;
+  hipLaunchKernelGGL(head_bwd_w_kernel, dim3((n_classes * emb + 255) / 256), dim3(256), 0, st, ha);
+  hipLaunchKernelGGL(head_bwd_x_kernel, dim3(batch), dim3(256), (size_t)emb * sizeof(float), st, ha);
+  return (int)hipGetLastError();
 }
 
 int plan_backward(tn_plan* p, float grad_scale, const float* grad_scale_dev, const float* grad_emb, float* grad_input,

@@ -347,7 +347,13 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
   }
   if (a.loss_type == 0) return;
   __syncthreads();
-  const int y = (int)a.targets[b];
+  int y = (int)a.targets[b];
+  if (y < 0 || y >= a.NC) {
+    // F.cross_entropy raises on an out-of-range target; a kernel cannot: poison the loss (the trainers' finite-loss guard,
+    // reference src/learn.py:110-112, trips) and keep every access in range
+    if (tid == 0) atomic_add_f32(a.loss, NAN);
+    y = min(max(y, 0), a.NC - 1);
+  }
   // logits / cosines
   float vmax = -INFINITY; int imax = 0x7fffffff;
   for (int c = tid; c < a.NC; c += 256) {

@@ -195,7 +195,10 @@ __device__ __forceinline__ void wg2_chunks(const WgradV2Desc& d, const WgSeg& sg
   }
 }
 
-template <int KD>
+// ALLOW_DW = false: every layer's second operand is a stored tensor (the forward kept the depthwise outputs): the
+// depthwise-recompute variants of the chunk loop are not even instantiated — they cost the kernel 100 spilled VGPRs
+// (the register allocation of a kernel is the worst case over all its branches).
+template <int KD, bool ALLOW_DW>
 __global__ __launch_bounds__(V2_NT, 2) void wgrad_batched_v2_kernel(const WgradV2Desc* __restrict__ descs, int n_layers,
                                                                      int M, int T, int chunks_per_layer,
                                                                      int units_per_wg, int* __restrict__ part_count,
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(V2_NT, 2) void wgrad_batched_v2_kernel(const WgradV
     const int nchunks = min(chunks_per_layer - chunk0, unit_end - unit);
     WgradV2Desc d = descs[layer];
     if (d.actX.drop_thr) d.actX.drop_key = tn_layer_key(seed, (uint32_t)d.drop_layer);
-    const bool dw = d.wdw != nullptr;
+    const bool dw = ALLOW_DW && d.wdw != nullptr;
     __syncthreads();
     if (tid < V2_C) {
       BnBwd bb;
@@ -245,12 +248,14 @@ __global__ __launch_bounds__(V2_NT, 2) void wgrad_batched_v2_kernel(const WgradV
     {
       const int fl = (d.actX.mode != 0 ? 1 : 0) | (d.actX.relu ? 2 : 0) | (d.actX.drop_thr ? 4 : 0);
       WgSeg sg{Pt, Qt, Xa, cst, chunk0, nchunks, M, T};
-      if (dw) {
-        switch (fl) {
-          case 7: wg2_chunks<KD, true, 7>(d, sg, acc); break;
-          case 3: wg2_chunks<KD, true, 3>(d, sg, acc); break;
-          case 0: wg2_chunks<KD, true, 0>(d, sg, acc); break;
-          default: wg2_chunks<KD, true, -1>(d, sg, acc); break;
+      if (ALLOW_DW && dw) {
+        if constexpr (ALLOW_DW) {
+          switch (fl) {
+            case 7: wg2_chunks<KD, true, 7>(d, sg, acc); break;
+            case 3: wg2_chunks<KD, true, 3>(d, sg, acc); break;
+            case 0: wg2_chunks<KD, true, 0>(d, sg, acc); break;
+            default: wg2_chunks<KD, true, -1>(d, sg, acc); break;
+          }
         }
       } else {
         switch (fl) {

@@ -6,6 +6,7 @@ The classes own the final ``fc`` parameters (same ``state_dict`` keys as the ref
 kernels of ``libtitanet_amd.so`` when the loss is attached to a :class:`titanet_amd.models.TitaNet`
 (``TitaNet.forward(spectrograms, speakers)``, reference src/models.py:339).
 """
+import ctypes as C
 import math
 
 import numpy as np
@@ -13,6 +14,57 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class _HeadFunction(torch.autograd.Function):
+    """``loss(inputs, targets)`` outside TitaNet.forward: tn_head_forward / tn_head_backward (include/titanet_amd.h)."""
+
+    @staticmethod
+    def forward(ctx, inputs, weight, bias, head, targets):
+        lib = _lib.load()
+        if not inputs.is_cuda:
+            raise RuntimeError("titanet_amd loss heads need ROCm device tensors; there is no CPU execution path")
+        x = inputs.detach().contiguous().float()
+        B, E = x.shape
+        NC = int(weight.shape[0])
+        y = targets.detach().to(device=x.device, dtype=torch.int64).contiguous()
+        lt, hs, sc, m1, m2, m3, eps = head.native_config()
+        norm = torch.empty_like(x)
+        preds = torch.empty(B, dtype=torch.int64, device=x.device)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        save = torch.empty(int(lib.tn_head_save_floats(B, E, NC)), dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(lib.tn_head_forward(lt, B, E, NC, _p(x), _p(y), _p(weight.data), _p(bias.data if bias is not None else None),
+                                       hs, sc, m1, m2, m3, eps, _p(norm), _p(preds), _p(loss), _p(save), C.c_void_p(stream)),
+                   "tn_head_forward")
+        ctx.cfg, ctx.save, ctx.weight, ctx.has_bias = (lt, B, E, NC), save, weight, bias is not None
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(preds)
+        return norm, preds, loss
+
+    @staticmethod
+    def backward(ctx, g_norm, g_preds, g_loss):
+        lib = _lib.load()
+        lt, B, E, NC = ctx.cfg
+        dev = ctx.save.device
+        g_in = torch.empty(B, E, dtype=torch.float32, device=dev)
+        g_w = torch.empty(NC, E, dtype=torch.float32, device=dev)
+        g_b = torch.empty(NC, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        scale = 1.0
+        if g_loss is None:
+            scale = 0.0
+        else:
+            g_loss = g_loss.contiguous().float()
+        if g_norm is not None:
+            g_norm = g_norm.contiguous().float()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.tn_head_backward(lt, B, E, NC, _p(ctx.weight.data), _p(ctx.save), C.c_float(scale), _p(g_loss), _p(g_norm),
+                                        _p(g_in), _p(g_w), _p(g_b), C.c_void_p(stream)), "tn_head_backward")
+        return g_in, g_w, g_b, None, None
 
 
 class _FC(nn.Module):
@@ -43,9 +95,12 @@ class MetricLearningLoss(nn.Module):
         self.device = device
 
     def forward(self, inputs, targets):
-        raise NotImplementedError(
-            "titanet_amd loss heads run fused inside TitaNet.forward(spectrograms, speakers); "
-            "attach the loss with TitaNet(..., loss_function=loss)")
+        """reference src/losses.py:32-44 / :77-132: (normalised inputs, predictions, loss).  Inside
+        ``TitaNet.forward(spectrograms, speakers)`` the same head kernels run fused with the decoder tail; this entry
+        is the stand-alone call of the reference's loss objects."""
+        if not hasattr(self, "fc"):
+            raise NotImplementedError
+        return _HeadFunction.apply(inputs, self.fc.weight, self.fc.bias, self, targets)
 
     def native_config(self):
         """(loss_type, has_scale, scale, m1, m2, m3, eps) for tn_config."""

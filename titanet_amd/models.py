@@ -286,8 +286,7 @@ class TitaNet(nn.Module):
         (normalised embeddings, predictions, loss) when ``speakers`` is given."""
         if speakers is not None:
             assert self.loss_function is not None, "Loss function should not be None in training mode"
-        needs_grad = torch.is_grad_enabled() and (spectrograms.requires_grad or
-                                                  any(p.requires_grad for p in (self._parameters_head())))
+        needs_grad = torch.is_grad_enabled() and (spectrograms.requires_grad or any(p.requires_grad for p in self.parameters()))
         if needs_grad:
             if self._anchor.device != spectrograms.device:
                 self._anchor = torch.zeros(1, device=spectrograms.device, requires_grad=True)
@@ -297,13 +296,6 @@ class TitaNet(nn.Module):
         if speakers is None:
             return emb
         return emb, preds, loss
-
-    def _parameters_head(self):
-        # cheap "does anything require grad" probe: the first parameter stands for all (they are
-        # frozen/unfrozen together by optimizers in the reference's training loop)
-        for p in self.parameters():
-            yield p
-            return
 
     # ------------------------------------------------------------------ native calls
     def _prec(self):

@@ -45,7 +45,8 @@ def synthetic_batches(batch_size, n_mels, n_classes, device, frames=(151, 201, 3
         yield x.to(device), torch.full((batch_size,), T), y.to(device)
 
 
-def run(params, steps=None, n_classes=251, data=None, device="cuda", precision="fp32", log_every=10):
+def run(params, steps=None, n_classes=251, data=None, device="cuda", precision="fp32", log_every=10, resume=None,
+        use_graph=False):
     torch.manual_seed(params.generic.seed)
     loss_name = params.training.loss
     loss_kw = dict(getattr(params.loss, loss_name).entries) if hasattr(params.loss, loss_name) else {}
@@ -56,15 +57,18 @@ def run(params, steps=None, n_classes=251, data=None, device="cuda", precision="
                                 loss_function=loss_function, dropout=params.titanet.dropout, device=device, precision=precision)
     model.train()
     opt = params.training.optimizer
-    trainer = Trainer(model, lr=opt.start_lr, weight_decay=opt.weight_decay)
+    trainer = Trainer(model, lr=opt.start_lr, weight_decay=opt.weight_decay, use_graph=use_graph)
+    first = 1
+    if resume:
+        first = load_checkpoint(model, trainer, resume)[0] + 1
     data = data or synthetic_batches(params.training.batch_size, params.audio.spectrogram.n_mels, n_classes, device,
                                      seed=params.generic.seed)
     epochs = params.training.epochs
     total = steps if steps is not None else epochs
     history = []
-    for step in range(1, total + 1):
-        if opt.scheduler:   # CosineAnnealingLR(T_max=epochs, eta_min=end_lr) stepped per epoch (src/train.py:137-144)
-            trainer.lr = opt.end_lr + 0.5 * (opt.start_lr - opt.end_lr) * (1 + math.cos(math.pi * min(step - 1, epochs) / epochs))
+    for step in range(first, total + 1):
+        if opt.scheduler:
+            trainer.lr = cosine_lr(opt, step - 1, epochs)
         spectrograms, _, speakers = next(data)
         emb, preds, loss = trainer.step(spectrograms, speakers)
         if step % log_every == 0 or step == total:
@@ -77,14 +81,28 @@ def run(params, steps=None, n_classes=251, data=None, device="cuda", precision="
     return model, trainer, history
 
 
-def save_checkpoint(model, trainer, epoch, path):
-    """reference src/learn.py:180-201 layout (optimizer state in torch.optim.Adam's state_dict shape)."""
+def cosine_lr(opt, epoch, epochs):
+    """CosineAnnealingLR(T_max=epochs, eta_min=end_lr) stepped once per epoch (reference src/train.py:137-144, src/learn.py:257-258)"""
+    return opt.end_lr + 0.5 * (opt.start_lr - opt.end_lr) * (1 + math.cos(math.pi * min(epoch, epochs) / epochs))
+
+
+def save_checkpoint(model, trainer, epoch, path, scheduler=None):
+    """reference src/learn.py:180-201: ``{"model", "optimizer", "lr_scheduler", "epoch"}``.  ``"optimizer"`` is in
+    ``torch.optim.Adam.state_dict()`` layout (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``), ``"lr_scheduler"`` a
+    ``CosineAnnealingLR``-shaped dict when a schedule is on, else ``dict()`` as the reference writes."""
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-    torch.save({"model": model.state_dict(),
-                "optimizer": {"state": {"flat": {"step": trainer.step_count, "exp_avg": trainer.exp_avg, "exp_avg_sq": trainer.exp_avg_sq}},
-                              "param_groups": [{"lr": trainer.lr, "betas": trainer.betas, "eps": trainer.eps,
-                                                "weight_decay": trainer.weight_decay}]},
-                "lr_scheduler": None, "epoch": epoch}, path)
+    torch.save({"model": model.state_dict(), "optimizer": trainer.optimizer_state_dict(),
+                "lr_scheduler": dict(scheduler) if scheduler else dict(), "epoch": epoch}, path)
+
+
+def load_checkpoint(model, trainer, path, strict=True):
+    """Resume from a checkpoint written by :func:`save_checkpoint` or by the reference (same dict layout): model weights
+    and BatchNorm buffers, Adam moments and step, learning rate.  Returns ``(epoch, lr_scheduler dict)``."""
+    ck = torch.load(path, map_location=model.flat_parameters().device, weights_only=False)
+    model.load_state_dict(ck["model"], strict=strict)
+    if trainer is not None and ck.get("optimizer"):
+        trainer.load_optimizer_state_dict(ck["optimizer"])
+    return ck.get("epoch", 0), ck.get("lr_scheduler") or {}
 
 
 def main():
@@ -93,12 +111,17 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--checkpoint", default=None)
+    ap.add_argument("--resume", default=None, help="checkpoint to resume from (reference layout, src/learn.py:188-195)")
     args = ap.parse_args()
     with open(args.params) as fh:
         params = Struct(**yaml.load(fh, Loader=yaml.SafeLoader))
-    model, trainer, _ = run(params, steps=args.steps, precision=args.precision)
+    model, trainer, _ = run(params, steps=args.steps, precision=args.precision, resume=args.resume)
     if args.checkpoint:
-        save_checkpoint(model, trainer, args.steps or params.training.epochs, args.checkpoint)
+        opt = params.training.optimizer
+        epoch = args.steps or params.training.epochs
+        sched = {"T_max": params.training.epochs, "eta_min": opt.end_lr, "base_lrs": [opt.start_lr], "last_epoch": epoch,
+                 "_last_lr": [trainer.lr]} if opt.scheduler else None
+        save_checkpoint(model, trainer, epoch, args.checkpoint, scheduler=sched)
 
 
 if __name__ == "__main__":

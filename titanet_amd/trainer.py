@@ -119,6 +119,45 @@ class Trainer:
         self.optimizer_step()
         return out
 
+    # ------------------------------------------------------------------ optimizer state (torch.optim.Adam layout)
+    def _param_slices(self):
+        from . import _lib as L
+        return [(off, numel, shape) for _, kind, off, numel, shape in self.model._layout if kind == L.TN_KIND_PARAM]
+
+    def optimizer_state_dict(self):
+        """The fused optimizer's state in ``torch.optim.Adam.state_dict()`` layout (what the reference checkpoints as
+        ``"optimizer"``, src/learn.py:188-195): per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` keyed by the index
+        of the parameter in ``model.parameters()`` order, one param group.  ``torch.optim.Adam(model.parameters())
+        .load_state_dict(...)`` accepts it, and :meth:`load_optimizer_state_dict` accepts an Adam state_dict."""
+        sl = self._param_slices()
+        state = {}
+        for i, (off, numel, shape) in enumerate(sl):
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.exp_avg[off:off + numel].view(shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + numel].view(shape).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "params": list(range(len(sl)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        sl = self._param_slices()
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        step = 0
+        for i, (off, numel, shape) in enumerate(sl):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            self.exp_avg[off:off + numel].view(shape).copy_(st["exp_avg"])
+            self.exp_avg_sq[off:off + numel].view(shape).copy_(st["exp_avg_sq"])
+            step = max(step, int(float(st["step"])))
+        self.step_count = step
+        for st in self._graphs.values():      # captured graphs hold no optimizer state, but restart their warm-up
+            st["graph"], st["eager"] = None, 0
+
     # ------------------------------------------------------------------ one hipGraph per step
     def _device_step(self, x, y):
         """tick -> forward -> backward -> Adam, with the step count and the dropout word in device memory"""
@@ -130,28 +169,38 @@ class Trainer:
         emb, preds, loss, plan = m._native_forward(x, y, fixed_seed=True)
         check(m._lib.tn_backward(plan.handle, C.c_float(1.0), vp(0), vp(0), vp(0), vp(stream)), "tn_backward")
         flat, grads = m.flat_parameters(), m.flat_gradients()
+        # lr < 0: read the plan's device lr word (written by _sync_device_state before every step, so a scheduler that
+        # assigns trainer.lr keeps working under graph replay); betas / eps / weight decay are captured by value — changing
+        # them re-captures (see _graph_step)
         check(m._lib.tn_adam_step_plan(plan.handle, vp(flat.data_ptr()), vp(grads.data_ptr()), vp(self.exp_avg.data_ptr()),
-                                       vp(self.exp_avg_sq.data_ptr()), flat.numel(), self.lr, self.betas[0], self.betas[1],
+                                       vp(self.exp_avg_sq.data_ptr()), flat.numel(), -1.0, self.betas[0], self.betas[1],
                                        self.eps, self.weight_decay, 1.0, vp(stream)), "tn_adam_step_plan")
         return emb, preds, loss, plan
+
+    def _sync_device_state(self, plan, device):
+        """ONE step counter per Trainer: every plan's device counter / dropout word / lr word is set from the trainer's
+        state right before the step that uses it (two one-thread kernels outside the graph), so alternating input shapes
+        (RandomChunk's 1.5 / 2 / 3 s lengths give three plans) cannot drift apart or replay a stale learning rate."""
+        m = self.model
+        stream = torch.cuda.current_stream(device).cuda_stream
+        check(m._lib.tn_plan_step_set(plan.handle, self.step_count - 1, C.c_void_p(stream)), "tn_plan_step_set")
+        check(m._lib.tn_plan_set_lr(plan.handle, C.c_float(float(self.lr)), C.c_void_p(stream)), "tn_plan_set_lr")
 
     def _graph_step(self, spectrograms, speakers):
         key = (tuple(spectrograms.shape), spectrograms.device.index)
         st = self._graphs.get(key)
         if st is None:
-            st = self._graphs[key] = {"graph": None, "eager": 0,
+            st = self._graphs[key] = {"graph": None, "eager": 0, "hp": None,
                                       "x": torch.empty_like(spectrograms), "y": torch.empty_like(speakers)}
         st["x"].copy_(spectrograms)
         st["y"].copy_(speakers)
         self.step_count += 1
-        if st["graph"] is not None and self.model._plans.get(st["plan"].key) is not st["plan"]:
-            st["graph"], st["eager"] = None, 0          # the plan was evicted from the model's cache: capture again
+        hp = (tuple(self.betas), self.eps, self.weight_decay)
+        if st["graph"] is not None and (self.model._plans.get(st["plan"].key) is not st["plan"] or st["hp"] != hp):
+            st["graph"], st["eager"] = None, 0          # plan evicted from the model's cache / captured hyper-parameters changed
+        plan = self.model._get_plan(st["x"].shape[0], st["x"].shape[2])
+        self._sync_device_state(plan, st["x"].device)
         if st["graph"] is None:
-            if st["eager"] == 0:
-                # the plan's device step counter continues this trainer's count
-                plan = self.model._get_plan(st["x"].shape[0], st["x"].shape[2])
-                stream = torch.cuda.current_stream(st["x"].device).cuda_stream
-                check(self.model._lib.tn_plan_step_set(plan.handle, self.step_count - 1, C.c_void_p(stream)), "tn_plan_step_set")
             if st["eager"] < self.graph_warmup:
                 st["eager"] += 1
                 return self._device_step(st["x"], st["y"])[:3]
@@ -159,7 +208,7 @@ class Trainer:
             torch.cuda.synchronize()
             with torch.cuda.graph(g):
                 out = self._device_step(st["x"], st["y"])
-            st["out"], st["plan"], st["graph"] = out[:3], out[3], g
+            st["out"], st["plan"], st["graph"], st["hp"] = out[:3], out[3], g, hp
             # the capture itself does not execute: run the captured step for this call
         st["graph"].replay()
         return st["out"]
