@@ -115,6 +115,21 @@ int tn_forward(tn_plan* p, const float* spectrograms, const int64_t* speakers, i
 int tn_backward(tn_plan* p, float grad_scale, const float* grad_scale_dev, const float* grad_embeddings,
                 float* grad_input, void* stream);
 
+/* ---- gradient buckets: overlapping the data-parallel all-reduce with backward (new; the reference is single-device) ----
+ * The flat gradient buffer is in state_dict order, and backward finishes it from the END: loss head, decoder, epilog,
+ * then the mega blocks from the last one down, the prolog last.  tn_plan_set_grad_groups(G > 1) (before
+ * tn_plan_workspace_bytes / tn_plan_bind) splits it into 1 + G contiguous buckets in COMPLETION order — bucket 0 = epilog
+ * conv .. loss head, buckets 1..G = groups of mega blocks from the top (the prolog rides with block 0's group) — and makes
+ * tn_backward finalise each bucket as soon as its layers are done (its own balanced weight-gradient launch) and record an
+ * event.  A trainer enqueues, per bucket i, tn_plan_wait_grad_bucket(i, comm_stream) + ncclAllReduce on comm_stream: the
+ * collective of bucket i then runs under the backward of the blocks below it (titanet_amd/trainer.py).  G = 1 (default):
+ * one bucket, every deferred weight gradient in one launch at the end of backward (fastest on a single GPU). */
+int tn_plan_set_grad_groups(tn_plan* p, int32_t groups);
+int32_t tn_plan_num_grad_buckets(const tn_plan* p);
+int tn_plan_grad_bucket(const tn_plan* p, int32_t i, int64_t* begin_float, int64_t* end_float);
+/* hipStreamWaitEvent(stream, event of bucket i of the last tn_backward) */
+int tn_plan_wait_grad_bucket(tn_plan* p, int32_t i, void* stream);
+
 /* ---- optim.Adam step on the flat buffers (reference src/train.py:131-135: Adam, lr 1e-3) -----
  * grads are multiplied by grad_mult first (1/world_size after a sum all-reduce). */
 int tn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

@@ -3,6 +3,10 @@
 All channel counts are multiples of 8 (the HIP kernels move 8-channel vectors).
 """
 
+import numpy as np
+
+from oracle import detgen
+
 _TINY = dict(n_mels=16, n_mega_blocks=2, hidden=32, enc_out=96, emb=16, kernel=3, attn_hidden=16)
 
 CASES = {
@@ -38,3 +42,17 @@ CASES = {
     "tiny_simple_pool": dict(cfg=dict(_TINY, n_mega_blocks=1), simple_pool=True, batch=4, frames=29, n_classes=9, seed=5,
                              inter=False, losses=("ce", "arc"), grads="all", buffers=()),
 }
+
+
+def head_clamp_inputs():
+    """Deterministic inputs of the ``head_clamp`` fixture (rebuilt by the tests): embeddings whose cosine with a class
+    row is exactly +1 / -1 before the clamp (SURVEY.md 8c "include a row with cos -> +-1 clamp"): row 0 is a positive
+    multiple of class row 2, row 1 a negative multiple of class row 5 (neither is that row's target: the reference's
+    arccos'(+-1) is infinite at the TARGET column, src/losses.py:100-110), rows 2.. are generic."""
+    B, E, NC = 6, 16, 9
+    w = detgen.tensor_for("head_clamp.fc.weight", (NC, E), seed=7).astype(np.float32)
+    x = (detgen.tensor_for("head_clamp.inputs", (B, E), seed=7) * 4.0).astype(np.float32)
+    x[0] = 3.0 * w[2]
+    x[1] = -2.0 * w[5]
+    y = np.array([4, 1, 0, 8, 3, 3], dtype=np.int64)
+    return x, w, y

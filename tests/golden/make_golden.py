@@ -27,7 +27,7 @@ import losses as ref_losses  # noqa: E402  (reference)
 import models as ref_models  # noqa: E402  (reference)
 
 from oracle import detgen  # noqa: E402
-from tests.golden.cases import CASES  # noqa: E402
+from tests.golden.cases import CASES, head_clamp_inputs  # noqa: E402
 
 
 def build_reference(case, loss_name, dtype):
@@ -153,6 +153,30 @@ def metrics_golden():
     print("metrics:", eer, mindcf, eer2, mindcf2)
 
 
+def head_clamp_golden():
+    x, w, y = head_clamp_inputs()
+    out = {}
+    for name, ctor in (("arc", lambda: ref_losses.ArcFaceLoss(16, 9, scale=30, margin=0.2)),
+                       ("cos", lambda: ref_losses.CosFaceLoss(16, 9, scale=64, margin=0.2))):
+        head = ctor().double()
+        head.fc.weight.data = torch.from_numpy(w).double()
+        xin = torch.from_numpy(x).double().requires_grad_(True)
+        cos_store = {}
+        h = head.fc.register_forward_hook(lambda m, i, o: cos_store.__setitem__("cos", o.detach().numpy()))
+        norm, preds, loss = head(xin, torch.from_numpy(y))
+        loss.backward()
+        h.remove()
+        out[name + ".raw_cos"] = cos_store["cos"]           # BEFORE the clamp: rows 0 / 1 reach +-1 (up to rounding)
+        out[name + ".normalized"] = norm.detach().numpy()
+        out[name + ".preds"] = preds.numpy()
+        out[name + ".loss"] = np.asarray(loss.item())
+        out[name + ".grad.inputs"] = xin.grad.numpy()
+        out[name + ".grad.weight"] = head.fc.weight.grad.numpy()
+        out[name + ".weight_after"] = head.fc.weight.data.numpy()
+    np.savez_compressed(os.path.join(HERE, "head_clamp.npz"), **out)
+    print("head_clamp: raw cos extremes", out["arc.raw_cos"].max(), out["arc.raw_cos"].min(), "loss", out["arc.loss"])
+
+
 def sizing_golden():
     """Known answers for model sizing (titanet.ipynb:743,765,787,961)."""
     out = {}
@@ -177,3 +201,5 @@ if __name__ == "__main__":
         metrics_golden()
     if not only or "sizing" in only:
         sizing_golden()
+    if not only or "head_clamp" in only:
+        head_clamp_golden()

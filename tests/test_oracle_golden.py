@@ -86,3 +86,29 @@ def test_state_dict_layout_matches_reference_listing():
         shapes = O.state_dict_shapes(O.OracleConfig.titanet(size, n_mega_blocks=nb))
         n = sum(int(np.prod(s)) for k, s in shapes.items() if "running_" not in k and "num_batches" not in k)
         assert n == int(sizing[f"params.{size}{nb}"])
+
+
+@pytest.mark.parametrize("name", ["arc", "cos"])
+def test_margin_head_at_the_cos_clamp_vs_reference_golden(name):
+    """a batch whose cosines reach exactly +-1 before the clamp (reference src/losses.py:94-98): loss,
+    predictions, normalised inputs, in-place weight normalisation and both gradients against the real reference (f64)."""
+    from tests.golden.cases import head_clamp_inputs
+    g = load_golden("head_clamp")
+    x, w, y = head_clamp_inputs()
+    xo = torch.from_numpy(x).double().requires_grad_(True)
+    wo = torch.from_numpy(w).double().requires_grad_(True)
+    kw = O.margin_kwargs(name, scale=30 if name == "arc" else 64, margin=0.2)
+    norm, preds, loss, cos, w_after = O.angular_margin_loss(xo, torch.from_numpy(y), {"loss_function.fc.weight": wo}, **kw)
+    loss.backward()
+    assert np.abs(g[name + ".raw_cos"]).max() >= 1.0 - 1e-12            # the fixture really sits on the clamp
+    assert abs(loss.item() - float(g[name + ".loss"])) < 1e-10 * max(1.0, abs(float(g[name + ".loss"])))
+    assert np.array_equal(preds.numpy(), g[name + ".preds"])
+    assert rel_err(norm.detach().numpy(), g[name + ".normalized"]) < 1e-12
+    assert rel_err(w_after.numpy(), g[name + ".weight_after"]) < 1e-12
+    # the reference takes arccos of EVERY clamped cosine (src/losses.py:100): at +-1 its backward is 0 * inf = NaN for the
+    # whole input row and the touched weight rows — the restatement reproduces exactly that pattern, finite entries to 1e-9
+    for got, want in ((xo.grad.numpy(), g[name + ".grad.inputs"]), (wo.grad.numpy(), g[name + ".grad.weight"])):
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert np.isnan(want).any() and np.isfinite(want).any()
+        ok = np.isfinite(want)
+        assert rel_err(got[ok], want[ok]) < 1e-9

@@ -218,3 +218,45 @@ def test_out_of_range_target_poisons_the_loss():
     y = torch.tensor([0, 3, 16, 2], device="cuda")          # 16 == n_classes
     _, _, lv = m(x, speakers=y)
     assert math.isnan(float(lv))
+
+
+@pytest.mark.parametrize("name", ["arc", "cos"])
+def test_margin_head_at_the_cos_clamp_vs_reference_golden(name):
+    """SURVEY.md 8c "a row with cos -> +-1 clamp": forward values against the real reference's golden.  Gradients: where the
+    reference is finite they match it; where the reference yields NaN (it differentiates arccos at +-1 for columns it
+    never uses: 0 * inf, src/losses.py:100) the HIP head returns the finite analytic gradient of the same loss."""
+    import numpy as np
+    from oracle import titanet_oracle as O
+    from tests.golden.cases import head_clamp_inputs
+    from tests.util import load_golden, rel_err
+    from titanet_amd import LOSSES
+    g = load_golden("head_clamp")
+    x, w, y = head_clamp_inputs()
+    head = LOSSES[name](16, 9, device="cuda", scale=30 if name == "arc" else 64, margin=0.2)
+    with torch.no_grad():
+        head.fc.weight.copy_(torch.from_numpy(w))
+    xi = torch.from_numpy(x).cuda().requires_grad_(True)
+    norm, preds, lv = head(xi, torch.from_numpy(y).cuda())
+    lv.backward()
+    torch.cuda.synchronize()
+    assert abs(float(lv) - float(g[name + ".loss"])) < 1e-4 * abs(float(g[name + ".loss"]))
+    assert np.array_equal(preds.cpu().numpy(), g[name + ".preds"])
+    assert rel_err(norm.detach().cpu().numpy(), g[name + ".normalized"]) < 1e-6
+    assert rel_err(head.fc.weight.detach().cpu().numpy(), g[name + ".weight_after"]) < 1e-6
+    gx, gw = xi.grad.cpu().numpy(), head.fc.weight.grad.cpu().numpy()
+    assert np.isfinite(gx).all() and np.isfinite(gw).all()
+    for got, want in ((gx, g[name + ".grad.inputs"]), (gw, g[name + ".grad.weight"])):
+        ok = np.isfinite(want)
+        assert ok.any() and rel_err(got[ok], want[ok]) < 1e-4
+    # the rows the reference poisons: analytic gradient with arccos taken at the target column only
+    kw = O.margin_kwargs(name, scale=30 if name == "arc" else 64, margin=0.2)
+    xo = torch.from_numpy(x).double().requires_grad_(True)
+    wn = torch.from_numpy(g[name + ".weight_after"]).double().requires_grad_(True)
+    xn = xo / xo.norm(dim=1, keepdim=True)
+    cos = (xn @ wn.t()).clamp(-1, 1)
+    yt = torch.from_numpy(y)[:, None]
+    num = kw["scale"] * (torch.cos(kw["m1"] * torch.arccos(cos.gather(1, yt)[:, 0]) + kw["m2"]) - kw["m3"])
+    expo = torch.exp(kw["scale"] * cos)
+    den = torch.exp(num) + expo.sum(1) - expo.gather(1, yt)[:, 0]
+    (-(num - torch.log(den + kw["eps"])).mean()).backward()
+    assert rel_err(gx, xo.grad.numpy()) < 1e-4 and rel_err(gw, wn.grad.numpy()) < 1e-4

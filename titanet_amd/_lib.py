@@ -18,6 +18,7 @@ EXPORTS = [
     "tn_plan_bind", "tn_forward", "tn_backward", "tn_adam_step", "tn_debug_fetch", "tn_version", "tn_profile_begin",
     "tn_profile_read", "tn_mel_create", "tn_mel_destroy", "tn_mel_num_frames", "tn_mel_forward", "tn_plan_step_tick",
     "tn_plan_step_set", "tn_adam_step_plan", "tn_plan_set_lr", "tn_head_save_floats", "tn_head_forward", "tn_head_backward",
+    "tn_plan_set_grad_groups", "tn_plan_num_grad_buckets", "tn_plan_grad_bucket", "tn_plan_wait_grad_bucket",
 ]
 
 
@@ -76,6 +77,11 @@ def load():
     lib.tn_plan_step_set.argtypes = [vp, i64, vp]
     lib.tn_adam_step_plan.argtypes = [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp]
     lib.tn_plan_set_lr.argtypes = [vp, f32, vp]
+    lib.tn_plan_set_grad_groups.argtypes = [vp, i32]
+    lib.tn_plan_num_grad_buckets.argtypes = [vp]
+    lib.tn_plan_num_grad_buckets.restype = i32
+    lib.tn_plan_grad_bucket.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64)]
+    lib.tn_plan_wait_grad_bucket.argtypes = [vp, i32, vp]
     lib.tn_head_save_floats.argtypes = [i32, i32, i32]
     lib.tn_head_save_floats.restype = C.c_size_t
     lib.tn_head_forward.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp]

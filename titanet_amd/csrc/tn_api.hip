@@ -277,11 +277,6 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     p->wg2_epi_slabs = (c.n_mega_blocks > 0 && D % 256 == 0 && (p->use_v2 & 16)) ? (int)(D / 256) : 0;
     p->wg2_layers += p->wg2_epi_slabs;
     p->wg2_grid = 256;
-    const int chunks = (p->M + 31) / 32;
-    const long total = (long)p->wg2_layers * chunks;
-    p->wg2_units_per_wg = (int)((total + p->wg2_grid - 1) / p->wg2_grid);
-    p->wg2_maxparts = (chunks + p->wg2_units_per_wg - 1) / p->wg2_units_per_wg + 1;
-    p->wg2_slabs = b.take((size_t)p->wg2_layers * p->wg2_maxparts * 256 * 256 * sizeof(float));
     p->wg2_desc = b.take((size_t)p->wg2_layers * 256);   // >= sizeof(WgradV2Desc) each (checked at upload)
     p->wg2_out = b.take((size_t)p->wg2_layers * 16);
     p->dw_table = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * 32);
@@ -294,14 +289,86 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   p->bwd_table = b.take(p->bwd_table_bytes);
   p->bwd_table_eval = b.take(p->bwd_table_bytes);
   p->se_table = b.take((size_t)(c.n_mega_blocks + 1) * 64);
-  p->ws_bytes = (b.off + 255) & ~(size_t)255;
+  p->ws_fixed_bytes = (b.off + 255) & ~(size_t)255;
+  plan_layout_tail(p);
   *out = p;
+  return 0;
+}
+
+// Gradient buckets + the regions sized by them.  grad_groups = 1: one bucket; G > 1: bucket 0 = everything from the epilog
+// conv to the loss head (final first), then G groups of mega blocks from the last block down, the prolog riding with the
+// group of block 0 (the flat buffer is in state_dict order, so every bucket is one contiguous range).
+void plan_layout_tail(tn_plan* p) {
+  const tn_model* m = p->model;
+  const tn_config& c = m->cfg;
+  const int nb = c.n_mega_blocks;
+  p->buckets.clear();
+  const int G = std::max(1, std::min(p->grad_groups, std::max(nb, 1)));
+  if (G == 1 || nb == 0) {
+    tn_plan::GradBucket bk;
+    bk.begin = 0; bk.end = m->n_params; bk.blk_lo = 0; bk.blk_hi = nb - 1; bk.tail = true; bk.prolog = true;
+    p->buckets.push_back(bk);
+  } else {
+    tn_plan::GradBucket tail;
+    tail.begin = m->epi_w; tail.end = m->n_params; tail.tail = true;
+    p->buckets.push_back(tail);
+    int hi = nb - 1;
+    for (int g = 0; g < G; ++g) {
+      const int left = G - g, cnt = (hi + 1 + left - 1) / left;
+      const int lo = hi - cnt + 1;
+      tn_plan::GradBucket bk;
+      bk.blk_lo = lo; bk.blk_hi = hi;
+      bk.begin = lo == 0 ? 0 : m->blocks[lo].sub[0].wdw;
+      bk.end = hi + 1 < nb ? m->blocks[hi + 1].sub[0].wdw : m->epi_w;
+      bk.prolog = lo == 0;
+      p->buckets.push_back(bk);
+      hi = lo - 1;
+    }
+  }
+  Bump b;
+  b.off = p->ws_fixed_bytes;
+  if (p->use_v2 && p->wg2_layers > 0) {
+    // every group's launch cuts its (layer, 32-row chunk) units into one contiguous range per workgroup: the number of
+    // partial slabs a layer can receive is bounded by the smallest group
+    const int chunks = (p->M + 31) / 32;
+    const int per_blk = c.n_sub_blocks + 1;
+    int maxparts = 1;
+    for (const auto& bk : p->buckets) {
+      const int layers = (bk.blk_hi >= bk.blk_lo ? (bk.blk_hi - bk.blk_lo + 1) * per_blk : 0) + (bk.tail ? p->wg2_epi_slabs : 0);
+      if (layers == 0) continue;
+      const long total = (long)layers * chunks;
+      const int upw = (int)((total + p->wg2_grid - 1) / p->wg2_grid);
+      maxparts = std::max(maxparts, (chunks + upw - 1) / upw + 1);
+    }
+    p->wg2_maxparts = maxparts;
+    p->wg2_slabs = b.take((size_t)p->wg2_layers * p->wg2_maxparts * 256 * 256 * sizeof(float));
+  }
+  p->ws_bytes = (b.off + 255) & ~(size_t)255;
+}
+
+extern "C" int tn_plan_set_grad_groups(tn_plan* p, int32_t groups) {
+  if (!p || groups < 1 || groups > 64) return TN_E_BADARG;
+  if (p->bound) return TN_E_STATE;          // changes the workspace size: call before tn_plan_workspace_bytes / tn_plan_bind
+  p->grad_groups = groups;
+  plan_layout_tail(p);
+  return 0;
+}
+extern "C" int32_t tn_plan_num_grad_buckets(const tn_plan* p) { return p ? (int32_t)p->buckets.size() : 0; }
+extern "C" int tn_plan_grad_bucket(const tn_plan* p, int32_t i, int64_t* begin, int64_t* end) {
+  if (!p || i < 0 || i >= (int32_t)p->buckets.size() || !begin || !end) return TN_E_BADARG;
+  *begin = p->buckets[i].begin; *end = p->buckets[i].end;
+  return 0;
+}
+extern "C" int tn_plan_wait_grad_bucket(tn_plan* p, int32_t i, void* stream) {
+  if (!p || i < 0 || i >= (int32_t)p->bucket_events.size()) return TN_E_BADARG;
+  TN_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, p->bucket_events[i], 0));
   return 0;
 }
 
 extern "C" void tn_plan_destroy(tn_plan* p) {
   if (!p) return;
   for (auto e : p->prof_events) (void)hipEventDestroy(e);
+  for (auto e : p->bucket_events) (void)hipEventDestroy(e);
   delete p;
 }
 
@@ -396,6 +463,11 @@ extern "C" int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbu
   TN_CHECK_HIP(hipStreamSynchronize(st));   // host vectors go out of scope
   int rc = plan_upload_bwd_tables(p, st);
   if (rc) return rc;
+  while (p->bucket_events.size() < p->buckets.size()) {
+    hipEvent_t e;
+    TN_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    p->bucket_events.push_back(e);
+  }
   p->bound = true;
   return 0;
 }

@@ -66,6 +66,64 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   TN_CHECK_HIP(hipMemsetAsync(ws + p->bzero_begin, 0, p->bzero_bytes, st));
   const bool batched_wgrad = sizeof(AT) == 2 && (p->use_v2 & 4) && training && p->wg2_layers > 0;
   const bool v2_bwd = sizeof(AT) == 2 && (p->use_v2 & 8);
+  const int nb = c.n_mega_blocks;
+  const int per_blk = nsub + 1;
+  int rc_fin = 0;
+  // ---- everything that turns accumulated sums / kept tensors into the final gradients of ONE bucket, then the bucket's
+  // event: with grad_groups > 1 the data-parallel trainer all-reduces bucket k while the backward of earlier blocks runs
+  auto finalize_bucket = [&](int k) {
+    const tn_plan::GradBucket& bk = p->buckets[k];
+    const bool has_blocks = bk.blk_hi >= bk.blk_lo;
+    if (bk.prolog) {
+      const int cur_ = p->prolog_cur;
+      ProdDy::Args pa{ws + p->dA[cur_], ws + p->Y0, H, make_bnbwd(p, m->prolog_bn, M, training)};
+      ProdIm2col::Args qa{p->last_input, c.n_mels, c.prolog_kernel, T};
+      int rc = launch_wgrad<AT, ProdDy, ProdIm2col>(M, H, c.n_mels * c.prolog_kernel, pa, qa, 0, slabs, p->slab_bytes,
+                                                   grads + m->prolog_w, st);
+      if (rc) { rc_fin = rc; return; }
+    }
+    if (v2_bwd && has_blocks)
+      hipLaunchKernelGGL(dw_grad_finalize_kernel, dim3((bk.blk_hi - bk.blk_lo + 1) * nsub), dim3(256), 0, st,
+                         (const DwGradOut*)(ws + p->dw_table) + (size_t)bk.blk_lo * nsub, c.kernel);
+    if (batched_wgrad) {
+      int first = has_blocks ? bk.blk_lo * per_blk : nb * per_blk;
+      int count = (has_blocks ? (bk.blk_hi - bk.blk_lo + 1) * per_blk : 0) + (bk.tail ? p->wg2_epi_slabs : 0);
+      if (has_blocks && bk.tail && bk.blk_hi != nb - 1) { rc_fin = TN_E_STATE; return; }   // ranges must be contiguous
+      if (count > 0) {
+        const int chunks = (M + 31) / 32;
+        const long total = (long)count * chunks;
+        const int upw = (int)((total + p->wg2_grid - 1) / p->wg2_grid);
+        const size_t smem = (size_t)(2 * WG2_RK * WG2_PITCH + (WG2_RK + 2) * V2_C) * sizeof(bf16_t) + (size_t)(6 + 3) * V2_C * sizeof(float);
+        auto kern = p->save_q ? wgrad_batched_v2_kernel<3, false> : wgrad_batched_v2_kernel<3, true>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+          rc_fin = TN_E_STATE; return;
+        }
+        {
+          ProfScope ps(p, TN_PROF_BWD_WGRAD, st);
+          hipLaunchKernelGGL(kern, dim3(p->wg2_grid), dim3(V2_NT), smem, st, (const WgradV2Desc*)(ws + p->wg2_desc) + first, count, M, T,
+                             chunks, upw, (int*)(ws + p->wg2_count) + first, seed);
+        }
+        hipLaunchKernelGGL(wgrad_v2_reduce_kernel, dim3(32, count), dim3(256), 0, st, (const WgradV2Out*)(ws + p->wg2_out) + first,
+                           (const int*)(ws + p->wg2_count) + first);
+      }
+    }
+    // gradients that are functions of the accumulated sums: BatchNorm affine + conv biases, SE weights
+    const BnGradDesc* bt = (const BnGradDesc*)(ws + (training ? p->bwd_table : p->bwd_table_eval));
+    auto bn_range = [&](int lo, int hi) {      // BN ids [lo, hi)
+      if (hi > lo) hipLaunchKernelGGL(bn_param_grad_kernel, dim3(2, hi - lo), dim3(256), 0, st, bt + lo);
+    };
+    if (bk.prolog && has_blocks && bk.tail) bn_range(0, m->n_bn);
+    else {
+      if (bk.prolog) bn_range(0, 1);
+      if (has_blocks) bn_range(1 + per_blk * bk.blk_lo, 1 + per_blk * (bk.blk_hi + 1));
+      if (bk.tail) bn_range(1 + per_blk * nb, m->n_bn);
+    }
+    if (has_blocks)
+      hipLaunchKernelGGL(se_wgrad_kernel, dim3((2 * H * Hr + 255) / 256, bk.blk_hi - bk.blk_lo + 1), dim3(256), 0, st,
+                         (const SeGradDesc*)(ws + p->se_table) + bk.blk_lo, B, H, Hr);
+    if (k < (int)p->bucket_events.size()) (void)hipEventRecord(p->bucket_events[k], st);
+  };
+  const bool grouped = p->buckets.size() > 1;
 
   // ================= loss head -> d emb =================
   {
@@ -187,7 +245,6 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     }
   }
   // ================= epilog 1x1 conv =================
-  const int nb = c.n_mega_blocks;
   const void* x_last = nb > 0 ? (const void*)(ws + p->blk[nb - 1].OUT) : (const void*)(ws + p->Y0);
   BnAct act0 = make_act(p, m->prolog_bn, M, training, 1, 0.f, seed, 0);
   BnAct act_last = nb > 0 ? identity_act() : act0;
@@ -215,7 +272,9 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     }
     if (rc) return rc;
   }
+  if (grouped) { finalize_bucket(0); if (rc_fin) return rc_fin; }
   // ================= mega blocks, last to first =================
+  int next_bucket = grouped ? 1 : 0;
   for (int i = nb - 1; i >= 0; --i) {
     const MegaBlockRef& mb = m->blocks[i];
     BlockWs& bw = p->blk[i];
@@ -365,6 +424,10 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       if (rc) return rc;
     }
     cur ^= 1;
+    if (grouped && next_bucket < (int)p->buckets.size() && p->buckets[next_bucket].blk_lo == i && !p->buckets[next_bucket].prolog) {
+      finalize_bucket(next_bucket++);
+      if (rc_fin) return rc_fin;
+    }
   }
   // ================= prolog conv =================
   {
@@ -372,42 +435,18 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       // no mega blocks: dA[cur] holds d act0(Y0); push it through the prolog relu/BN mask
       return TN_E_UNSUPPORTED;
     }
-    ProdDy::Args pa{ws + p->dA[cur], ws + p->Y0, H, make_bnbwd(p, m->prolog_bn, M, training)};
-    const float* spec = p->last_input;
-    ProdIm2col::Args qa{spec, c.n_mels, c.prolog_kernel, T};
-    int rc = launch_wgrad<AT, ProdDy, ProdIm2col>(M, H, c.n_mels * c.prolog_kernel, pa, qa, 0, slabs, p->slab_bytes,
-                                                 grads + m->prolog_w, st);
-    if (rc) return rc;
+    p->prolog_cur = cur;
     if (grad_input) {
+      ProdDy::Args pa{ws + p->dA[cur], ws + p->Y0, H, make_bnbwd(p, m->prolog_bn, M, training)};
       const int n = B * c.n_mels * T;
       hipLaunchKernelGGL(prolog_input_grad_kernel<AT>, dim3((n + 255) / 256), dim3(256), 0, st, (const AT*)(ws + p->dA[cur]),
                          (const AT*)(ws + p->Y0), pa.bn, params + m->prolog_w, B, c.n_mels, T, H, c.prolog_kernel, grad_input);
     }
   }
-  if (v2_bwd && nb > 0) {
-    hipLaunchKernelGGL(dw_grad_finalize_kernel, dim3(nb * nsub), dim3(256), 0, st, (const DwGradOut*)(ws + p->dw_table), c.kernel);
-  }
-  // ================= all mega-block pointwise weight gradients in one launch (v2) =================
-  if (batched_wgrad) {
-    const int chunks = (M + 31) / 32;
-    const size_t smem = (size_t)(2 * WG2_RK * WG2_PITCH + (WG2_RK + 2) * V2_C) * sizeof(bf16_t) + (size_t)(6 + 3) * V2_C * sizeof(float);
-    auto kern = p->save_q ? wgrad_batched_v2_kernel<3, false> : wgrad_batched_v2_kernel<3, true>;
-    TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    {
-      ProfScope ps(p, TN_PROF_BWD_WGRAD, st);
-      hipLaunchKernelGGL(kern, dim3(p->wg2_grid), dim3(V2_NT), smem, st, (const WgradV2Desc*)(ws + p->wg2_desc), p->wg2_layers, M, T,
-                         chunks, p->wg2_units_per_wg, (int*)(ws + p->wg2_count), seed);
-    }
-    hipLaunchKernelGGL(wgrad_v2_reduce_kernel, dim3(32, p->wg2_layers), dim3(256), 0, st, (const WgradV2Out*)(ws + p->wg2_out),
-                       (const int*)(ws + p->wg2_count));
-  }
-  // ================= gradients that are functions of the accumulated sums =================
-  hipLaunchKernelGGL(bn_param_grad_kernel, dim3(2, m->n_bn), dim3(256), 0, st,
-                     (const BnGradDesc*)(ws + (training ? p->bwd_table : p->bwd_table_eval)));
-  if (nb > 0) {
-    hipLaunchKernelGGL(se_wgrad_kernel, dim3((2 * H * Hr + 255) / 256, nb), dim3(256), 0, st,
-                       (const SeGradDesc*)(ws + p->se_table), B, H, Hr);
-  }
+  // ================= the last bucket (the only one without grouping): prolog weight gradient, the deferred pointwise
+  // weight gradients (v2: all of the bucket's layers in one balanced launch), sums -> BatchNorm / bias / SE gradients
+  finalize_bucket((int)p->buckets.size() - 1);
+  if (rc_fin) return rc_fin;
   return (int)hipGetLastError();
 }
 

@@ -81,6 +81,7 @@ struct tn_plan {
   int use_v2 = 0;           // specialised hidden=256 bf16 kernels (tn_v2_kernels.h)
   size_t esz;               // activation element size
   size_t ws_bytes = 0;
+  size_t ws_fixed_bytes = 0;    // end of the part of the layout that does not depend on grad_groups
   // bound buffers
   float* params = nullptr;
   float* grads = nullptr;
@@ -123,6 +124,17 @@ struct tn_plan {
   size_t dw_gacc, dw_table;                         // depthwise gradient accumulators [layer][NREP][KD+1][256] + finalize table
   int wg2_layers = 0, wg2_maxparts = 0, wg2_units_per_wg = 0, wg2_grid = 0, wg2_epi_slabs = 0;
   size_t bwd_table_bytes = 0;
+  // gradient buckets in COMPLETION order (data-parallel overlap: bucket i's all-reduce starts when its event fires)
+  struct GradBucket {
+    int64_t begin = 0, end = 0;   // float range in the flat gradient buffer
+    int blk_lo = 0, blk_hi = -1;  // mega blocks finalised with this bucket (inclusive), or empty
+    bool tail = false;            // epilog conv, pooling, decoder tail, loss head
+    bool prolog = false;          // prolog conv + BN
+  };
+  int prolog_cur = 0;             // which dA buffer holds the gradient wrt the prolog output (set by backward)
+  int grad_groups = 1;            // 1: one bucket, every deferred weight gradient in one launch at the end of backward
+  std::vector<GradBucket> buckets;
+  std::vector<hipEvent_t> bucket_events;
   // per-kernel event timing (tn_profile_*)
   int prof_class = 0;
   std::vector<hipEvent_t> prof_events;
@@ -140,6 +152,7 @@ int plan_backward(tn_plan* p, float grad_scale, const float* grad_scale_dev, con
                   hipStream_t st);
 
 int plan_upload_bwd_tables(tn_plan* p, hipStream_t st);
+void plan_layout_tail(tn_plan* p);   // workspace regions whose size depends on grad_groups (end of the layout)
 
 // bracket a launch with events when its class is being profiled
 struct ProfScope {

@@ -118,6 +118,7 @@ class TitaNet(nn.Module):
         self._step = 0
         self._seed_base = int(torch.initial_seed()) & 0xFFFFFFFFFFFF
         self._opt_state = None
+        self.grad_groups = 1         # > 1: tn_backward finalises the gradient in 1 + grad_groups buckets (data-parallel overlap)
 
         # ---- flat storage + mirrored module tree
         dev = torch.device(device)
@@ -318,6 +319,8 @@ class TitaNet(nn.Module):
             self._lib.tn_plan_destroy(old.handle)
         handle = C.c_void_p()
         check(self._lib.tn_plan_create(self._model, batch, frames, self._prec(), C.byref(handle)), "tn_plan_create")
+        if self.grad_groups > 1:
+            check(self._lib.tn_plan_set_grad_groups(handle, int(self.grad_groups)), "tn_plan_set_grad_groups")
         nbytes = int(self._lib.tn_plan_workspace_bytes(handle))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=flat.device)
         if self._flat_gtmp is None:
@@ -326,6 +329,11 @@ class TitaNet(nn.Module):
         check(self._lib.tn_plan_bind(handle, _ptr(flat), _ptr(self._flat_gtmp), _ptr(self._flat["bnbuf"]),
                                      _ptr(self._flat["nbt"]), _ptr(ws), nbytes, C.c_void_p(stream)), "tn_plan_bind")
         plan = _Plan(handle, ws, key)
+        plan.buckets = []
+        lo, hi = C.c_int64(), C.c_int64()
+        for i in range(int(self._lib.tn_plan_num_grad_buckets(handle))):
+            check(self._lib.tn_plan_grad_bucket(handle, i, C.byref(lo), C.byref(hi)), "tn_plan_grad_bucket")
+            plan.buckets.append((lo.value, hi.value))
         self._plans[key] = plan
         return plan
 

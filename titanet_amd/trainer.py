@@ -10,7 +10,9 @@ Data parallelism (new — the reference is single-device): one process per GPU, 
 batch sharded contiguously over ranks, BatchNorm statistics local to each rank (DDP semantics), the
 flat float32 gradient buffer summed with RCCL (``torch.distributed`` backend "nccl" == RCCL on ROCm)
 in a few large buckets sized for the xGMI links (fewer, larger collectives), the 1/world factor folded
-into the fused Adam kernel.  The collective runs on a side stream ordered by events.
+into the fused Adam kernel.  The collectives run on a side stream and OVERLAP backward: tn_backward finalises the
+gradient bucket by bucket from the decoder side down and records an event per bucket (include/titanet_amd.h,
+"gradient buckets"); each bucket's all-reduce is enqueued behind its event.
 
 ``use_graph=True`` (single GPU): the whole step — ~470 kernel launches for TitaNet-S — is captured once per input shape
 into ONE hipGraph and replayed; the per-step state that used to be kernel arguments (dropout stream, Adam step count)
@@ -45,6 +47,25 @@ class FlatAllReducer:
         self.n_buckets, self.group = n_buckets, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self._stream = None
+
+    def all_reduce_overlapped_(self, flat, plan, lib):
+        """The overlapped form: backward has been ENQUEUED on the current stream and records one event per gradient bucket
+        (completion order: decoder side first, include/titanet_amd.h "gradient buckets").  Each bucket's all-reduce is
+        enqueued on the communication stream behind its event, so RCCL moves bucket i over xGMI while the kernels of the
+        mega blocks below it still run; the current stream only waits for the last collective."""
+        if self.world == 1:
+            return flat
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=flat.device)
+        cur = torch.cuda.current_stream(flat.device)
+        with torch.cuda.stream(self._stream):
+            for i, (lo, hi) in enumerate(plan.buckets):
+                check(lib.tn_plan_wait_grad_bucket(plan.handle, i, C.c_void_p(self._stream.cuda_stream)), "tn_plan_wait_grad_bucket")
+                dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+            done = torch.cuda.Event()
+            done.record(self._stream)
+        cur.wait_event(done)
+        return flat
 
     def all_reduce_(self, flat):
         if self.world == 1:
@@ -89,6 +110,10 @@ class Trainer:
             # replicas start identical (rank 0's weights), as DDP does
             dist.broadcast(flat, src=0, group=group)
             dist.broadcast(model._flat["bnbuf"], src=0, group=group)
+            # backward finalises the gradient in 1 + n_buckets buckets, each all-reduced as soon as it is final
+            if model.grad_groups != n_buckets and n_buckets > 1:
+                model.grad_groups = n_buckets
+                model._drop_plans()
 
     def forward_backward(self, spectrograms, speakers):
         """forward + backward into the flat gradient buffer; returns (embeddings, preds, loss)."""
@@ -98,6 +123,7 @@ class Trainer:
         stream = torch.cuda.current_stream(dev).cuda_stream
         vp = C.c_void_p
         check(m._lib.tn_backward(plan.handle, C.c_float(1.0), vp(0), vp(0), vp(0), vp(stream)), "tn_backward")
+        self._last_plan = plan
         return emb, preds, loss
 
     def optimizer_step(self):
@@ -115,7 +141,11 @@ class Trainer:
         if self.use_graph:
             return self._graph_step(spectrograms, speakers)
         out = self.forward_backward(spectrograms, speakers)
-        self.reducer.all_reduce_(self.model.flat_gradients())
+        grads = self.model.flat_gradients()
+        if grads.is_cuda and len(self._last_plan.buckets) > 1:
+            self.reducer.all_reduce_overlapped_(grads, self._last_plan, self.model._lib)
+        else:
+            self.reducer.all_reduce_(grads)
         self.optimizer_step()
         return out
 
