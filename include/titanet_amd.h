@@ -124,7 +124,7 @@ int tn_backward(tn_plan* p, float grad_scale, const float* grad_scale_dev, const
  * event.  A trainer enqueues, per bucket i, tn_plan_wait_grad_bucket(i, comm_stream) + ncclAllReduce on comm_stream: the
  * collective of bucket i then runs under the backward of the blocks below it (titanet_amd/trainer.py).  G = 1 (default):
  * one bucket, every deferred weight gradient in one launch at the end of backward (fastest on a single GPU). */
-int tn_plan_set_grad_groups(tn_plan* p, int32_t groups);
+int tn_plan_set_grad_groups(tn_plan* p, int32_t groups); /* after tn_plan_bind: only if the new layout fits the bound workspace */
 int32_t tn_plan_num_grad_buckets(const tn_plan* p);
 int tn_plan_grad_bucket(const tn_plan* p, int32_t i, int64_t* begin_float, int64_t* end_float);
 /* hipStreamWaitEvent(stream, event of bucket i of the last tn_backward) */

@@ -24,8 +24,47 @@ B, T, P, SEED = 256, 300, 0.1, 424242
 CFG2 = dict(n_mels=80, n_mega_blocks=2, hidden=256, enc_out=1536, emb=192, kernel=3, attn_hidden=128)
 ARC = dict(scale=30, margin=0.2)
 
-# budgets = ~2x what the kernels measure on MI355X (printed by the test); bf16 has 8 mantissa bits (2^-9 = 2e-3 per rounding)
-BUDGET = {"prolog_out": 6e-3, "block_out:0": 1.5e-2, "block_out:1": 2.5e-2, "pooled": 3e-2, "embeddings": 4e-2, "logits": 5e-2}
+# Two oracles.  "plain": the float32 restatement of the reference — the distance to it is what bf16 storage costs.
+# "emu": the same restatement with every tensor the bf16 plan stores / feeds to an MFMA rounded to bfloat16 at the same
+# points (OracleConfig.store_round) — the distance to it is what the KERNELS add on top of the declared storage format
+# (accumulation order, the bf16 gradients of the backward pass), and it is the sharp parity statement at this shape.
+# Budgets = ~2x the values measured on MI355X (printed by the test).
+# Measured (MI355X, CE / ArcFace alike): plain 3.6e-3 / 6.1e-3 / 8.5e-3 / 1.2e-3 / 1.6e-2 / 1.6e-2, gradient cosine 0.9947;
+# emu 3.3e-5 / 2.0e-3 / 4.6e-3 / 7.8e-4 / 1.0e-2 / 1.0e-2, gradient cosine 0.9979.  The emulation is exact through the first
+# stored tensor (3e-5 = a few flipped roundings) and then saturates at the bf16 rounding-noise floor: two bf16 computations
+# whose pre-rounding values differ at all (here: MFMA vs sgemm summation order) decorrelate to ~ulp / sqrt(3) per storage
+# step within one mega block.  The same mechanism bounds what a gradient comparison can show at a RANDOM initialisation:
+# ~0.5 % of the ReLU / dropout-survivor decisions differ, and a random-walk gradient sum then differs by ~sqrt(0.5 %) = 7 %.
+BUDGET_PLAIN = {"prolog_out": 8e-3, "block_out:0": 1.5e-2, "block_out:1": 2e-2, "pooled": 5e-3, "embeddings": 4e-2, "logits": 4e-2}
+BUDGET_EMU = {"prolog_out": 2e-4, "block_out:0": 5e-3, "block_out:1": 1e-2, "pooled": 2.5e-3, "embeddings": 2.5e-2, "logits": 2.5e-2}
+GRAD_KEYS = ("encoder.mega_blocks.1.sub_blocks.2.conv_block.0.conv.1.weight", "encoder.mega_blocks.0.sub_blocks.0.conv_block.0.conv.1.weight",
+             "encoder.mega_blocks.0.skip_connection.0.weight", "encoder.epilog.conv_block.0.weight",
+             "encoder.mega_blocks.1.sub_blocks.1.conv_block.0.conv.0.weight", "decoder.pool.0.in_linear.weight",
+             "decoder.linear.0.weight", "loss_function.fc.weight", "encoder.prolog.conv_block.0.weight")
+
+
+def _oracle(case, loss, emulate):
+    sd = case_state_dict(case, loss, torch.float32)
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running_" not in k:
+            v.requires_grad_(True)
+    xo, yo = case_inputs(case, torch.float32)
+    cfg = oracle_cfg(case, dropout=P)
+    if emulate:
+        cfg.store_round = O.bf16_store
+    kw = dict(loss="ce") if loss == "ce" else dict(loss="margin", loss_kwargs=O.margin_kwargs("arc", **ARC))
+    out = O.titanet_forward(sd, xo, cfg, training=True, speakers=yo, mask_fn=mask_fn_for(SEED, P), keep_inter=True, **kw)
+    out.loss.backward()
+    layers = {"prolog_out": out.inter["encoder.prolog.out"], "block_out:0": out.inter["encoder.mega_blocks.0.out"],
+              "block_out:1": out.inter["encoder.mega_blocks.1.out"], "pooled": out.inter["decoder.pool.0.out"],
+              "logits": out.logits.detach(), "embeddings": out.normalized.detach()}
+    layers = {k: v.numpy().copy() for k, v in layers.items()}
+    grads = {k: v.grad.numpy().copy() for k, v in sd.items() if v.dtype.is_floating_point and v.grad is not None}
+    return layers, grads, float(out.loss), out.preds.clone()
+
+
+def _flat(g, keys):
+    return np.concatenate([g[k].ravel() for k in keys])
 
 
 @pytest.mark.parametrize("loss", ["ce", "arc"])
@@ -35,50 +74,45 @@ def test_bf16_train_step_at_bench_shape_vs_oracle(loss):
     m._seed_base, m._step = SEED, 0
     x, y = case_inputs(case, torch.float32)
     emb, preds, lv = m(x.cuda(), speakers=y.cuda())
-    fetched = {"prolog_out": m.debug_fetch("prolog_out", (B, 256, T)).cpu().numpy(),
-               "block_out:0": m.debug_fetch("block_out:0", (B, 256, T)).cpu().numpy(),
-               "block_out:1": m.debug_fetch("block_out:1", (B, 256, T)).cpu().numpy(),
-               "pooled": m.debug_fetch("pooled", (B, 3072)).cpu().numpy(),
-               "logits": m.debug_fetch("logits", (B, 251)).cpu().numpy()}
+    got = {"prolog_out": m.debug_fetch("prolog_out", (B, 256, T)).cpu().numpy(),
+           "block_out:0": m.debug_fetch("block_out:0", (B, 256, T)).cpu().numpy(),
+           "block_out:1": m.debug_fetch("block_out:1", (B, 256, T)).cpu().numpy(),
+           "pooled": m.debug_fetch("pooled", (B, 3072)).cpu().numpy(),
+           "logits": m.debug_fetch("logits", (B, 251)).cpu().numpy(),
+           "embeddings": emb.detach().cpu().numpy()}
     lv.backward()
     torch.cuda.synchronize()
-
-    torch.set_num_threads(min(32, torch.get_num_threads() * 4))
-    sd = case_state_dict(case, loss, torch.float32)
-    for k, v in sd.items():
-        if v.dtype.is_floating_point and "running_" not in k:
-            v.requires_grad_(True)
-    xo, yo = case_inputs(case, torch.float32)
-    kw = dict(loss="ce") if loss == "ce" else dict(loss="margin", loss_kwargs=O.margin_kwargs("arc", **ARC))
-    out = O.titanet_forward(sd, xo, oracle_cfg(case, dropout=P), training=True, speakers=yo, mask_fn=mask_fn_for(SEED, P),
-                            keep_inter=True, **kw)
-    out.loss.backward()
-    want = {"prolog_out": out.inter["encoder.prolog.out"], "block_out:0": out.inter["encoder.mega_blocks.0.out"],
-            "block_out:1": out.inter["encoder.mega_blocks.1.out"], "pooled": out.inter["decoder.pool.0.out"],
-            "logits": out.logits}
-    errs = {k: rel_err(fetched[k], want[k].detach().numpy().reshape(fetched[k].shape)) for k in fetched}
-    errs["embeddings"] = rel_err(emb.detach().cpu().numpy(), out.normalized.detach().numpy())
-    print(loss, "layer errors:", {k: f"{v:.2e}" for k, v in errs.items()}, "loss", lv.item(), out.loss.item())
-    for k, v in errs.items():
-        assert v < BUDGET[k], (k, v, BUDGET[k])
-    assert abs(lv.item() - out.loss.item()) < 2e-2 * max(1.0, abs(out.loss.item()))
-    agree = float((preds.cpu() == out.preds).float().mean())
-    assert agree > 0.9, agree
-
     named = dict(m.named_parameters())
-    a = np.concatenate([named[k].grad.detach().cpu().numpy().ravel() for k in named])
-    b = np.concatenate([sd[k].grad.numpy().ravel() for k in named])
-    cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
-    per = {}
-    for k in ("encoder.mega_blocks.1.sub_blocks.2.conv_block.0.conv.1.weight", "encoder.mega_blocks.0.sub_blocks.0.conv_block.0.conv.1.weight",
-              "encoder.mega_blocks.0.skip_connection.0.weight", "encoder.epilog.conv_block.0.weight",
-              "encoder.mega_blocks.1.sub_blocks.1.conv_block.0.conv.0.weight", "decoder.pool.0.in_linear.weight",
-              "decoder.linear.0.weight", "loss_function.fc.weight", "encoder.prolog.conv_block.0.weight"):
-        per[k] = rel_err(named[k].grad.detach().cpu().numpy(), sd[k].grad.numpy())
-    print(loss, "gradient cosine", cos, {k.split("encoder.")[-1]: f"{v:.2e}" for k, v in per.items()})
-    assert cos > 0.995, cos
-    for k, v in per.items():
-        assert v < 0.12, (k, v)
+    ggrad = {k: named[k].grad.detach().cpu().numpy() for k in named}
+    keys = list(named)
+    torch.set_num_threads(min(64, max(8, torch.get_num_threads())))
+    res = {}
+    for tag, emulate, budget in (("plain", False, BUDGET_PLAIN), ("emu", True, BUDGET_EMU)):
+        layers, grads, oloss, opreds = _oracle(case, loss, emulate)
+        errs = {k: rel_err(got[k], layers[k].reshape(got[k].shape)) for k in got}
+        a, b = _flat(ggrad, keys), _flat(grads, keys)
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+        per = {k: rel_err(ggrad[k], grads[k]) for k in GRAD_KEYS}
+        agree = float((preds.cpu() == opreds).float().mean())
+        print(f"[{loss} vs {tag}] layers", {k: f"{v:.2e}" for k, v in errs.items()}, f"loss {lv.item():.5f} / {oloss:.5f} preds agree {agree:.3f}")
+        print(f"[{loss} vs {tag}] gradient cosine {cos:.5f}", {k.split('encoder.')[-1]: f"{v:.2e}" for k, v in per.items()})
+        res[tag] = (errs, cos, per, oloss, agree, grads)
+        for k, v in errs.items():
+            assert v < budget[k], (tag, k, v, budget[k])
+    # what bf16 storage costs at a random initialisation (ReLU / dropout-survivor sign flips of ~1 % of the elements make a
+    # random-walk gradient sum differ by ~sqrt(1 %)): the emulating oracle shows the same distance to the plain one
+    pg, eg = _flat(res["plain"][5], keys), _flat(res["emu"][5], keys)
+    cos_pe = float(pg @ eg / (np.linalg.norm(pg) * np.linalg.norm(eg)))
+    print(f"[{loss}] emu vs plain oracle gradient cosine {cos_pe:.5f}")
+    assert abs(lv.item() - res["plain"][3]) < 2e-2 * max(1.0, abs(res["plain"][3]))
+    assert abs(lv.item() - res["emu"][3]) < 5e-3 * max(1.0, abs(res["emu"][3]))
+    assert res["plain"][4] > 0.9 and res["emu"][4] > 0.97
+    assert res["plain"][1] > 0.99 and res["plain"][1] > cos_pe - 0.003      # no worse than the storage format itself
+    assert res["emu"][1] > 0.996, res["emu"][1]
+    for k, v in res["emu"][2].items():
+        assert v < 0.2, (k, v)
+    for k, v in res["plain"][2].items():
+        assert v < 0.3, (k, v)
 
 
 def test_bf16_vs_fp32_plan_layerwise_drift_full_s17():

@@ -91,19 +91,30 @@ def test_two_rank_model_step_same_device():
 
 
 def test_gradient_grouping_does_not_change_the_gradient():
-    """grad_groups = 1 (one deferred weight-gradient launch) vs 4 (per-bucket launches, events): same forward, same
-    dropout stream -> same gradient up to the split-K summation order of the pointwise weight gradients."""
+    """grad_groups = 1 (one deferred weight-gradient launch at the end) vs 4 (per-bucket launches + events) on the SAME
+    forward: backward is repeatable from one forward and linear in it, so the two gradients may differ only by the
+    summation order of the split-K slabs and of the atomics-accumulated BatchNorm sums.  (Two separate FORWARD runs would
+    not be comparable this tightly: bf16 storage makes a randomly initialised train-mode network chaotic)"""
+    import ctypes as C
+    from titanet_amd._lib import check
     x, y = _shard(0, per=32, T=300)
+    m = _model("ce", groups=4, seed=5)          # the workspace is sized for the larger slab region
+    m._seed_base, m._step = 99, 0
+    m._native_forward(x, y)
+    plan = m._active_plan
+    stream = torch.cuda.current_stream().cuda_stream
     gs = {}
-    for groups in (1, 4):
-        m = _model("ce", groups=groups, seed=5)
-        m._seed_base, m._step = 99, 0
-        _, _, lv = m(x, speakers=y)
-        lv.backward()
+    for groups in (4, 1, 4):
         torch.cuda.synchronize()
-        gs[groups] = m.flat_gradients().clone()
-        assert len(m._active_plan.buckets) == (1 if groups == 1 else 5)
-        del m
-    err = float((gs[1] - gs[4]).norm() / gs[1].norm())
-    print("grouped vs ungrouped gradient rel diff:", err)
-    assert err < 2e-3, err              # BatchNorm-statistic atomics and slab order reorder f32 sums; bf16 operands are identical
+        check(m._lib.tn_plan_set_grad_groups(plan.handle, groups), "tn_plan_set_grad_groups")
+        m._read_buckets(plan)
+        assert len(plan.buckets) == (1 if groups == 1 else 5)
+        check(m._lib.tn_backward(plan.handle, C.c_float(1.0), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), C.c_void_p(stream)), "tn_backward")
+        torch.cuda.synchronize()
+        gs.setdefault(groups, []).append(m.flat_gradients().clone())
+    ref = gs[1][0]
+    d_group = float((gs[4][0] - ref).norm() / ref.norm())
+    d_repeat = float((gs[4][0] - gs[4][1]).norm() / ref.norm())
+    print(f"grouped vs ungrouped gradient rel diff {d_group:.2e}; same grouping repeated {d_repeat:.2e}")
+    assert d_group < 1e-3, d_group
+    assert torch.isfinite(ref).all() and float(ref.norm()) > 0

@@ -112,3 +112,27 @@ def test_margin_head_at_the_cos_clamp_vs_reference_golden(name):
         assert np.isnan(want).any() and np.isfinite(want).any()
         ok = np.isfinite(want)
         assert rel_err(got[ok], want[ok]) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["tiny_k3", "mid_k3"])
+def test_eager_module_graph_matches_reference_goldens(name):
+    """oracle/eager_modules.py (what bench.py's cpu_baseline times: the reference's nn.Module graph rebuilt from its
+    structure) loads the reference's state_dict keys and reproduces the reference's outputs."""
+    from oracle.eager_modules import EagerTitaNet
+    case, g = CASES[name], load_golden(name)
+    c = case["cfg"]
+    for loss in ("ce", "arc"):
+        m = EagerTitaNet(n_mels=c["n_mels"], n_mega_blocks=c["n_mega_blocks"], hidden=c["hidden"], enc_out=c["enc_out"], emb=c["emb"],
+                         kernel=c["kernel"], attn_hidden=c["attn_hidden"], dropout=0.0, loss=loss, n_classes=case["n_classes"]).double()
+        sd = case_state_dict(case, loss, torch.float64)
+        assert list(m.state_dict().keys()) == list(sd.keys())
+        m.load_state_dict(sd)
+        x, y = case_inputs(case, torch.float64)
+        m.eval()
+        with torch.no_grad():
+            assert rel_err(m(x).numpy(), g["eval.f64.embeddings"]) < 1e-10
+        m.train()
+        emb, preds, lv = m(x, y)
+        assert abs(lv.item() - float(g[f"train.{loss}.loss"])) < 1e-9 * max(1.0, abs(float(g[f"train.{loss}.loss"])))
+        assert rel_err(emb.detach().numpy(), g[f"train.{loss}.embeddings"]) < 1e-9
+        assert np.array_equal(preds.numpy(), g[f"train.{loss}.preds"])

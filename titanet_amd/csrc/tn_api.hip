@@ -348,9 +348,24 @@ void plan_layout_tail(tn_plan* p) {
 
 extern "C" int tn_plan_set_grad_groups(tn_plan* p, int32_t groups) {
   if (!p || groups < 1 || groups > 64) return TN_E_BADARG;
-  if (p->bound) return TN_E_STATE;          // changes the workspace size: call before tn_plan_workspace_bytes / tn_plan_bind
+  const int old = p->grad_groups;
   p->grad_groups = groups;
   plan_layout_tail(p);
+  if (!p->bound) return 0;
+  // already bound: allowed when the new layout fits the bound workspace (the region sized by the groups is the last one);
+  // re-uploads the descriptor tables (synchronises the given plan's stream 0: not for use inside a capture)
+  if (p->ws_bytes > p->bound_bytes) {
+    p->grad_groups = old;
+    plan_layout_tail(p);
+    return TN_E_STATE;
+  }
+  int rc = plan_upload_bwd_tables(p, 0);
+  if (rc) return rc;
+  while (p->bucket_events.size() < p->buckets.size()) {
+    hipEvent_t e;
+    TN_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    p->bucket_events.push_back(e);
+  }
   return 0;
 }
 extern "C" int32_t tn_plan_num_grad_buckets(const tn_plan* p) { return p ? (int32_t)p->buckets.size() : 0; }
@@ -400,6 +415,7 @@ extern "C" int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbu
   if (workspace_bytes < p->ws_bytes) return TN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   p->params = params; p->grads = grads; p->bnbuf = bnbuf; p->nbt = nbt; p->ws = (char*)workspace;
+  p->bound_bytes = workspace_bytes;
   TN_CHECK_HIP(hipMemsetAsync(p->ws + p->step_state, 0, 64, st));
   const tn_model* m = p->model;
   const tn_config& c = m->cfg;

@@ -81,6 +81,7 @@ struct tn_plan {
   int use_v2 = 0;           // specialised hidden=256 bf16 kernels (tn_v2_kernels.h)
   size_t esz;               // activation element size
   size_t ws_bytes = 0;
+  size_t bound_bytes = 0;       // size of the workspace handed to tn_plan_bind
   size_t ws_fixed_bytes = 0;    // end of the part of the layout that does not depend on grad_groups
   // bound buffers
   float* params = nullptr;

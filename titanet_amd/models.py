@@ -329,13 +329,17 @@ class TitaNet(nn.Module):
         check(self._lib.tn_plan_bind(handle, _ptr(flat), _ptr(self._flat_gtmp), _ptr(self._flat["bnbuf"]),
                                      _ptr(self._flat["nbt"]), _ptr(ws), nbytes, C.c_void_p(stream)), "tn_plan_bind")
         plan = _Plan(handle, ws, key)
-        plan.buckets = []
-        lo, hi = C.c_int64(), C.c_int64()
-        for i in range(int(self._lib.tn_plan_num_grad_buckets(handle))):
-            check(self._lib.tn_plan_grad_bucket(handle, i, C.byref(lo), C.byref(hi)), "tn_plan_grad_bucket")
-            plan.buckets.append((lo.value, hi.value))
+        self._read_buckets(plan)
         self._plans[key] = plan
         return plan
+
+    def _read_buckets(self, plan):
+        """gradient buckets of the plan in completion order (include/titanet_amd.h): [(begin, end)] float ranges"""
+        plan.buckets = []
+        lo, hi = C.c_int64(), C.c_int64()
+        for i in range(int(self._lib.tn_plan_num_grad_buckets(plan.handle))):
+            check(self._lib.tn_plan_grad_bucket(plan.handle, i, C.byref(lo), C.byref(hi)), "tn_plan_grad_bucket")
+            plan.buckets.append((lo.value, hi.value))
 
     def _native_forward(self, spectrograms, speakers, fixed_seed=False):
         if spectrograms.dim() != 3 or spectrograms.shape[1] != self._cfg.n_mels:

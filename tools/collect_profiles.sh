@@ -12,10 +12,10 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_
     python bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> gpurun_out/${TAG}_fetch.log
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_write -o w -- \
     python bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> gpurun_out/${TAG}_write.log
-python tools/pmc_summary.py gpurun_out/${TAG}_pmc_traffic.json gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write | head -20
+python tools/pmc_summary.py gpurun_out/${TAG}_pmc_traffic.json --steps 9 gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write | head -20
 find gpurun_out/${TAG}_trace -name "*kernel_stats.csv" | head -2
 # un-profiled run last (this is the line the round reports)
-timeout 300 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2>/dev/null
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2>/dev/null
 tail -c 1500 gpurun_out/${TAG}_bench.json
 # keep the merge-back small: only summaries travel
 find gpurun_out/${TAG}_trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats.csv \;
