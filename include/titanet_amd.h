@@ -103,6 +103,18 @@ int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbuf, int64_t*
 int tn_forward(tn_plan* p, const float* spectrograms, const int64_t* speakers, int32_t training, uint64_t seed,
                float* embeddings, int64_t* preds, float* loss, void* stream);
 
+/* ---- variable-length batches (new: SURVEY.md 8f3 / BASELINE.json configs[3]; the reference zero-pads to the batch maximum
+ * and ignores the lengths, src/datasets.py:63-73, src/learn.py:88) ---------------------------------------------------------
+ * lengths_host: HOST int64 [batch] (what collate_fn returns), 1 <= lengths[b] <= frames, or NULL (== tn_forward).
+ * Frames t >= lengths[b] of utterance b are padding: every layer sees zeros there (the zero padding an un-padded utterance
+ * would get at its end), BatchNorm statistics, the SE mean and the attentive softmax run over the valid frames only, and
+ * padded frames receive no gradient — a padded batch gives every utterance the embedding it has on its own (eval mode
+ * exactly; train mode with the BatchNorm statistics pooled over all valid frames of the batch).  With every length equal
+ * to `frames` the results equal tn_forward's.  Runs the generic kernel templates; the following tn_backward uses the same
+ * lengths.  Not for stream capture (host lengths). */
+int tn_forward_masked(tn_plan* p, const float* spectrograms, const int64_t* lengths_host, const int64_t* speakers,
+                      int32_t training, uint64_t seed, float* embeddings, int64_t* preds, float* loss, void* stream);
+
 /* ---- loss.backward() through the module (reference src/learn.py:117) -------------------------
  * Must follow a tn_forward(training or eval) on the same plan.  Writes d loss / d params into
  * the bound grads buffer (overwrite, not accumulate), scaled by grad_scale (d out / d loss, 1.0

@@ -136,3 +136,37 @@ def test_eager_module_graph_matches_reference_goldens(name):
         assert abs(lv.item() - float(g[f"train.{loss}.loss"])) < 1e-9 * max(1.0, abs(float(g[f"train.{loss}.loss"])))
         assert rel_err(emb.detach().numpy(), g[f"train.{loss}.embeddings"]) < 1e-9
         assert np.array_equal(preds.numpy(), g[f"train.{loss}.preds"])
+
+
+def test_padding_mask_definition_matches_unpadded_utterances():
+    """The padding-mask extension of the oracle (lengths=...) is DEFINED by: a zero-padded batch gives every utterance the
+    result it has on its own.  Eval mode: embeddings of the padded batch == embeddings of each utterance run un-padded
+    (through the reference-pinned, unmasked oracle).  Train mode: lengths == T reproduces the unmasked oracle exactly, and
+    the masked statistics of a ragged batch equal the statistics of the concatenated valid frames."""
+    case = CASES["tiny_k3"]
+    cfg = oracle_cfg(case)
+    sd = case_state_dict(case, "ce", torch.float64)
+    x, y = case_inputs(case, torch.float64)
+    B, T = x.shape[0], x.shape[2]
+    lengths = torch.tensor([T, 9, 23, 30])[:B]
+    xp = x.clone()
+    for b in range(B):
+        xp[b, :, lengths[b]:] = 0.0
+    with torch.no_grad():
+        padded = O.titanet_forward(sd, xp, cfg, training=False, lengths=lengths).normalized
+        for b in range(B):
+            alone = O.titanet_forward(sd, xp[b:b + 1, :, :lengths[b]], cfg, training=False).normalized
+            assert rel_err(padded[b:b + 1].numpy(), alone.numpy()) < 1e-12, b
+        full = O.titanet_forward(sd, x, cfg, training=True, speakers=y, loss="ce", lengths=torch.full((B,), T))
+        ref = O.titanet_forward(sd, x, cfg, training=True, speakers=y, loss="ce")
+        assert abs(full.loss.item() - ref.loss.item()) < 1e-12
+        assert rel_err(full.normalized.numpy(), ref.normalized.numpy()) < 1e-12
+        # masked train-mode statistics: garbage in the padded frames must not change anything
+        xg = xp.clone()
+        for b in range(B):
+            xg[b, :, lengths[b]:] = 7.0
+        a = O.titanet_forward(sd, xp, cfg, training=True, speakers=y, loss="ce", lengths=lengths)
+        g = O.titanet_forward(sd, xg, cfg, training=True, speakers=y, loss="ce", lengths=lengths)
+        assert abs(a.loss.item() - g.loss.item()) < 1e-12
+        k = "encoder.prolog.conv_block.1.running_mean"
+        assert rel_err(a.new_buffers[k].numpy(), g.new_buffers[k].numpy()) < 1e-12

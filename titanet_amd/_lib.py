@@ -18,7 +18,7 @@ EXPORTS = [
     "tn_plan_bind", "tn_forward", "tn_backward", "tn_adam_step", "tn_debug_fetch", "tn_version", "tn_profile_begin",
     "tn_profile_read", "tn_mel_create", "tn_mel_destroy", "tn_mel_num_frames", "tn_mel_forward", "tn_plan_step_tick",
     "tn_plan_step_set", "tn_adam_step_plan", "tn_plan_set_lr", "tn_head_save_floats", "tn_head_forward", "tn_head_backward",
-    "tn_plan_set_grad_groups", "tn_plan_num_grad_buckets", "tn_plan_grad_bucket", "tn_plan_wait_grad_bucket",
+    "tn_forward_masked", "tn_plan_set_grad_groups", "tn_plan_num_grad_buckets", "tn_plan_grad_bucket", "tn_plan_wait_grad_bucket",
 ]
 
 
@@ -71,6 +71,7 @@ def load():
     lib.tn_plan_workspace_bytes.restype = C.c_size_t
     lib.tn_plan_bind.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.tn_forward.argtypes = [vp, vp, vp, i32, C.c_uint64, vp, vp, vp, vp]
+    lib.tn_forward_masked.argtypes = [vp, vp, vp, vp, i32, C.c_uint64, vp, vp, vp, vp]
     lib.tn_backward.argtypes = [vp, f32, vp, vp, vp, vp]
     lib.tn_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]
     lib.tn_plan_step_tick.argtypes = [vp, vp]

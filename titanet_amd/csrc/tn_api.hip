@@ -203,6 +203,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   b.off = p->bzero_begin + p->bzero_bytes;
   // ---- device-resident step state {uint64 step; uint32 word; ...}: cleared once at bind, advanced by tn_plan_step_tick
   p->step_state = b.take(64);
+  p->lens = b.take(sizeof(int) * (size_t)batch);
   // ---- compute-precision weights
   auto wc = [&](size_t n, size_t k) {
     WcRef r; r.w = b.take(n * k * e); r.wt = b.take(n * k * e);
@@ -496,6 +497,18 @@ BnAct identity_act() {
   memset(&a, 0, sizeof(a));
   return a;
 }
+RowMask plan_row_mask(const tn_plan* p) {
+  RowMask m;
+  m.len = p->masked ? (const int*)(p->ws + p->lens) : nullptr;
+  m.T = p->T;
+  return m;
+}
+// identity activation of a stored, already activated [B*T]-row tensor (mega-block outputs): only the padding mask applies
+static BnAct identity_rows(const tn_plan* p) {
+  BnAct a = identity_act();
+  a.rm = plan_row_mask(p);
+  return a;
+}
 
 BnAct make_act(const tn_plan* p, const BnRef& bn, int rows, int training, int relu, float drop_p, uint64_t seed,
                int layer) {
@@ -505,6 +518,12 @@ BnAct make_act(const tn_plan* p, const BnRef& bn, int rows, int training, int re
   a.gamma = p->params + bn.gamma;
   a.beta = p->params + bn.beta;
   a.inv_n = 1.f / (float)rows;
+  if (p->masked && rows == p->M) {
+    a.rm = plan_row_mask(p);
+    // train: the statistics were summed over the valid rows only; eval: the synthetic sums of the running statistics
+    // (bn_eval_prepare_kernel) are built for n = B*T, whatever the lengths
+    if (training) a.inv_n = 1.f / (float)std::max(p->n_valid, 1);
+  }
   a.eps = 1e-5f;
   a.mode = 1;
   a.relu = relu;
@@ -541,6 +560,10 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   float* params = p->params;
   const float pd = c.dropout;
   auto statp = [&](const BnRef& bn) -> float* { return training ? (float*)(ws + p->stats[bn.id]) : nullptr; };
+  // variable-length batches run the generic kernel templates (the mask lives in their activation-on-load and epilogues)
+  const int use_v2 = p->masked ? 0 : p->use_v2;
+  const RowMask rm = plan_row_mask(p);
+  if (p->masked && c.simple_pool) return TN_E_UNSUPPORTED;
 
   TN_CHECK_HIP(hipMemsetAsync(ws + p->zero_begin, 0, p->zero_bytes, st));
   if (p->n_cast > 0) {
@@ -555,8 +578,8 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   // ---- prolog: dense k=3 conv as an im2col GEMM (reference src/models.py:370, :398)
   {
     GemmShape g{M, H, c.n_mels * c.prolog_kernel, wsel<AT>(p, m->prolog_w, p->wprolog)};
-    ProdIm2col::Args pa{spec, c.n_mels, c.prolog_kernel, T};
-    EpiStoreArgs ea{ws + p->Y0, H, params + m->prolog_b, statp(m->prolog_bn)};
+    ProdIm2col::Args pa{spec, c.n_mels, c.prolog_kernel, T, rm.len};
+    EpiStoreArgs ea{ws + p->Y0, H, params + m->prolog_b, statp(m->prolog_bn), rm};
     int rc = gemm_store<AT, ProdIm2col>(g, pa, ea, 0, st);
     if (rc) return rc;
   }
@@ -568,7 +591,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
     // skip connection: 1x1 conv (reference src/models.py:452-455)
     {
       int rc;
-      if (p->use_v2 & 2) {
+      if (use_v2 & 2) {
         SubFwdV2Args va{(const bf16_t*)xin, actx, nullptr, nullptr, (const bf16_t*)(ws + bw.wskip.w), params + mb.bskip,
                         (bf16_t*)(ws + bw.S), statp(mb.bnskip), M, T, 0,
                         bw.wskip.sw ? (const uint4*)(ws + bw.wskip.sw) : nullptr, nullptr};
@@ -576,7 +599,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       } else {
         GemmShape g{M, H, H, wsel<AT>(p, mb.wskip, bw.wskip)};
         ProdPlain::Args pa{xin, H, actx};
-        EpiStoreArgs ea{ws + bw.S, H, params + mb.bskip, statp(mb.bnskip)};
+        EpiStoreArgs ea{ws + bw.S, H, params + mb.bskip, statp(mb.bnskip), rm};
         rc = gemm_store<AT, ProdPlain>(g, pa, ea, 0, st);
       }
       if (rc) return rc;
@@ -588,11 +611,11 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       GemmShape g{M, H, H, wsel<AT>(p, sb.wpw, bw.wpw[j])};
       ProdDw::Args pa{cur, H, acur, params + sb.wdw, params + sb.bdw, c.kernel, T,
                       (p->save_q && training) ? (void*)(ws + bw.Q[j]) : nullptr};
-      EpiStoreArgs ea{ws + bw.Y[j], H, params + sb.bpw, statp(sb.bn)};
+      EpiStoreArgs ea{ws + bw.Y[j], H, params + sb.bpw, statp(sb.bn), rm};
       int rc;
       {
         ProfScope ps(p, TN_PROF_FWD_SUBBLOCK, st);
-        if (p->use_v2 & 1) {
+        if (use_v2 & 1) {
           SubFwdV2Args va{(const bf16_t*)cur, acur, params + sb.wdw, params + sb.bdw, (const bf16_t*)(ws + bw.wpw[j].w),
                           params + sb.bpw, (bf16_t*)(ws + bw.Y[j]), statp(sb.bn), M, T, 0,
                           bw.wpw[j].sw ? (const uint4*)(ws + bw.wpw[j].sw) : nullptr,
@@ -611,7 +634,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       const int CV = H / 8, TG = 512 / CV;
       size_t smem = (size_t)(3 * H + ((Hr + 3) & ~3) + TG * H) * sizeof(float);
       int rc1 = -1000;
-      if (sizeof(AT) == 2 && H == V2_C && Hr == 16 && (p->use_v2 & 1)) {
+      if (sizeof(AT) == 2 && H == V2_C && Hr == 16 && (use_v2 & 1)) {
         SeSqueezeV2Args sa;
         memset(&sa, 0, sizeof(sa));
         sa.Y = (const bf16_t*)cur; sa.act = acur; sa.W1 = params + mb.se_w1; sa.W2 = params + mb.se_w2;
@@ -631,7 +654,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
         ik = 1.f / (1.f - pd);
       }
       int rc2 = -1000;
-      if (sizeof(AT) == 2 && H == V2_C && (p->use_v2 & 1)) {
+      if (sizeof(AT) == 2 && H == V2_C && (use_v2 & 1)) {
         CombineFwdV2Args ca;
         memset(&ca, 0, sizeof(ca));
         ca.S = (const bf16_t*)(ws + bw.S); ca.actS = acts; ca.Y3 = (const bf16_t*)cur; ca.act3 = acur;
@@ -649,11 +672,11 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       }
     }
     xin = ws + bw.OUT;
-    actx = identity_act();
+    actx = identity_rows(p);
   }
   // ---- epilog 1x1 conv (reference src/models.py:384, :404)
   {
-    const bool wide = sizeof(AT) == 2 && (p->use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128;
+    const bool wide = sizeof(AT) == 2 && (use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128;
     if (wide && actx.mode == 0 && !actx.relu && !actx.drop_thr) {
       WideOutArgs wa;
       memset(&wa, 0, sizeof(wa));
@@ -665,7 +688,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
     } else {
       GemmShape g{M, D, H, wsel<AT>(p, m->epi_w, p->wepi)};
       ProdPlain::Args pa{xin, H, actx};
-      EpiStoreArgs ea{ws + p->E, D, params + m->epi_b, statp(m->epi_bn)};
+      EpiStoreArgs ea{ws + p->E, D, params + m->epi_b, statp(m->epi_bn), rm};
       int rc = gemm_store<AT, ProdPlain>(g, pa, ea, 0, st);
       if (rc) return rc;
     }
@@ -677,14 +700,14 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
                        (float*)(ws + p->mu));
     GemmShape gp{B, 2 * D, D, params + m->pool2_w};
     ProdPlain::Args pap{ws + p->mu, D, identity_act()};
-    EpiStoreArgs eap{ws + p->pooled, 2 * D, params + m->pool2_b, nullptr};
+    EpiStoreArgs eap{ws + p->pooled, 2 * D, params + m->pool2_b, nullptr, RowMask{nullptr, 0}};
     int rc = gemm_store<float, ProdPlain>(gp, pap, eap, 0, st);
     if (rc) return rc;
   } else
   // ---- attentive statistics pooling (reference src/models.py:553-584)
   {
     int rc;
-    if (sizeof(AT) == 2 && (p->use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128) {
+    if (sizeof(AT) == 2 && (use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128) {
       WideInArgs wa;
       memset(&wa, 0, sizeof(wa));
       wa.A = (const bf16_t*)(ws + p->E); wa.act = acte; wa.W = (const bf16_t*)wsel<AT>(p, m->asp_win, p->wwin);
@@ -693,11 +716,11 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
     } else {
       GemmShape g1{M, A, D, wsel<AT>(p, m->asp_win, p->wwin)};
       ProdPlain::Args pa1{ws + p->E, D, acte};
-      EpiStoreArgs ea1{ws + p->HID, A, params + m->asp_bin, nullptr};
+      EpiStoreArgs ea1{ws + p->HID, A, params + m->asp_bin, nullptr, RowMask{nullptr, 0}};
       rc = gemm_store<AT, ProdPlain, EpiStoreTanh>(g1, pa1, ea1, 0, st);
     }
     if (rc) return rc;
-    if (sizeof(AT) == 2 && (p->use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128) {
+    if (sizeof(AT) == 2 && (use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128) {
       WideOutArgs wa;
       memset(&wa, 0, sizeof(wa));
       wa.X = (const bf16_t*)(ws + p->HID); wa.W = (const bf16_t*)wsel<AT>(p, m->asp_wout, p->wwout); wa.bias = params + m->asp_bout;
@@ -707,7 +730,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
     } else {
       GemmShape g2{M, D, A, wsel<AT>(p, m->asp_wout, p->wwout)};
       ProdPlain::Args pa2{ws + p->HID, A, identity_act()};
-      EpiStoreArgs ea2{ws + p->EN, D, params + m->asp_bout, nullptr};
+      EpiStoreArgs ea2{ws + p->EN, D, params + m->asp_bout, nullptr, RowMask{nullptr, 0}};
       rc = gemm_store<AT, ProdPlain>(g2, pa2, ea2, 0, st);
     }
     if (rc) return rc;
@@ -748,7 +771,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   }
   if (training) {
     hipLaunchKernelGGL(bn_running_update_kernel, dim3(2, m->n_bn), dim3(256), 0, st, (const BnUpdateDesc*)(ws + p->bn_table),
-                       0.1f, p->nbt, m->n_bn);
+                       0.1f, p->nbt, m->n_bn, M, p->masked ? std::max(p->n_valid, 1) : M);
   }
   p->last_training = training;
   p->last_input = spec;
@@ -770,6 +793,28 @@ extern "C" int tn_forward(tn_plan* p, const float* spectrograms, const int64_t* 
   if (!p || !spectrograms) return TN_E_BADARG;
   if (!p->bound) return TN_E_NOTBOUND;
   if (training && p->B < 2) return TN_E_BADARG;   // BatchNorm1d raises on a batch of 1 in train mode
+  p->masked = false;
+  return plan_forward(p, spectrograms, speakers, training, seed, embeddings, preds, loss, (hipStream_t)stream);
+}
+
+extern "C" int tn_forward_masked(tn_plan* p, const float* spectrograms, const int64_t* lengths_host, const int64_t* speakers,
+                                 int32_t training, uint64_t seed, float* embeddings, int64_t* preds, float* loss, void* stream) {
+  if (!lengths_host) return tn_forward(p, spectrograms, speakers, training, seed, embeddings, preds, loss, stream);
+  if (!p || !spectrograms) return TN_E_BADARG;
+  if (!p->bound) return TN_E_NOTBOUND;
+  if (training && p->B < 2) return TN_E_BADARG;
+  p->lens_host.resize(p->B);
+  long total = 0;
+  for (int b = 0; b < p->B; ++b) {
+    if (lengths_host[b] < 1 || lengths_host[b] > p->T) return TN_E_BADARG;
+    p->lens_host[b] = (int)lengths_host[b];
+    total += lengths_host[b];
+  }
+  if (training && total < 2) return TN_E_BADARG;
+  p->n_valid = (int)total;
+  p->masked = true;
+  // pageable host memory: the runtime stages the bytes before the call returns
+  TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->lens, p->lens_host.data(), sizeof(int) * (size_t)p->B, hipMemcpyHostToDevice, (hipStream_t)stream));
   return plan_forward(p, spectrograms, speakers, training, seed, embeddings, preds, loss, (hipStream_t)stream);
 }
 

@@ -20,6 +20,10 @@ BnBwd make_bnbwd(const tn_plan* p, const BnRef& bn, int rows, int training) {
   b.inv_n = 1.f / (float)rows;
   b.eps = 1e-5f;
   b.batch = training ? 1.f : 0.f;
+  if (p->masked && rows == p->M) {
+    b.rm = plan_row_mask(p);
+    if (training) b.inv_n = 1.f / (float)std::max(p->n_valid, 1);
+  }
   return b;
 }
 
@@ -64,8 +68,11 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
 
   TN_CHECK_HIP(hipMemsetAsync(grads, 0, (size_t)m->n_params * sizeof(float), st));
   TN_CHECK_HIP(hipMemsetAsync(ws + p->bzero_begin, 0, p->bzero_bytes, st));
-  const bool batched_wgrad = sizeof(AT) == 2 && (p->use_v2 & 4) && training && p->wg2_layers > 0;
-  const bool v2_bwd = sizeof(AT) == 2 && (p->use_v2 & 8);
+  const int use_v2 = p->masked ? 0 : p->use_v2;     // variable-length batches: generic templates (see forward)
+  if (p->masked && c.simple_pool) return TN_E_UNSUPPORTED;
+  auto identity_rows = [&]() { BnAct a = identity_act(); a.rm = plan_row_mask(p); return a; };
+  const bool batched_wgrad = sizeof(AT) == 2 && (use_v2 & 4) && training && p->wg2_layers > 0;
+  const bool v2_bwd = sizeof(AT) == 2 && (use_v2 & 8);
   const int nb = c.n_mega_blocks;
   const int per_blk = nsub + 1;
   int rc_fin = 0;
@@ -77,7 +84,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     if (bk.prolog) {
       const int cur_ = p->prolog_cur;
       ProdDy::Args pa{ws + p->dA[cur_], ws + p->Y0, H, make_bnbwd(p, m->prolog_bn, M, training)};
-      ProdIm2col::Args qa{p->last_input, c.n_mels, c.prolog_kernel, T};
+      ProdIm2col::Args qa{p->last_input, c.n_mels, c.prolog_kernel, T, plan_row_mask(p).len};
       int rc = launch_wgrad<AT, ProdDy, ProdIm2col>(M, H, c.n_mels * c.prolog_kernel, pa, qa, 0, slabs, p->slab_bytes,
                                                    grads + m->prolog_w, st);
       if (rc) { rc_fin = rc; return; }
@@ -204,7 +211,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     // d hid_pre = (dEN * W_out) .* (1 - hid^2)
     {
       int rc;
-      if (sizeof(AT) == 2 && (p->use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128) {
+      if (sizeof(AT) == 2 && (use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128) {
         WideInArgs wa;
         memset(&wa, 0, sizeof(wa));
         wa.A = (const bf16_t*)(ws + p->dE); wa.W = (const bf16_t*)wt(p->wwout); wa.H = (const bf16_t*)(ws + p->HID);
@@ -228,7 +235,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     // d x = dHP * W_in + direct term; through the epilog relu -> dEbn (+ BN backward sums)
     {
       int rc;
-      if (sizeof(AT) == 2 && (p->use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128) {
+      if (sizeof(AT) == 2 && (use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128) {
         WideOutArgs wa;
         memset(&wa, 0, sizeof(wa));
         wa.X = (const bf16_t*)(ws + p->dHP); wa.W = (const bf16_t*)wt(p->wwin); wa.Y = (bf16_t*)(ws + p->dEbn);
@@ -247,7 +254,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   // ================= epilog 1x1 conv =================
   const void* x_last = nb > 0 ? (const void*)(ws + p->blk[nb - 1].OUT) : (const void*)(ws + p->Y0);
   BnAct act0 = make_act(p, m->prolog_bn, M, training, 1, 0.f, seed, 0);
-  BnAct act_last = nb > 0 ? identity_act() : act0;
+  BnAct act_last = nb > 0 ? identity_rows() : act0;
   int cur = 0;   // dA[cur] holds the gradient wrt the current block output
   {
     ProdDy::Args pa{ws + p->dEbn, ws + p->E, D, make_bnbwd(p, m->epi_bn, M, training)};
@@ -259,7 +266,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       }
     }
     int rc;
-    if (sizeof(AT) == 2 && (p->use_v2 & 16) && H == 256 && D % 256 == 0) {
+    if (sizeof(AT) == 2 && (use_v2 & 16) && H == 256 && D % 256 == 0) {
       DgradWideArgs da;
       memset(&da, 0, sizeof(da));
       da.dZ = (const bf16_t*)(ws + p->dEbn); da.Y = (const bf16_t*)(ws + p->E); da.bn = pa.bn;
@@ -279,7 +286,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     const MegaBlockRef& mb = m->blocks[i];
     BlockWs& bw = p->blk[i];
     const void* xin = i > 0 ? (const void*)(ws + p->blk[i - 1].OUT) : (const void*)(ws + p->Y0);
-    BnAct actx = i > 0 ? identity_act() : act0;
+    BnAct actx = i > 0 ? identity_rows() : act0;
     BnAct act3 = make_act(p, mb.sub[nsub - 1].bn, M, training, 1, pd, seed, i * (nsub + 1) + nsub - 1);
     BnAct acts = make_act(p, mb.bnskip, M, training, 0, 0.f, seed, 0);
     const float inv_keep = (training && pd > 0.f) ? 1.f / (1.f - pd) : 1.f;

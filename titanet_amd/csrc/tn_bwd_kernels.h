@@ -22,6 +22,7 @@ struct BnBwd {
   const float* gamma;
   float inv_n, eps;
   float batch;           // 1.f: batch statistics (train) -> mean/variance terms; 0.f: fixed statistics (eval)
+  RowMask rm;            // padded rows have no gradient (dy = 0 there, not k1*y + k2)
 };
 
 __device__ __forceinline__ void bn_fwd_mean_rstd(const BnBwd& b, int C, int c, float& mean, float& rstd) {
@@ -73,7 +74,7 @@ struct ProdDy {
     for (int r = rl; r < ROWS; r += RL) {
       float v[8];
       const int gr = r0 + r;
-      if (gr < M && k < K) {
+      if (gr < M && k < K && tn_row_valid(a.bn.rm, (uint32_t)gr)) {
         float y[8];
         load8(dZ + (size_t)gr * a.ld + k, v);
         load8(Y + (size_t)gr * a.ld + k, y);
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(512) void combine_bwd2_kernel(const AT* __restrict_
     }
   }
   __syncthreads();
-  const float invT = 1.f / (float)T;
+  const float invT = 1.f / (float)(act3.rm.len ? max(act3.rm.len[b], 1) : T);   // the SE mean ran over the valid frames
   for (int c = tid; c < C; c += NT) {
     float s = 0.f;
     for (int j = 0; j < Hr; ++j) s += W1[(size_t)j * C + c] * p1[j];
@@ -669,7 +670,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(DwBwdArgs a) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) dA[q] += ad[q];
       }
-      if (a.actX.mode != 0 || a.actX.relu || a.actX.drop_thr) {
+      if (a.actX.mode != 0 || a.actX.relu || a.actX.drop_thr || a.actX.rm.len) {
         float y[8], m[8];
         load8(XR + o, y);
         act8_grad_mask(y, m, &par[0][vc * 8], &par[1][vc * 8], a.actX, (uint32_t)gr, a.C, c0);
@@ -749,7 +750,14 @@ __global__ __launch_bounds__(256) void asp_bwd_de_kernel(const AT* __restrict__ 
       mx[i] = smax[o];
       iv[i] = sinv[o];
     }
-    for (int t = tg; t < T; t += TG) {
+    const int L = actE.rm.len ? actE.rm.len[b] : T;     // softmax over the valid frames only
+    for (int t = L + tg; t < T; t += TG) {                 // padded frames: no gradient
+      const size_t o = ((size_t)b * T + t) * D + c0;
+      float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      store8(dEN + o, z);
+      store8(DXD + o, z);
+    }
+    for (int t = tg; t < L; t += TG) {
       const uint32_t row = (uint32_t)b * T + t;
       const size_t o = (size_t)row * D + c0;
       float x[8], e[8], de[8], dx[8];
@@ -1047,6 +1055,7 @@ __global__ __launch_bounds__(256) void prolog_input_grad_kernel(const AT* __rest
       const int tt = t - j + pad;
       if (tt < 0 || tt >= T) continue;
       const size_t row = (size_t)b * T + tt;
+      if (!tn_row_valid(bn.rm, (uint32_t)row)) continue;
       for (int h = 0; h < H; ++h) {
         float k0, k1, k2;
         bn_bwd_coefs(bn, H, h, k0, k1, k2);

@@ -148,6 +148,21 @@ __host__ __device__ __forceinline__ bool tn_keep_elem(uint32_t e, uint32_t key, 
 // Dropout (reference src/modules.py:119-133).  Raw outputs are stored once; normalisation,
 // activation and the dropout mask are recomputed by every consumer (never materialised).
 // ------------------------------------------------------------------------------------------
+// Variable-length batches (BASELINE.json configs[3]; the reference pads and then ignores the lengths,
+// src/datasets.py:63-73, src/learn.py:88): utterance b has len[b] valid frames, rows b*T + t with t >= len[b] are padding.
+// The mask lives in the ACTIVATION: every consumer sees act(.) = 0 on padded rows, which is exactly the zero padding the
+// convolutions apply at the end of an un-padded utterance; reductions (BatchNorm sums, SE mean, attentive softmax) skip
+// padded rows and divide by the valid count.  len == null: every row is valid (the reference's semantics, bit for bit).
+struct RowMask {
+  const int* len;   // [B] valid frames per utterance, or null
+  int T;
+};
+__device__ __forceinline__ bool tn_row_valid(const RowMask& m, uint32_t row) {
+  if (!m.len) return true;
+  const uint32_t b = row / (uint32_t)m.T;
+  return (int)(row - b * (uint32_t)m.T) < m.len[b];
+}
+
 struct BnAct {
   // [TN_NREP][2][C]: sum, sum of squares over the M rows.  Train mode: accumulated by the producing
   // kernel's epilogue.  Eval mode: bn_eval_prepare_kernel writes the sums that reproduce the running
@@ -166,6 +181,7 @@ struct BnAct {
   const uint32_t* key_add;   // device word added to drop_key (the plan's per-step word: 0 unless tn_plan_step_tick drives the
                              // step from device memory, which is what lets a whole training step replay as ONE hipGraph); or null
   float inv_keep;       // 1 / (1 - p)
+  RowMask rm;           // padded rows read as 0 (len == null: no mask)
 };
 
 // per-channel (mean, rstd) from the replicated batch sums
@@ -202,6 +218,10 @@ __device__ __forceinline__ void act8(float v[8], const float* sc, const float* s
     for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
   }
   if (a.drop_thr) tn_drop8(v, (row * (uint32_t)C + (uint32_t)c0) >> 3, tn_act_key(a), a.drop_thr);
+  if (a.rm.len && !tn_row_valid(a.rm, row)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+  }
 }
 // mask-only variant for the backward pass: given the raw value's post-BN sign and the keep
 // bits, returns the multiplier d(act)/d(bn output) for each of the 8 channels.
@@ -214,6 +234,10 @@ __device__ __forceinline__ void act8_grad_mask(const float raw[8], float m[8], c
     m[i] = (!a.relu || z > 0.f) ? on : 0.f;
   }
   if (a.drop_thr) tn_drop8(m, (row * (uint32_t)C + (uint32_t)c0) >> 3, tn_act_key(a), a.drop_thr);
+  if (a.rm.len && !tn_row_valid(a.rm, row)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = 0.f;
+  }
 }
 
 // ------------------------------------------------------------------------------------------

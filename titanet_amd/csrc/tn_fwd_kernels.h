@@ -69,7 +69,7 @@ __global__ __launch_bounds__(512) void se_squeeze_fc_kernel(const AT* __restrict
   for (int c = tid; c < C; c += NT) {
     float s = 0.f;
     for (int k = 0; k < TG; ++k) s += part[k * C + c];
-    s *= (1.f / (float)T);
+    s *= 1.f / (float)(act.rm.len ? max(act.rm.len[b], 1) : T);   // padded rows read as 0 (act8): mean over the valid frames
     mean[c] = s;
     m_out[(size_t)b * C + c] = s;
   }
@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) void asp_pool_fwd_kernel(const AT* __restrict_
 #pragma unroll
   for (int i = 0; i < 8; ++i) { m[i] = -INFINITY; l[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
   if (c0 < D) {
-    for (int t = tg; t < T; t += TG) {
+    const int L = actE.rm.len ? actE.rm.len[b] : T;     // softmax over the valid frames only
+    for (int t = tg; t < L; t += TG) {
       const uint32_t row = (uint32_t)b * T + t;
       float x[8], e[8];
       load8(E + (size_t)row * D + c0, x);
@@ -447,8 +448,11 @@ __global__ void bn_eval_prepare_kernel(const BnUpdateDesc* descs, float* const* 
   }
 }
 
-__global__ void bn_running_update_kernel(const BnUpdateDesc* descs, float momentum, int64_t* nbt, int n_layers) {
-  const BnUpdateDesc d = descs[blockIdx.y];
+// n_rows_plan / n_rows_valid: layers reduced over all B*T rows of the plan use the valid-row count of a masked batch
+__global__ void bn_running_update_kernel(const BnUpdateDesc* descs, float momentum, int64_t* nbt, int n_layers, int n_rows_plan,
+                                         int n_rows_valid) {
+  BnUpdateDesc d = descs[blockIdx.y];
+  if (d.n == n_rows_plan) d.n = n_rows_valid;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < d.C; c += gridDim.x * blockDim.x) {
     float s = 0.f, q = 0.f;
     for (int r = 0; r < TN_NREP; ++r) { s += d.stats[(r * 2 + 0) * d.C + c]; q += d.stats[(r * 2 + 1) * d.C + c]; }

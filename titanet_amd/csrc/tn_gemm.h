@@ -251,6 +251,7 @@ struct ProdIm2col {
   struct Args {
     const float* x;   // [B][n_mels][T] float32, T contiguous (reference layout)
     int n_mels, KP, T;
+    const int* len;   // [B] valid frames (frames beyond them read as zero whatever the buffer holds) or null
   };
   __host__ __device__ static size_t scratch_bytes(int, int, int, int, size_t) { return 16; }
   template <typename AT, int NT, int CW>
@@ -268,6 +269,7 @@ struct ProdIm2col {
     const bool row_ok = gr < g.M;
     const int b = row_ok ? gr / a.T : 0, t = row_ok ? gr - b * a.T : 0;
     const float* xb = a.x + (size_t)b * a.n_mels * a.T;
+    const int L = (a.len && row_ok) ? a.len[b] : a.T;
     for (int kk = tid / BM; kk < BK; kk += NT / BM) {
       const int k = kc + kk;
       float v = 0.f;
@@ -276,7 +278,7 @@ struct ProdIm2col {
         if (a.KP == 3) { ci = (int)((unsigned)k / 3u); j = k - 3 * ci; }
         else { ci = k / a.KP; j = k - ci * a.KP; }
         const int tt = t + j - pad;
-        if (tt >= 0 && tt < a.T) v = xb[(size_t)ci * a.T + tt];
+        if (tt >= 0 && tt < L) v = xb[(size_t)ci * a.T + tt];
       }
       As[r * BKP + kk] = Elem<AT>::from_f(v);
     }
@@ -294,6 +296,7 @@ struct EpiStoreArgs {
   int ldy;
   const float* bias;   // [N] or null
   float* stats;        // [TN_NREP][2][N] or null
+  RowMask rm;          // rows left out of the statistics (variable-length batches); {null, 0}: none
 };
 __device__ __forceinline__ float fast_tanh(float x) {
   const float e = __expf(2.f * x);       // inf for large x -> 1, 0 for very negative x -> -1
@@ -331,7 +334,7 @@ struct EpiStoreT {
           if (TANH) y = fast_tanh(y);
           acc[mt][nt][r] = y;
           const int row = r0 + wm * 64 + mt * 32 + cd_row(r, lane);
-          if (row < g.M) { s += y; q += y * y; }
+          if (row < g.M && tn_row_valid(e.rm, (uint32_t)row)) { s += y; q += y * y; }
         }
       }
       if (e.stats) {

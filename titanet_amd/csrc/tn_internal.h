@@ -140,6 +140,11 @@ struct tn_plan {
   int prof_class = 0;
   std::vector<hipEvent_t> prof_events;
   size_t prof_used = 0;
+  // variable-length batches (tn_forward_masked): valid frames per utterance
+  size_t lens = 0;                      // int32 [B] in the workspace
+  std::vector<int> lens_host;
+  bool masked = false;                  // the last forward carried lengths
+  int n_valid = 0;                      // sum of the lengths (rows that enter the [B*T]-row BatchNorm statistics)
   // state
   const float* last_input = nullptr;
   int last_training = -1;
@@ -149,6 +154,7 @@ struct tn_plan {
 
 int plan_forward(tn_plan* p, const float* spec, const int64_t* speakers, int training, uint64_t seed, float* emb_out,
                  int64_t* preds, float* loss, hipStream_t st);
+RowMask plan_row_mask(const tn_plan* p);   // {device lengths, T} of the last forward, or {null, T}
 int plan_backward(tn_plan* p, float grad_scale, const float* grad_scale_dev, const float* grad_emb, float* grad_input,
                   hipStream_t st);
 

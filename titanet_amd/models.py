@@ -47,8 +47,8 @@ class _TitaNetFunction(torch.autograd.Function):
     """One autograd node for the whole network: forward = tn_forward, backward = tn_backward."""
 
     @staticmethod
-    def forward(ctx, spectrograms, anchor, module, speakers):
-        emb, preds, loss, plan = module._native_forward(spectrograms, speakers)
+    def forward(ctx, spectrograms, anchor, module, speakers, lengths=None):
+        emb, preds, loss, plan = module._native_forward(spectrograms, speakers, lengths=lengths)
         ctx.module, ctx.plan = module, plan
         ctx.in_shape = spectrograms.shape if spectrograms.requires_grad else None
         ctx.set_materialize_grads(False)
@@ -62,7 +62,7 @@ class _TitaNetFunction(torch.autograd.Function):
             raise RuntimeError("titanet_amd: backward() must follow the forward() it belongs to "
                                "(another forward ran on this module in between)")
         g_in = module._native_backward(plan, g_emb, g_loss, ctx.in_shape)
-        return g_in, None, None, None
+        return g_in, None, None, None, None
 
 
 class TitaNet(nn.Module):
@@ -282,18 +282,22 @@ class TitaNet(nn.Module):
         elif model_size.lower() == "l":
             return titanet(encoder_hidden_size=1024, mega_block_kernel_size=11)
 
-    def forward(self, spectrograms, speakers=None):
+    def forward(self, spectrograms, speakers=None, lengths=None):
         """reference src/models.py:318-339: [B, M, T] -> normalised embeddings [B, E] (inference) or
-        (normalised embeddings, predictions, loss) when ``speakers`` is given."""
+        (normalised embeddings, predictions, loss) when ``speakers`` is given.
+
+        ``lengths`` (extension; the reference's callers drop collate_fn's lengths, src/learn.py:88): int64 ``[B]`` valid
+        frames per utterance of a zero-padded batch — padded frames are then masked out of every layer, statistic and
+        gradient (``tn_forward_masked``, include/titanet_amd.h); ``None`` = the reference's semantics."""
         if speakers is not None:
             assert self.loss_function is not None, "Loss function should not be None in training mode"
         needs_grad = torch.is_grad_enabled() and (spectrograms.requires_grad or any(p.requires_grad for p in self.parameters()))
         if needs_grad:
             if self._anchor.device != spectrograms.device:
                 self._anchor = torch.zeros(1, device=spectrograms.device, requires_grad=True)
-            emb, preds, loss = _TitaNetFunction.apply(spectrograms, self._anchor, self, speakers)
+            emb, preds, loss = _TitaNetFunction.apply(spectrograms, self._anchor, self, speakers, lengths)
         else:
-            emb, preds, loss, _ = self._native_forward(spectrograms, speakers)
+            emb, preds, loss, _ = self._native_forward(spectrograms, speakers, lengths=lengths)
         if speakers is None:
             return emb
         return emb, preds, loss
@@ -341,7 +345,7 @@ class TitaNet(nn.Module):
             check(self._lib.tn_plan_grad_bucket(plan.handle, i, C.byref(lo), C.byref(hi)), "tn_plan_grad_bucket")
             plan.buckets.append((lo.value, hi.value))
 
-    def _native_forward(self, spectrograms, speakers, fixed_seed=False):
+    def _native_forward(self, spectrograms, speakers, fixed_seed=False, lengths=None):
         if spectrograms.dim() != 3 or spectrograms.shape[1] != self._cfg.n_mels:
             raise ValueError(f"expected spectrograms of shape [B, {self._cfg.n_mels}, T], got {tuple(spectrograms.shape)}")
         if not spectrograms.is_cuda:
@@ -366,8 +370,16 @@ class TitaNet(nn.Module):
             seed = (self._seed_base + self._step * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
             self._step += 1
         stream = torch.cuda.current_stream(dev).cuda_stream
-        check(self._lib.tn_forward(plan.handle, _ptr(x), _ptr(y), 1 if self.training else 0, C.c_uint64(seed), _ptr(emb),
-                                   _ptr(preds), _ptr(loss), C.c_void_p(stream)), "tn_forward")
+        if lengths is None:
+            check(self._lib.tn_forward(plan.handle, _ptr(x), _ptr(y), 1 if self.training else 0, C.c_uint64(seed), _ptr(emb),
+                                       _ptr(preds), _ptr(loss), C.c_void_p(stream)), "tn_forward")
+        else:
+            ln = torch.as_tensor(lengths).detach().to(device="cpu", dtype=torch.int64).contiguous()    # host lengths (collate_fn)
+            if ln.numel() != B or int(ln.min()) < 1 or int(ln.max()) > T:
+                raise ValueError(f"lengths must be {B} values in [1, {T}], got {tuple(ln.tolist())[:8]}...")
+            check(self._lib.tn_forward_masked(plan.handle, _ptr(x), C.c_void_p(ln.data_ptr()), _ptr(y), 1 if self.training else 0,
+                                              C.c_uint64(seed), _ptr(emb), _ptr(preds), _ptr(loss), C.c_void_p(stream)),
+                  "tn_forward_masked")
         plan.input_ref = x      # keep the input alive for backward (prolog weight gradient re-reads it)
         self._active_plan = plan
         if speakers is None:
