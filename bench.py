@@ -185,6 +185,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--loss", default="ce", choices=["ce", "arc"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the streaming-ceiling microbenchmark (PMC passes: keeps foreign kernels out of the counters)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo for single-GPU smoke tests)")
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -276,7 +277,7 @@ def main():
         step_alg = ALG_BYTES_PER_UTT_BF16 * (esz / 2) * args.batch          # per GPU
         achieved = step_alg / step_s / 1e9
         k_traffic, s_traffic, src = pmc_traffic(dom) if headline else (None, None, None)
-        ceil = stream_ceiling(dev)
+        ceil = {"cold": float("nan"), "hot": float("nan")} if args.no_ceiling else stream_ceiling(dev)
         out = {
             "metric": "utterances/sec TitaNet-S fwd+bwd (80-mel x 300f)",
             "value": round(value, 1),

@@ -116,5 +116,7 @@ def test_gradient_grouping_does_not_change_the_gradient():
     d_group = float((gs[4][0] - ref).norm() / ref.norm())
     d_repeat = float((gs[4][0] - gs[4][1]).norm() / ref.norm())
     print(f"grouped vs ungrouped gradient rel diff {d_group:.2e}; same grouping repeated {d_repeat:.2e}")
-    assert d_group < 1e-3, d_group
+    # run-to-run noise of the bf16 backward itself (atomics-ordered BatchNorm sums flip a few bf16 roundings of the stored
+    # gradients): grouping must not add to it
+    assert d_group < 3 * d_repeat + 1e-3 and d_group < 3e-2, (d_group, d_repeat)
     assert torch.isfinite(ref).all() and float(ref.norm()) > 0
