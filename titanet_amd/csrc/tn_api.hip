@@ -178,6 +178,9 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     // generic template path (fp32 parity plans, TitaNet-M / -L): same idea, the forward GEMM's depthwise producer stores its tile
     const char* sq = getenv("TN_SAVEQ");
     if (!p->use_v2 && !(sq && atoi(sq) == 0)) p->save_q = true;
+    // hidden >= TN_DW_SPLIT (default 512): stand-alone depthwise producer + plain pointwise GEMM (tn_fwd_kernels.h: dw_fwd_kernel)
+    const char* ds = getenv("TN_DW_SPLIT");
+    p->split_dw = !p->use_v2 && m->cfg.hidden >= (ds ? atoi(ds) : 512) && m->cfg.hidden % 8 == 0;
     const char* pe = getenv("TN_PARTS");
     if (pe && atoi(pe) > 0) p->combine_parts = atoi(pe);
   }
@@ -197,7 +200,10 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   //      loss.backward(retain_graph=True) twice): BN-backward sums, split-K counters, depthwise accumulators
   p->bzero_begin = b.take(0);
   for (int i = 0; i < m->n_bn; ++i) p->bsums[i] = b.take((size_t)TN_NREP * 2 * m->all_bn[i].C * sizeof(float));
-  p->wg2_count = b.take(sizeof(int) * (size_t)(c.n_mega_blocks * (c.n_sub_blocks + 1) + D / 256 + 1));
+  {
+    const size_t hs = std::max<size_t>(H / 256, 1);
+    p->wg2_count = b.take(sizeof(int) * (size_t)(c.n_mega_blocks * (c.n_sub_blocks + 1) * hs * hs + (D / 256 + 1) * hs + 1));
+  }
   p->dw_gacc = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * TN_NREP * (c.kernel + 1) * H * sizeof(float));
   p->bzero_bytes = ((b.off + 255) & ~(size_t)255) - p->bzero_begin;
   b.off = p->bzero_begin + p->bzero_bytes;
@@ -272,14 +278,21 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     p->slab_bytes = biggest * sizeof(float) * 48;   // ~48 K-splits of the largest weight, more for smaller ones
     p->slabs = b.take(p->slab_bytes);
   }
-  if (p->use_v2) {
-    p->wg2_layers = c.n_mega_blocks * (c.n_sub_blocks + 1);
-    // the epilog conv's weight gradient rides along as D / 256 slabs of 256 output channels
-    p->wg2_epi_slabs = (c.n_mega_blocks > 0 && D % 256 == 0 && (p->use_v2 & 16)) ? (int)(D / 256) : 0;
+  {
+    const char* ww = getenv("TN_WIDE_WGRAD");
+    p->wide_wgrad = !p->use_v2 && precision == TN_PREC_BF16 && (H == 512 || H == 1024) && D % 256 == 0 && p->save_q &&
+                    c.n_mega_blocks > 0 && !(ww && atoi(ww) == 0);
+  }
+  if (p->use_v2 || p->wide_wgrad) {
+    const int hs = (int)(H / 256);
+    p->wg2_upl = hs * hs;
+    p->wg2_layers = c.n_mega_blocks * (c.n_sub_blocks + 1) * p->wg2_upl;
+    // the epilog conv's weight gradient rides along as (D / 256) x (H / 256) slabs of 256 x 256
+    p->wg2_epi_slabs = (c.n_mega_blocks > 0 && D % 256 == 0 && ((p->use_v2 & 16) || p->wide_wgrad)) ? (int)(D / 256) * hs : 0;
     p->wg2_layers += p->wg2_epi_slabs;
     p->wg2_grid = 256;
     p->wg2_desc = b.take((size_t)p->wg2_layers * 256);   // >= sizeof(WgradV2Desc) each (checked at upload)
-    p->wg2_out = b.take((size_t)p->wg2_layers * 16);
+    p->wg2_out = b.take((size_t)p->wg2_layers * 32);
     p->dw_table = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * 32);
   }
   p->cast_table = b.take(sizeof(CastDesc) * (8 + (size_t)c.n_mega_blocks * (c.n_sub_blocks + 1)));
@@ -328,11 +341,11 @@ void plan_layout_tail(tn_plan* p) {
   }
   Bump b;
   b.off = p->ws_fixed_bytes;
-  if (p->use_v2 && p->wg2_layers > 0) {
+  if ((p->use_v2 || p->wide_wgrad) && p->wg2_layers > 0) {
     // every group's launch cuts its (layer, 32-row chunk) units into one contiguous range per workgroup: the number of
     // partial slabs a layer can receive is bounded by the smallest group
     const int chunks = (p->M + 31) / 32;
-    const int per_blk = c.n_sub_blocks + 1;
+    const int per_blk = (c.n_sub_blocks + 1) * p->wg2_upl;
     int maxparts = 1;
     for (const auto& bk : p->buckets) {
       const int layers = (bk.blk_hi >= bk.blk_lo ? (bk.blk_hi - bk.blk_lo + 1) * per_blk : 0) + (bk.tail ? p->wg2_epi_slabs : 0);
@@ -621,6 +634,13 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
                           bw.wpw[j].sw ? (const uint4*)(ws + bw.wpw[j].sw) : nullptr,
                           (p->save_q && training) ? (bf16_t*)(ws + bw.Q[j]) : nullptr};
           rc = launch_sub_fwd_v5<3, true>(va, 256, st);
+        } else if (p->split_dw && p->save_q) {
+          // wide models: the depthwise output is produced once by a streaming kernel (it is kept for the weight gradients
+          // anyway) and the pointwise GEMM reads it as a plain operand
+          rc = launch_dw_fwd<AT>((const AT*)cur, acur, params + sb.wdw, params + sb.bdw, (AT*)(ws + bw.Q[j]), M, T, H, c.kernel, st);
+          if (rc) return rc;
+          ProdPlain::Args pq{ws + bw.Q[j], H, identity_act()};
+          rc = gemm_store<AT, ProdPlain>(g, pq, ea, 0, st);
         } else {
           rc = gemm_store<AT, ProdDw>(g, pa, ea, c.kernel, st);
         }

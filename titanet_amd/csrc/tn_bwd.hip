@@ -71,7 +71,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   const int use_v2 = p->masked ? 0 : p->use_v2;     // variable-length batches: generic templates (see forward)
   if (p->masked && c.simple_pool) return TN_E_UNSUPPORTED;
   auto identity_rows = [&]() { BnAct a = identity_act(); a.rm = plan_row_mask(p); return a; };
-  const bool batched_wgrad = sizeof(AT) == 2 && (use_v2 & 4) && training && p->wg2_layers > 0;
+  const bool batched_wgrad = sizeof(AT) == 2 && ((use_v2 & 4) || (p->wide_wgrad && !p->masked)) && training && p->wg2_layers > 0;
   const bool v2_bwd = sizeof(AT) == 2 && (use_v2 & 8);
   const int nb = c.n_mega_blocks;
   const int per_blk = nsub + 1;
@@ -93,8 +93,9 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       hipLaunchKernelGGL(dw_grad_finalize_kernel, dim3((bk.blk_hi - bk.blk_lo + 1) * nsub), dim3(256), 0, st,
                          (const DwGradOut*)(ws + p->dw_table) + (size_t)bk.blk_lo * nsub, c.kernel);
     if (batched_wgrad) {
-      int first = has_blocks ? bk.blk_lo * per_blk : nb * per_blk;
-      int count = (has_blocks ? (bk.blk_hi - bk.blk_lo + 1) * per_blk : 0) + (bk.tail ? p->wg2_epi_slabs : 0);
+      const int upb = per_blk * p->wg2_upl;      // weight-gradient units per mega block
+      int first = has_blocks ? bk.blk_lo * upb : nb * upb;
+      int count = (has_blocks ? (bk.blk_hi - bk.blk_lo + 1) * upb : 0) + (bk.tail ? p->wg2_epi_slabs : 0);
       if (has_blocks && bk.tail && bk.blk_hi != nb - 1) { rc_fin = TN_E_STATE; return; }   // ranges must be contiguous
       if (count > 0) {
         const int chunks = (M + 31) / 32;
@@ -498,30 +499,32 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
   }
   if (!sd.empty())
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->se_table, sd.data(), sd.size() * sizeof(SeGradDesc), hipMemcpyHostToDevice, st));
-  if (p->use_v2 && p->wg2_layers > 0) {
+  if ((p->use_v2 || p->wide_wgrad) && p->wg2_layers > 0) {
     const tn_config& c = m->cfg;
-    const int nsub = c.n_sub_blocks, M = p->M;
+    const int nsub = c.n_sub_blocks, M = p->M, H = c.hidden, hs = H / 256;
     std::vector<WgradV2Desc> wd;
     std::vector<WgradV2Out> wo;
     const size_t slab_stride = (size_t)p->wg2_maxparts * 256 * 256;
-    auto add = [&](size_t dz, size_t y, const BnRef& bn, const void* x, const BnAct& ax, int drop_layer, int64_t wdw, int64_t bdw,
-                   int64_t wout) {
+    // one unit per 256 x 256 slab of d W[out][in]: P = BN-backward(dZ, Y)[:, out slab], Q = the layer's GEMM operand[:, in slab]
+    auto add = [&](size_t dz, size_t y, const BnRef& bn, int p_width, const void* x, const BnAct& ax, int q_width, int drop_layer,
+                   int64_t wdw, int64_t bdw, int64_t wout, int po, int qo) {
       WgradV2Desc d;
       memset(&d, 0, sizeof(d));
-      d.dZ = (const bf16_t*)(p->ws + dz);
-      d.Y = (const bf16_t*)(p->ws + y);
+      d.dZ = (const bf16_t*)(p->ws + dz) + (size_t)po * 256;
+      d.Y = (const bf16_t*)(p->ws + y) + (size_t)po * 256;
       d.fstats = (const float*)(p->ws + p->stats[bn.id]);
       d.bsums = (const float*)(p->ws + p->bsums[bn.id]);
-      d.gamma = p->params + bn.gamma;
+      d.gamma = p->params + bn.gamma;          // indexed with chan0 + channel, like the statistics
       d.inv_n = 1.f / (float)M; d.eps = 1e-5f; d.batch = 1.f;
       d.X = (const bf16_t*)x;
       d.actX = ax;
       d.drop_layer = drop_layer;
       d.wdw = wdw >= 0 ? p->params + wdw : nullptr;
       d.bdw = bdw >= 0 ? p->params + bdw : nullptr;
-      d.ldp = 256; d.statC = 256; d.chan0 = 0;
+      d.ldp = p_width; d.statC = p_width; d.chan0 = po * 256;
+      d.ldq = q_width; d.q0 = qo * 256;
       d.slabs = (float*)(p->ws + p->wg2_slabs) + wd.size() * slab_stride;
-      WgradV2Out o{d.slabs, p->grads + wout};
+      WgradV2Out o{d.slabs, p->grads + wout + (int64_t)po * 256 * q_width + (int64_t)qo * 256, q_width, 0};
       wd.push_back(d);
       wo.push_back(o);
     };
@@ -531,25 +534,29 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
       const BlockWs& bw = p->blk[i];
       const void* xin = i > 0 ? (const void*)(p->ws + p->blk[i - 1].OUT) : (const void*)(p->ws + p->Y0);
       BnAct actx = i > 0 ? identity_act() : make_act(p, m->prolog_bn, M, 1, 1, 0.f, 0, 0);
-      add(bw.dZk, bw.S, mb.bnskip, xin, actx, 0, -1, -1, mb.wskip);
+      for (int po = 0; po < hs; ++po)
+        for (int qo = 0; qo < hs; ++qo) add(bw.dZk, bw.S, mb.bnskip, H, xin, actx, H, 0, -1, -1, mb.wskip, po, qo);
       for (int j = 0; j < nsub; ++j) {
         const void* sin = j > 0 ? (const void*)(p->ws + bw.Y[j - 1]) : xin;
         BnAct asin = j > 0 ? make_act(p, mb.sub[j - 1].bn, M, 1, 1, pd, 0, 0) : actx;
-        if (p->save_q)   // the forward kept the depthwise output: a plain operand, no activation / stencil recompute
-          add(bw.dY[j], bw.Y[j], mb.sub[j].bn, (const void*)(p->ws + bw.Q[j]), identity_act(), 0, -1, -1, mb.sub[j].wpw);
-        else
-          add(bw.dY[j], bw.Y[j], mb.sub[j].bn, sin, asin, i * (nsub + 1) + j - 1, mb.sub[j].wdw, mb.sub[j].bdw, mb.sub[j].wpw);
+        for (int po = 0; po < hs; ++po)
+          for (int qo = 0; qo < hs; ++qo) {
+            if (p->save_q)   // the forward kept the depthwise output: a plain operand, no activation / stencil recompute
+              add(bw.dY[j], bw.Y[j], mb.sub[j].bn, H, (const void*)(p->ws + bw.Q[j]), identity_act(), H, 0, -1, -1, mb.sub[j].wpw, po, qo);
+            else
+              add(bw.dY[j], bw.Y[j], mb.sub[j].bn, H, sin, asin, H, i * (nsub + 1) + j - 1, mb.sub[j].wdw, mb.sub[j].bdw, mb.sub[j].wpw, po, qo);
+          }
       }
     }
-    // epilog conv: d W[s*256 .. +256][256] = BN-backward(dEbn, E)[:, slab s]^T * x_last   (x_last = last block output, stored activated)
-    for (int sl = 0; sl < p->wg2_epi_slabs; ++sl) {
-      const int D = c.enc_out;
-      add(p->dEbn + (size_t)sl * 256 * sizeof(bf16_t), p->E + (size_t)sl * 256 * sizeof(bf16_t), m->epi_bn,
-          (const void*)(p->ws + p->blk[c.n_mega_blocks - 1].OUT), identity_act(), 0, -1, -1, m->epi_w + (int64_t)sl * 256 * 256);
-      wd.back().ldp = D; wd.back().statC = D; wd.back().chan0 = sl * 256;
-    }
+    // epilog conv: d W[D][H] in 256 x 256 slabs = BN-backward(dEbn, E)[:, out slab]^T * x_last[:, in slab]
+    // (x_last = last block output, stored activated)
+    if (p->wg2_epi_slabs > 0)
+      for (int po = 0; po < c.enc_out / 256; ++po)
+        for (int qo = 0; qo < hs; ++qo)
+          add(p->dEbn, p->E, m->epi_bn, c.enc_out, (const void*)(p->ws + p->blk[c.n_mega_blocks - 1].OUT), identity_act(), H, 0, -1, -1,
+              m->epi_w, po, qo);
     if ((int)wd.size() != p->wg2_layers) return TN_E_STATE;
-    if (sizeof(WgradV2Desc) > 256 || sizeof(WgradV2Out) > 16) return TN_E_STATE;
+    if (sizeof(WgradV2Desc) > 256 || sizeof(WgradV2Out) > 32) return TN_E_STATE;
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_desc, wd.data(), wd.size() * sizeof(WgradV2Desc), hipMemcpyHostToDevice, st));
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_out, wo.data(), wo.size() * sizeof(WgradV2Out), hipMemcpyHostToDevice, st));
     std::vector<DwGradOut> dg;

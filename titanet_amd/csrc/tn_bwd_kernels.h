@@ -584,8 +584,9 @@ struct DwBwdArgs {
 template <typename AT, int KD>
 __global__ __launch_bounds__(256) void dw_bwd_kernel(DwBwdArgs a) {
   constexpr int RT = 64, CW = 64, NT = 256, PAD = (KD - 1) / 2, ROWS = RT + KD - 1, VC = CW / 8, RL = NT / VC;
-  __shared__ __attribute__((aligned(16))) float dDs[ROWS][CW];
-  __shared__ __attribute__((aligned(16))) float As[ROWS][CW];
+  // + 8 floats per row: a wave covers 8 rows x 8 channel vectors; with a 256-byte row stride all 8 rows hit the same banks
+  __shared__ __attribute__((aligned(16))) float dDs[ROWS][CW + 8];
+  __shared__ __attribute__((aligned(16))) float As[ROWS][CW + 8];
   __shared__ float red[KD + 3][CW];
   __shared__ float par[4][CW];   // sc, sh, mean, rstd of actX
   __shared__ float wds[KD][CW];

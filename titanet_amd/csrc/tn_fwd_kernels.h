@@ -2,6 +2,8 @@
 // attentive-statistics pooling, decoder tail, loss heads, BatchNorm running-statistics update and the
 // per-step weight cast/transposition.  All tensors are "rows x channels" (see tn_common.h).
 #pragma once
+#include <algorithm>
+
 #include "tn_common.h"
 
 // ------------------------------------------------------------------------------------------
@@ -26,6 +28,99 @@ __global__ void cast_params_kernel(const CastDesc* descs) {
       reinterpret_cast<AT*>(d.dstT)[(size_t)c * d.R + r] = Elem<AT>::from_f(v);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Stand-alone depthwise producer for the WIDE models (hidden 1024, TitaNet-L): Q = dwconv_KD(act(X)) + b_dw
+// (reference src/modules.py:65-75).  Fusing this producer into the pointwise GEMM (ProdDw) recomputes activation +
+// stencil once per 256-column block of the output — 4 times at hidden 1024, with K = 11 taps — and made the forward GEMM
+// VALU / LDS bound (1.3 ms per launch at B = 256); the depthwise output is kept for the weight gradients anyway, so here
+// it is produced ONCE by a streaming kernel and the GEMM reads it as a plain operand.
+// Persistent workgroups, each bound to one 256-channel slab and walking 64-row tiles (the per-channel constants — BatchNorm
+// scale / shift from the replicated statistics, KD + 1 taps per channel — cost more than a tile if reloaded per tile): the
+// activated input rows of a tile (+ halo) are staged in LDS with all their loads in flight at once, then every thread
+// produces 8 output rows for its 8 channels, taps in registers.
+// ------------------------------------------------------------------------------------------
+template <typename AT, int KD>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const AT* __restrict__ X, BnAct act, const float* __restrict__ wdw,
+                                                     const float* __restrict__ bdw, AT* __restrict__ Q, int M, int T, int C) {
+  constexpr int PAD = (KD - 1) / 2, RT = 64, ROWS = RT + KD - 1, CW = 256, XP = CW + 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  AT* Xs = reinterpret_cast<AT*>(smem);                       // [ROWS][XP] activated rows
+  float* cst = reinterpret_cast<float*>(Xs + ROWS * XP);      // sc, sh : [2][CW]
+  const int tid = threadIdx.x, vc = tid & 31, rq = tid >> 5;
+  const int cb = blockIdx.y * CW, c0 = cb + vc * 8;
+  {
+    float s = 1.f, h = 0.f;
+    if (cb + tid < C) bn_scale_shift(act, C, cb + tid, s, h);
+    cst[tid] = s; cst[CW + tid] = h;
+  }
+  __syncthreads();
+  const bool cvalid = c0 < C;
+  float bd[8], wd[KD][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    bd[i] = cvalid ? bdw[c0 + i] : 0.f;
+#pragma unroll
+    for (int k = 0; k < KD; ++k) wd[k][i] = cvalid ? wdw[(size_t)(c0 + i) * KD + k] : 0.f;
+  }
+  const int ntiles = (M + RT - 1) / RT;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int r0 = tile * RT;
+  __syncthreads();            // the previous tile's taps have been read
+  for (int i = rq; i < ROWS; i += 8) {
+    const int gr = r0 - PAD + i;
+    float v[8];
+    if (cvalid && gr >= 0 && gr < M) {
+      load8(X + (size_t)gr * C + c0, v);
+      act8(v, cst + vc * 8, cst + CW + vc * 8, act, (uint32_t)gr, C, c0);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = 0.f;
+    }
+    store8(Xs + i * XP + vc * 8, v);
+  }
+  __syncthreads();
+  if (cvalid)
+  for (int r = rq; r < RT; r += 8) {
+    const int gr = r0 + r;
+    if (gr >= M) break;
+    const int t = gr % T;
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = bd[i];
+#pragma unroll
+    for (int k = 0; k < KD; ++k) {
+      const int tt = t + k - PAD;
+      if (tt >= 0 && tt < T) {               // taps beyond the utterance read the zero padding
+        float v[8];
+        load8(Xs + (r + k) * XP + vc * 8, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = fmaf(wd[k][i], v[i], o[i]);
+      }
+    }
+    store8(Q + (size_t)gr * C + c0, o);
+  }
+  }
+}
+template <typename AT>
+inline int launch_dw_fwd(const AT* X, const BnAct& act, const float* wdw, const float* bdw, AT* Q, int M, int T, int C, int KD,
+                         hipStream_t st) {
+  const int slabs = (C + 255) / 256, tiles = (M + 63) / 64;
+  dim3 grid(std::min(tiles, std::max(1, 768 / slabs)), slabs);       // ~3 resident workgroups per CU
+  const size_t smem = (size_t)(64 + KD - 1) * (256 + 8) * sizeof(AT) + 2 * 256 * sizeof(float);
+  switch (KD) {
+#define TN_DWF_CASE(K)                                                                                              \
+  case K: {                                                                                                         \
+    auto kern = dw_fwd_kernel<AT, K>;                                                                               \
+    if (smem > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -4; \
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, X, act, wdw, bdw, Q, M, T, C);                              \
+  } break;
+    TN_DWF_CASE(3) TN_DWF_CASE(5) TN_DWF_CASE(7) TN_DWF_CASE(9) TN_DWF_CASE(11) TN_DWF_CASE(13) TN_DWF_CASE(15)
+#undef TN_DWF_CASE
+    default: return -2;   // TN_E_UNSUPPORTED
+  }
+  return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------

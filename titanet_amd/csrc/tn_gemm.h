@@ -178,7 +178,7 @@ struct ProdDw {
   float* bd;    // [BK]
   char* xs;     // [(BM + KD - 1)][BK] AT
   __host__ __device__ static size_t scratch_bytes(int K, int KD, int ROWS, int CW, size_t elem) {
-    return (size_t)2 * K * sizeof(float) + (size_t)(KD + 1) * CW * sizeof(float) + (size_t)(ROWS + KD - 1) * CW * elem + 32;
+    return (size_t)2 * K * sizeof(float) + (size_t)(KD + 1) * CW * sizeof(float) + (size_t)(ROWS + KD - 1) * (CW + 8) * elem + 32;
   }
   template <typename AT, int NT, int CW>
   __device__ __forceinline__ void init(const Args& a, int M, int K, char* scratch, int tid) {
@@ -197,6 +197,7 @@ struct ProdDw {
   template <typename AT, int ROWS, int NT, int CW, int PITCH>
   __device__ __forceinline__ void fill(AT* As, const Args& a, int M, int K, int tid, int r0, int kc) {
     constexpr int BK = CW, BKP = PITCH, VC = BK / 8, RL = NT / VC, BM = ROWS;
+    constexpr int XP = BK + 8;    // staged-row pitch: without the pad the 8 rows a wave touches share their LDS banks
     struct { int M, K; } g{M, K};
     const int vc = tid % VC, rl = tid / VC;
     const int k = kc + vc * 8;
@@ -214,7 +215,7 @@ struct ProdDw {
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = 0.f;
       }
-      store8(Xs + i * BK + vc * 8, v);
+      store8(Xs + i * XP + vc * 8, v);
     }
     for (int i = tid; i < (KD + 1) * BK; i += NT) {
       const int j = i / BK, c = i % BK;
@@ -234,7 +235,7 @@ struct ProdDw {
         const int tt = t + j - pad;
         if (tt >= 0 && tt < a.T) {
           float v[8];
-          load8(Xs + (r + j) * BK + vc * 8, v);
+          load8(Xs + (r + j) * XP + vc * 8, v);
 #pragma unroll
           for (int q = 0; q < 8; ++q) o[q] = fmaf(wd[j * BK + vc * 8 + q], v[q], o[q]);
         }

@@ -92,6 +92,7 @@ struct tn_plan {
   bool bound = false;
   // workspace layout (byte offsets)
   size_t zero_begin, zero_bytes;        // region cleared at the start of every forward
+  bool split_dw = false;                // wide models: depthwise producer as its own streaming kernel (forward)
   bool save_q = false;                  // forward stores the depthwise outputs (bf16 v2 path with batched weight gradients)
   int combine_parts = 4;                // row parts per utterance of the v2 element-wise kernels (env TN_PARTS)
   size_t bzero_begin, bzero_bytes;      // region cleared at the start of every backward
@@ -124,6 +125,9 @@ struct tn_plan {
   size_t wg2_desc, wg2_out, wg2_count, wg2_slabs;   // batched weight-gradient launch (v2)
   size_t dw_gacc, dw_table;                         // depthwise gradient accumulators [layer][NREP][KD+1][256] + finalize table
   int wg2_layers = 0, wg2_maxparts = 0, wg2_units_per_wg = 0, wg2_grid = 0, wg2_epi_slabs = 0;
+  int wg2_upl = 1;              // units per pointwise layer: (hidden / 256)^2 output slabs of 256 x 256
+  bool wide_wgrad = false;      // hidden = 512 / 1024 (TitaNet-M / -L), bf16: generic forward / data-gradient kernels, but the
+                                // pointwise weight gradients run as slab units of the batched launch
   size_t bwd_table_bytes = 0;
   // gradient buckets in COMPLETION order (data-parallel overlap: bucket i's all-reduce starts when its event fires)
   struct GradBucket {

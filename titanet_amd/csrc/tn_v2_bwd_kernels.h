@@ -50,6 +50,8 @@ struct WgradV2Desc {
   int drop_layer;        // dropout stream id of actX (key = tn_layer_key(seed, drop_layer)), set per step on device
   int ldp;               // row stride (elements) of dZ / Y: 256, or the full width when the layer is a 256-channel slab of a wider tensor
   int statC, chan0;      // channel count of the BN statistics arrays and this slab's first channel in them
+  int ldq, q0;           // row stride (elements) of X and this unit's first channel in it (256 / 0 for the 256-wide models; wider
+                         // models are cut into 256 x 256 output slabs: one unit per (P slab, Q slab) pair)
 };
 
 
@@ -97,7 +99,7 @@ __device__ __forceinline__ void wg2_chunks(const WgradV2Desc& d, const WgSeg& sg
     for (int q = 0; q < 3; ++q) {
       const int i = rq + 16 * q;               // Xa row 0 .. 47 (need < 32 + KD - 1)
       const int gr = r0 - PADR + i;
-      if (i < WG2_RK + KD - 1 && gr >= 0 && gr < M) px[q] = *reinterpret_cast<const uint4*>(d.X + (size_t)gr * V2_C + c0);
+      if (i < WG2_RK + KD - 1 && gr >= 0 && gr < M) px[q] = *reinterpret_cast<const uint4*>(d.X + (size_t)gr * d.ldq + d.q0 + c0);
       else px[q] = make_uint4(0, 0, 0, 0);
     }
   };
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(V2_NT, 2) void wgrad_batched_v2_kernel(const WgradV
       bb.fstats = d.fstats; bb.bsums = d.bsums; bb.gamma = d.gamma; bb.inv_n = d.inv_n; bb.eps = d.eps; bb.batch = d.batch;
       float k0, k1, k2, s, h;
       bn_bwd_coefs(bb, d.statC, d.chan0 + tid, k0, k1, k2);
-      bn_scale_shift(d.actX, V2_C, tid, s, h);
+      bn_scale_shift(d.actX, d.ldq, d.q0 + tid, s, h);
       cst[tid] = k0; cst[V2_C + tid] = k1; cst[2 * V2_C + tid] = k2; cst[3 * V2_C + tid] = s; cst[4 * V2_C + tid] = h;
       cst[5 * V2_C + tid] = dw ? d.bdw[tid] : 0.f;
 #pragma unroll
@@ -293,7 +295,9 @@ __global__ __launch_bounds__(V2_NT, 2) void wgrad_batched_v2_kernel(const WgradV
 // guaranteed across runs — parts are claimed by arrival — but each sum has <= ~6 terms)
 struct WgradV2Out {
   const float* slabs;
-  float* out;
+  float* out;        // first element of this unit's 256 x 256 block of the weight gradient
+  int ld;            // its row stride (256, or the layer's input width for slabs of a wider weight)
+  int pad_;
 };
 __global__ void wgrad_v2_reduce_kernel(const WgradV2Out* __restrict__ outs, const int* __restrict__ part_count) {
   const WgradV2Out o = outs[blockIdx.y];
@@ -301,7 +305,7 @@ __global__ void wgrad_v2_reduce_kernel(const WgradV2Out* __restrict__ outs, cons
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V2_C * V2_C; i += gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < parts; ++k) s += o.slabs[(size_t)k * V2_C * V2_C + i];
-    o.out[i] = s;
+    o.out[(size_t)(i >> 8) * o.ld + (i & 255)] = s;
   }
 }
 

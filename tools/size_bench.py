@@ -36,6 +36,10 @@ def run(size, nblocks, prec, head, B=256, T=300, steps=10):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:            # e.g. `python tools/size_bench.py m l`: only the named sizes, bf16
+        for sz in sys.argv[1:]:
+            run(sz, {"s": 17, "m": 10, "l": 5}[sz], "bf16", "ce")
+        sys.exit(0)
     run("s", 17, "bf16", "ce")
     run("s", 17, "bf16", "arc")
     run("s", 17, "fp32", "ce")
