@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtitanet_amd.so")
 
-TN_PREC_FP32, TN_PREC_BF16 = 0, 1
+TN_PREC_FP32, TN_PREC_BF16, TN_PREC_FP8 = 0, 1, 2
 TN_LOSS_NONE, TN_LOSS_CE, TN_LOSS_MARGIN = 0, 1, 2
 TN_KIND_PARAM, TN_KIND_BUFFER, TN_KIND_NBT = 0, 1, 2
 

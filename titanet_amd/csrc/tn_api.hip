@@ -162,17 +162,21 @@ struct Bump {
 
 extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, int32_t precision, tn_plan** out) {
   if (!m || !out || batch <= 0 || frames <= 0) return TN_E_BADARG;
-  if (precision != TN_PREC_FP32 && precision != TN_PREC_BF16) return TN_E_BADARG;
+  if (precision != TN_PREC_FP32 && precision != TN_PREC_BF16 && precision != TN_PREC_FP8) return TN_E_BADARG;
+  if (precision == TN_PREC_FP8 && m->cfg.hidden % 16) return TN_E_UNSUPPORTED;
   if ((int64_t)batch * frames * std::max(m->cfg.enc_out, m->cfg.hidden) >= ((int64_t)1 << 32)) return TN_E_UNSUPPORTED;
   tn_plan* p = new tn_plan();
   p->model = m;
   p->B = batch; p->T = frames; p->M = batch * frames; p->prec = precision;
+  p->fp8 = precision == TN_PREC_FP8;
+  if (p->fp8) precision = TN_PREC_BF16;      // storage, statistics and the backward pass are the bf16 plan's
+  p->prec = precision;
   p->esz = precision == TN_PREC_BF16 ? 2 : 4;
   {
     const char* e = getenv("TN_V2");
     // TN_V2 = bit mask (debug / A-B): 1 forward sub-block, 2 forward skip conv, 4 batched weight gradients, 8 fused data-gradient kernel; default all
     const int mask = e ? atoi(e) : 63;   // 16: wide (1536-channel) decoder-side kernels
-    p->use_v2 = (precision == TN_PREC_BF16 && m->cfg.hidden == 256 && m->cfg.kernel == 3) ? mask : 0;
+    p->use_v2 = (precision == TN_PREC_BF16 && !p->fp8 && m->cfg.hidden == 256 && m->cfg.kernel == 3) ? mask : 0;
     // 32: keep the depthwise outputs for the batched weight gradients (needs 1 and 4)
     p->save_q = (p->use_v2 & 1) && (p->use_v2 & 4) && (p->use_v2 & 32);
     // generic template path (fp32 parity plans, TitaNet-M / -L): same idea, the forward GEMM's depthwise producer stores its tile
@@ -180,7 +184,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     if (!p->use_v2 && !(sq && atoi(sq) == 0)) p->save_q = true;
     // hidden >= TN_DW_SPLIT (default 512): stand-alone depthwise producer + plain pointwise GEMM (tn_fwd_kernels.h: dw_fwd_kernel)
     const char* ds = getenv("TN_DW_SPLIT");
-    p->split_dw = !p->use_v2 && m->cfg.hidden >= (ds ? atoi(ds) : 512) && m->cfg.hidden % 8 == 0;
+    p->split_dw = !p->use_v2 && (p->fp8 || m->cfg.hidden >= (ds ? atoi(ds) : 512)) && m->cfg.hidden % 8 == 0;
     const char* pe = getenv("TN_PARTS");
     if (pe && atoi(pe) > 0) p->combine_parts = atoi(pe);
   }
@@ -240,6 +244,12 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     bw.dgate = b.take((size_t)batch * H * 4);
     for (int j = 0; j < c.n_sub_blocks; ++j) bw.dY.push_back(b.take(M * H * e));
     bw.dZk = b.take(M * H * e);
+  }
+  if (p->fp8) {
+    p->q8 = b.take(M * H);
+    for (auto& bw : p->blk)
+      for (int j = 0; j < c.n_sub_blocks; ++j) { bw.w8.push_back(b.take(H * H)); bw.w8s.push_back(b.take(H * sizeof(float))); }
+    p->fp8_table = b.take(sizeof(Fp8CastDesc) * (size_t)std::max(1, c.n_mega_blocks * c.n_sub_blocks));
   }
   p->E = b.take(M * D * e);
   p->HID = b.take(M * A * e);
@@ -475,6 +485,16 @@ extern "C" int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbu
     p->n_swz = (int)sd.size();
     if (p->n_swz) TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->swz_table, sd.data(), sd.size() * sizeof(SwzDesc), hipMemcpyHostToDevice, st));
   }
+  if (p->fp8) {
+    std::vector<Fp8CastDesc> fd;
+    for (int i = 0; i < c.n_mega_blocks; ++i)
+      for (int j = 0; j < c.n_sub_blocks; ++j)
+        fd.push_back(Fp8CastDesc{params + m->blocks[i].sub[j].wpw, (uint8_t*)(p->ws + p->blk[i].w8[j]), (float*)(p->ws + p->blk[i].w8s[j]),
+                                 c.hidden, c.hidden});
+    p->n_fp8 = (int)fd.size();
+    if (p->n_fp8) TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->fp8_table, fd.data(), fd.size() * sizeof(Fp8CastDesc), hipMemcpyHostToDevice, st));
+    TN_CHECK_HIP(hipStreamSynchronize(st));
+  }
   p->n_cast = (int)cd.size();
   TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->cast_table, cd.data(), cd.size() * sizeof(CastDesc), hipMemcpyHostToDevice, st));
   std::vector<BnUpdateDesc> bd(m->n_bn);
@@ -583,6 +603,8 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
     hipLaunchKernelGGL(cast_params_kernel<AT>, dim3(64, p->n_cast), dim3(256), 0, st, (const CastDesc*)(ws + p->cast_table));
     if (p->n_swz) hipLaunchKernelGGL(swizzle256_kernel<0>, dim3(16, p->n_swz), dim3(256), 0, st, (const SwzDesc*)(ws + p->swz_table));
   }
+  if (p->fp8 && p->n_fp8 > 0)
+    hipLaunchKernelGGL(cast_fp8_rows_kernel, dim3(64, p->n_fp8), dim3(64), 0, st, (const Fp8CastDesc*)(ws + p->fp8_table));
   if (!training) {
     // eval: BatchNorm uses the running statistics -> write the equivalent sums once for all layers
     hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(2, m->n_bn), dim3(256), 0, st, (const BnUpdateDesc*)(ws + p->bn_table),
@@ -637,10 +659,19 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
         } else if (p->split_dw && p->save_q) {
           // wide models: the depthwise output is produced once by a streaming kernel (it is kept for the weight gradients
           // anyway) and the pointwise GEMM reads it as a plain operand
-          rc = launch_dw_fwd<AT>((const AT*)cur, acur, params + sb.wdw, params + sb.bdw, (AT*)(ws + bw.Q[j]), M, T, H, c.kernel, st);
+          uint8_t* q8 = (p->fp8 && sizeof(AT) == 2) ? (uint8_t*)(ws + p->q8) : nullptr;
+          rc = launch_dw_fwd<AT>((const AT*)cur, acur, params + sb.wdw, params + sb.bdw, (AT*)(ws + bw.Q[j]), M, T, H, c.kernel, st, q8);
           if (rc) return rc;
-          ProdPlain::Args pq{ws + bw.Q[j], H, identity_act()};
-          rc = gemm_store<AT, ProdPlain>(g, pq, ea, 0, st);
+          if (q8) {
+            // TN_PREC_FP8: e4m3 x e4m3 -> f32 on the fp8 matrix cores, per-output-channel weight scales in the epilogue
+            GemmShape g8{M, H, H, ws + bw.w8[j]};
+            EpiStoreArgs e8 = ea;
+            e8.colscale = (const float*)(ws + bw.w8s[j]);
+            rc = launch_gemm_fp8<EpiStore>(g8, q8, e8, st);
+          } else {
+            ProdPlain::Args pq{ws + bw.Q[j], H, identity_act()};
+            rc = gemm_store<AT, ProdPlain>(g, pq, ea, 0, st);
+          }
         } else {
           rc = gemm_store<AT, ProdDw>(g, pa, ea, c.kernel, st);
         }

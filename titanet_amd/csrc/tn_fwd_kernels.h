@@ -31,6 +31,37 @@ __global__ void cast_params_kernel(const CastDesc* descs) {
 }
 
 // ------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) helpers and the per-step weight cast of the TN_PREC_FP8 plan: W8[n][:] = e4m3(W[n][:] / s[n]) with
+// s[n] = max|W[n][:]| / 448 (the largest finite e4m3), one workgroup (one wave) per output row.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f2fp8x4(float a, float b, float c, float d) {
+  uint32_t w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return w;
+}
+struct Fp8CastDesc { const float* src; uint8_t* dst; float* scale; int R, C; };
+__global__ __launch_bounds__(64) void cast_fp8_rows_kernel(const Fp8CastDesc* descs) {
+  const Fp8CastDesc d = descs[blockIdx.y];
+  const int lane = threadIdx.x;
+  for (int r = blockIdx.x; r < d.R; r += gridDim.x) {
+    const float* w = d.src + (size_t)r * d.C;
+    float m = 0.f;
+    for (int c = lane * 4; c < d.C; c += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(w + c);
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    m = wave_max(m);
+    const float sc = m > 0.f ? m * (1.f / 448.f) : 1.f, inv = 1.f / sc;
+    if (lane == 0) d.scale[r] = sc;
+    for (int c = lane * 4; c < d.C; c += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(w + c);
+      *reinterpret_cast<uint32_t*>(d.dst + (size_t)r * d.C + c) = f2fp8x4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Stand-alone depthwise producer for the WIDE models (hidden 1024, TitaNet-L): Q = dwconv_KD(act(X)) + b_dw
 // (reference src/modules.py:65-75).  Fusing this producer into the pointwise GEMM (ProdDw) recomputes activation +
 // stencil once per 256-column block of the output — 4 times at hidden 1024, with K = 11 taps — and made the forward GEMM
@@ -43,7 +74,8 @@ __global__ void cast_params_kernel(const CastDesc* descs) {
 // ------------------------------------------------------------------------------------------
 template <typename AT, int KD>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const AT* __restrict__ X, BnAct act, const float* __restrict__ wdw,
-                                                     const float* __restrict__ bdw, AT* __restrict__ Q, int M, int T, int C) {
+                                                     const float* __restrict__ bdw, AT* __restrict__ Q, int M, int T, int C,
+                                                     uint8_t* __restrict__ Q8) {
   constexpr int PAD = (KD - 1) / 2, RT = 64, ROWS = RT + KD - 1, CW = 256, XP = CW + 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   AT* Xs = reinterpret_cast<AT*>(smem);                       // [ROWS][XP] activated rows
@@ -100,12 +132,18 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const AT* __restrict__ X, B
       }
     }
     store8(Q + (size_t)gr * C + c0, o);
+    if (Q8) {       // TN_PREC_FP8: the same values in e4m3 for the fp8 pointwise GEMM (unit scale: the operand is O(1))
+      uint2 w;
+      w.x = f2fp8x4(o[0], o[1], o[2], o[3]);
+      w.y = f2fp8x4(o[4], o[5], o[6], o[7]);
+      *reinterpret_cast<uint2*>(Q8 + (size_t)gr * C + c0) = w;
+    }
   }
   }
 }
 template <typename AT>
 inline int launch_dw_fwd(const AT* X, const BnAct& act, const float* wdw, const float* bdw, AT* Q, int M, int T, int C, int KD,
-                         hipStream_t st) {
+                         hipStream_t st, uint8_t* Q8 = nullptr) {
   const int slabs = (C + 255) / 256, tiles = (M + 63) / 64;
   dim3 grid(std::min(tiles, std::max(1, 768 / slabs)), slabs);       // ~3 resident workgroups per CU
   const size_t smem = (size_t)(64 + KD - 1) * (256 + 8) * sizeof(AT) + 2 * 256 * sizeof(float);
@@ -114,7 +152,7 @@ inline int launch_dw_fwd(const AT* X, const BnAct& act, const float* wdw, const 
   case K: {                                                                                                         \
     auto kern = dw_fwd_kernel<AT, K>;                                                                               \
     if (smem > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -4; \
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, X, act, wdw, bdw, Q, M, T, C);                              \
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, X, act, wdw, bdw, Q, M, T, C, Q8);                          \
   } break;
     TN_DWF_CASE(3) TN_DWF_CASE(5) TN_DWF_CASE(7) TN_DWF_CASE(9) TN_DWF_CASE(11) TN_DWF_CASE(13) TN_DWF_CASE(15)
 #undef TN_DWF_CASE

@@ -298,6 +298,7 @@ struct EpiStoreArgs {
   const float* bias;   // [N] or null
   float* stats;        // [TN_NREP][2][N] or null
   RowMask rm;          // rows left out of the statistics (variable-length batches); {null, 0}: none
+  const float* colscale;   // [N] or null: y = acc * colscale[n] + bias[n] (fp8 weights: one scale per output channel)
 };
 __device__ __forceinline__ float fast_tanh(float x) {
   const float e = __expf(2.f * x);       // inf for large x -> 1, 0 for very negative x -> -1
@@ -326,12 +327,13 @@ struct EpiStoreT {
     for (int nt = 0; nt < 2; ++nt) {
       const int n = wn * 64 + nt * 32 + (lane & 31);
       const float b = (e.bias && n0 + n < g.N) ? e.bias[n0 + n] : 0.f;
+      const float cs = (e.colscale && n0 + n < g.N) ? e.colscale[n0 + n] : 1.f;
       float s = 0.f, q = 0.f;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float y = acc[mt][nt][r] + b;
+          float y = fmaf(acc[mt][nt][r], cs, b);
           if (TANH) y = fast_tanh(y);
           acc[mt][nt][r] = y;
           const int row = r0 + wm * 64 + mt * 32 + cd_row(r, lane);
@@ -404,5 +406,76 @@ inline int launch_gemm(const GemmShape& g, const typename Prod::Args& pa, const 
   }
   dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN);
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, g, pa, ea);
+  return (int)hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------------------------
+// fp8 variant (TN_PREC_FP8): C[M x N] = A8[M x K] * W8[N x K]^T on v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3, f32 accumulate).
+// Both operands are plain fp8 matrices in HBM (the depthwise producer of the wide models writes its output in e4m3
+// beside the bf16 copy the weight gradients read; the weights are cast once per step with one scale per output row), so
+// the tiles are straight 16-byte copies: half the operand bytes of the bf16 GEMM through HBM, L2 and LDS.  Same
+// tiling, fragment layout (8 K-elements per lane) and epilogue as gemm_nt_kernel; the epilogue applies the row scales.
+// ------------------------------------------------------------------------------------------
+template <int WM, int WN, typename Epi>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 4 : 3)) void gemm_fp8_nt_kernel(GemmShape g, const uint8_t* __restrict__ A8,
+                                                                                          typename Epi::Args ea) {
+  constexpr int BM = WM * 64, BN = WN * 64, BK = 128, BKP = BK + 16, NT = WM * WN * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint8_t* As = reinterpret_cast<uint8_t*>(smem);
+  uint8_t* Bs = As + BM * BKP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const uint8_t* W8 = reinterpret_cast<const uint8_t*>(g.W);
+  auto fill = [&](uint8_t* dst, const uint8_t* src, int rows, int nrows, int row0, int kc) {
+    constexpr int VC = BK / 16;
+    for (int i = tid; i < rows * VC; i += NT) {
+      const int r = i / VC, v = i % VC, gr = row0 + r, k = kc + v * 16;
+      uint4 x = make_uint4(0, 0, 0, 0);
+      if (gr < nrows && k < g.K) x = *reinterpret_cast<const uint4*>(src + (size_t)gr * g.K + k);
+      *reinterpret_cast<uint4*>(dst + r * BKP + v * 16) = x;
+    }
+  };
+  for (int kc = 0; kc < g.K; kc += BK) {
+    fill(Bs, W8, BN, g.N, n0, kc);
+    fill(As, A8, BM, g.M, r0, kc);
+    __syncthreads();
+    const uint8_t* arow0 = As + (wm * 64 + (lane & 31)) * BKP + (lane >> 5) * 8;
+    const uint8_t* brow0 = Bs + (wn * 64 + (lane & 31)) * BKP + (lane >> 5) * 8;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const long a0 = *reinterpret_cast<const long*>(arow0 + ks * 16);
+      const long a1 = *reinterpret_cast<const long*>(arow0 + 32 * BKP + ks * 16);
+      const long b0 = *reinterpret_cast<const long*>(brow0 + ks * 16);
+      const long b1 = *reinterpret_cast<const long*>(brow0 + 32 * BKP + ks * 16);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  Epi::template run<bf16_t, WM, WN>(acc, ea, g, smem, tid, r0, n0);
+}
+
+template <typename Epi>
+inline int launch_gemm_fp8(const GemmShape& g, const uint8_t* A8, const typename Epi::Args& ea, hipStream_t stream) {
+  constexpr int WM = 2, WN = 4, BM = WM * 64, BN = WN * 64;
+  if (g.K % 16) return -2;
+  size_t smem = (size_t)(BM + BN) * (128 + 16);
+  const size_t epi = Epi::template lds_bytes<bf16_t, WM, WN>();
+  if (epi > smem) smem = epi;
+  auto kern = gemm_fp8_nt_kernel<WM, WN, Epi>;
+  if (smem > 64 * 1024) TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN);
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, g, A8, ea);
   return (int)hipGetLastError();
 }

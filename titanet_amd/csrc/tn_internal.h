@@ -67,6 +67,7 @@ struct BlockWs {
   size_t S, OUT;
   size_t m, h, g;          // SE: mean [B][C], hidden [B][Hr], gate [B][C]  (float)
   std::vector<WcRef> wpw;
+  std::vector<size_t> w8, w8s;   // TN_PREC_FP8: e4m3 pointwise weights [H][H] and their per-row scales [H] (float)
   WcRef wskip;
   // backward (float): SE pre-activation grads
   size_t dpre2, dpre1, dgate;
@@ -92,6 +93,9 @@ struct tn_plan {
   bool bound = false;
   // workspace layout (byte offsets)
   size_t zero_begin, zero_bytes;        // region cleared at the start of every forward
+  bool fp8 = false;                     // TN_PREC_FP8: forward pointwise GEMMs of the sub-blocks on the fp8 matrix cores
+  size_t q8 = 0, fp8_table = 0;         // e4m3 copy of the current depthwise output [M][H] bytes; weight-cast descriptors
+  int n_fp8 = 0;
   bool split_dw = false;                // wide models: depthwise producer as its own streaming kernel (forward)
   bool save_q = false;                  // forward stores the depthwise outputs (bf16 v2 path with batched weight gradients)
   int combine_parts = 4;                // row parts per utterance of the v2 element-wise kernels (env TN_PARTS)

@@ -304,7 +304,7 @@ class TitaNet(nn.Module):
 
     # ------------------------------------------------------------------ native calls
     def _prec(self):
-        return {"fp32": _lib.TN_PREC_FP32, "bf16": _lib.TN_PREC_BF16}[self.precision]
+        return {"fp32": _lib.TN_PREC_FP32, "bf16": _lib.TN_PREC_BF16, "fp8": _lib.TN_PREC_FP8}[self.precision]
 
     def _get_plan(self, batch, frames):
         key = (batch, frames, self._prec())

@@ -37,8 +37,9 @@ def run(size, nblocks, prec, head, B=256, T=300, steps=10):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:            # e.g. `python tools/size_bench.py m l`: only the named sizes, bf16
-        for sz in sys.argv[1:]:
-            run(sz, {"s": 17, "m": 10, "l": 5}[sz], "bf16", "ce")
+        for sz in sys.argv[1:]:           # "l" -> bf16, "l:fp8" -> the fp8 pointwise plan
+            name, _, prec = sz.partition(":")
+            run(name, {"s": 17, "m": 10, "l": 5}[name], prec or "bf16", "ce")
         sys.exit(0)
     run("s", 17, "bf16", "ce")
     run("s", 17, "bf16", "arc")
