@@ -408,6 +408,8 @@ extern "C" void tn_plan_destroy(tn_plan* p) {
   if (!p) return;
   for (auto e : p->prof_events) (void)hipEventDestroy(e);
   for (auto e : p->bucket_events) (void)hipEventDestroy(e);
+  for (auto e : p->fork_events) (void)hipEventDestroy(e);
+  if (p->side_stream) (void)hipStreamDestroy(p->side_stream);
   delete p;
 }
 
@@ -517,6 +519,15 @@ extern "C" int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbu
     hipEvent_t e;
     TN_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     p->bucket_events.push_back(e);
+  }
+  {
+    const char* ss = getenv("TN_WGRAD_STREAM");
+    if (!p->side_stream && ss && atoi(ss) != 0) TN_CHECK_HIP(hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking));
+    while (p->fork_events.size() < 64) {
+      hipEvent_t e;
+      TN_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      p->fork_events.push_back(e);
+    }
   }
   p->bound = true;
   return 0;

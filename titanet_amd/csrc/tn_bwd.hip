@@ -78,9 +78,18 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   int rc_fin = 0;
   // ---- everything that turns accumulated sums / kept tensors into the final gradients of ONE bucket, then the bucket's
   // event: with grad_groups > 1 the data-parallel trainer all-reduces bucket k while the backward of earlier blocks runs
+  const hipStream_t main_st = st;
   auto finalize_bucket = [&](int k) {
     const tn_plan::GradBucket& bk = p->buckets[k];
     const bool has_blocks = bk.blk_hi >= bk.blk_lo;
+    // every bucket but the last runs on the side stream (fork here, joined at the end of backward): nothing it reads is
+    // written again by the rest of backward (per-layer kept gradients, per-layer sums, per-block SE scratch)
+    hipStream_t st = main_st;
+    if (p->side_stream && k + 1 < (int)p->buckets.size() && k < (int)p->fork_events.size()) {
+      (void)hipEventRecord(p->fork_events[k], main_st);
+      (void)hipStreamWaitEvent(p->side_stream, p->fork_events[k], 0);
+      st = p->side_stream;
+    }
     if (bk.prolog) {
       const int cur_ = p->prolog_cur;
       ProdDy::Args pa{ws + p->dA[cur_], ws + p->Y0, H, make_bnbwd(p, m->prolog_bn, M, training)};
@@ -455,6 +464,9 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   // weight gradients (v2: all of the bucket's layers in one balanced launch), sums -> BatchNorm / bias / SE gradients
   finalize_bucket((int)p->buckets.size() - 1);
   if (rc_fin) return rc_fin;
+  if (p->side_stream)      // join: the caller's stream owns every gradient when tn_backward's work is done
+    for (int k = 0; k + 1 < (int)p->buckets.size() && k < (int)p->bucket_events.size(); ++k)
+      (void)hipStreamWaitEvent(main_st, p->bucket_events[k], 0);
   return (int)hipGetLastError();
 }
 

@@ -144,6 +144,10 @@ struct tn_plan {
   int grad_groups = 1;            // 1: one bucket, every deferred weight gradient in one launch at the end of backward
   std::vector<GradBucket> buckets;
   std::vector<hipEvent_t> bucket_events;
+  // optional: all but the last bucket are finalised on a plan-owned side stream (fork / join by events), so that their
+  // bandwidth-bound weight-gradient launches fill the launch gaps and tails of the dependent backward chain
+  hipStream_t side_stream = nullptr;
+  std::vector<hipEvent_t> fork_events;
   // per-kernel event timing (tn_profile_*)
   int prof_class = 0;
   std::vector<hipEvent_t> prof_events;

@@ -118,7 +118,8 @@ class TitaNet(nn.Module):
         self._step = 0
         self._seed_base = int(torch.initial_seed()) & 0xFFFFFFFFFFFF
         self._opt_state = None
-        self.grad_groups = 1         # > 1: tn_backward finalises the gradient in 1 + grad_groups buckets (data-parallel overlap)
+        import os
+        self.grad_groups = int(os.environ.get("TN_GRAD_GROUPS", "1"))   # > 1: tn_backward finalises the gradient in 1 + grad_groups buckets (data-parallel overlap)
 
         # ---- flat storage + mirrored module tree
         dev = torch.device(device)
