@@ -175,7 +175,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   {
     const char* e = getenv("TN_V2");
     // TN_V2 = bit mask (debug / A-B): 1 forward sub-block, 2 forward skip conv, 4 batched weight gradients, 8 fused data-gradient kernel; default all
-    const int mask = e ? atoi(e) : 63;   // 16: wide (1536-channel) decoder-side kernels
+    const int mask = e ? atoi(e) : 127;   // 16: wide (1536-channel) decoder-side kernels; 64: fused dgrad + depthwise backward
     p->use_v2 = (precision == TN_PREC_BF16 && !p->fp8 && m->cfg.hidden == 256 && m->cfg.kernel == 3) ? mask : 0;
     // 32: keep the depthwise outputs for the batched weight gradients (needs 1 and 4)
     p->save_q = (p->use_v2 & 1) && (p->use_v2 & 4) && (p->use_v2 & 32);

@@ -373,6 +373,28 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         }
         if (rc) return rc;
       }
+      if (v2_bwd && (use_v2 & 64)) {
+        // (A + B) in one pass: dD never leaves the CU (dgrad_dw_v6)
+        DgradDwArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.dZ = (const bf16_t*)(ws + bw.dY[j]); fa.Y = (const bf16_t*)(ws + bw.Y[j]); fa.bn = pa.bn;
+        fa.Wswz = bw.wpw[j].swt ? (const uint4*)(ws + bw.wpw[j].swt) : nullptr;
+        fa.X = (const bf16_t*)sin; fa.actX = asin; fa.wdw = params + sb.wdw; fa.M = M; fa.T = T;
+        fa.gacc = (float*)(ws + p->dw_gacc) + (size_t)(i * nsub + j) * TN_NREP * (c.kernel + 1) * H;
+        if (j > 0) {
+          fa.ADD = nullptr; fa.OUT = (bf16_t*)(ws + bw.dY[j - 1]); fa.bsumsX = bsum(mb.sub[j - 1].bn);
+        } else {
+          fa.ADD = (const bf16_t*)(ws + p->dXs); fa.OUT = (bf16_t*)(ws + p->dA[cur ^ 1]);
+          fa.bsumsX = (i == 0) ? bsum(m->prolog_bn) : nullptr;
+        }
+        int rc;
+        {
+          ProfScope ps(p, TN_PROF_BWD_DGRAD, st);
+          rc = launch_dgrad_dw_v6(fa, 256, st);
+        }
+        if (rc > 0) return rc;
+        if (rc == 0) continue;
+      }
       if (v2_bwd) {
         // (A) pointwise data gradient dD = BN-backward(dZ, Y) * W   (persistent MFMA kernel, W^T in registers)
         DgradV2Args va;

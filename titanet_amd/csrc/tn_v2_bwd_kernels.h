@@ -1065,6 +1065,291 @@ inline int launch_dgrad_v2(DgradV2Args a, int max_wgs, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+// ==========================================================================================
+// dgrad_dw_v6: pointwise data gradient + depthwise / activation backward of one sub-block in ONE pass
+//   dD   = BatchNorm-backward-on-load(dZ, Y) * W                    (MFMA, W^T resident in registers)
+//   dA   = sum_k w_dw[c][k] dD[r - k + pad]  (+ ADD)                  (transposed stencil over time, through LDS)
+//   OUT  = dA * d act / d bn (X)  -> stored;  BN-backward sums of the layer that made X;  d w_dw, d b_dw
+// dgrad_v2 + dw_bwd_v4 wrote dD (one rows x 256 tensor) to HBM and read it back: 6 passes per sub-block; this kernel
+// moves 4 (dZ, Y, X in, OUT out).  Both predecessors run at the rate of a plain streaming kernel, so the passes are the
+// time.  Tiles are 32 GEMM rows that yield 30 output rows (the stencil needs dD[r-1] and dD[r+1]: consecutive tiles
+// overlap by two rows, re-read from L2), small enough that the three input streams of the NEXT tile (48 KB per CU) stay in
+// flight in registers (6 x 16 bytes per thread) without spilling next to the 64 weight VGPRs.
+// FL bits: 1 = BatchNorm on load of X, 2 = ReLU, 4 = dropout, 8 = skip-path addend.
+// ==========================================================================================
+#define V6_R 32
+#define V6_OUT 30
+struct DgradDwArgs {
+  const bf16_t* dZ; const bf16_t* Y; BnBwd bn;       // gradient wrt the BatchNorm output of this sub-block, its raw output
+  const uint4* Wswz;                                   // W^T in MFMA-fragment order (swizzle256_kernel)
+  const bf16_t* X; BnAct actX;                         // raw input of the sub-block's depthwise conv + its activation
+  const bf16_t* ADD;                                   // or null
+  bf16_t* OUT;
+  const float* wdw;
+  float* gacc;                                         // [TN_NREP][KD + 1][256]
+  float* bsumsX;                                       // or null
+  int M, T, ntiles;
+};
+
+template <int FL>
+__global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
+  constexpr int KD = 3, NT = V2_NT;
+  constexpr bool HAS_MASK = (FL & 7) != 0, HAS_ADD = (FL & 8) != 0;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* Pt = reinterpret_cast<bf16_t*>(smem);          // [32][264] BN-backward'd dY rows (MFMA B operand)
+  bf16_t* Dt = Pt + V6_R * V2_AP;                         // [32][264] dD rows
+  bf16_t* Xs = Dt + V6_R * V2_AP;                         // [32][256] raw X rows
+  float* cst = reinterpret_cast<float*>(Xs + V6_R * V2_C);   // k0,k1,k2, sc,sh,mean*rstd,rstd, wd[3] : [10][256]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int vc = tid & 31, rq = tid >> 5, c0 = vc * 8;   // transform layout: 8 channels x rows rq, rq + 16
+  const int c4 = lane * 4;                               // stencil layout: 4 channels per lane, one wave per strip of 4 rows
+  const float mscale = (FL & 4) ? a.actX.inv_keep : 1.f;
+  const uint32_t dkey = tn_act_key(a.actX), dthr = a.actX.drop_thr;
+  if (tid < V2_C) {
+    float k0, k1, k2, s = 1.f, h = 0.f, mean = 0.f, rstd = 1.f;
+    bn_bwd_coefs(a.bn, V2_C, tid, k0, k1, k2);
+    if (FL & 1) { bn_scale_shift(a.actX, V2_C, tid, s, h); bn_mean_rstd(a.actX, V2_C, tid, mean, rstd); }
+    cst[tid] = k0; cst[V2_C + tid] = k1; cst[2 * V2_C + tid] = k2;
+    cst[3 * V2_C + tid] = s; cst[4 * V2_C + tid] = h; cst[5 * V2_C + tid] = mean * rstd; cst[6 * V2_C + tid] = rstd;
+#pragma unroll
+    for (int k = 0; k < KD; ++k) cst[(7 + k) * V2_C + tid] = a.wdw[(size_t)tid * KD + k];
+  }
+  bf16x8_t wf[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) wf[ks] = __builtin_bit_cast(bf16x8_t, a.Wswz[((size_t)wave * 16 + ks) * 64 + lane]);
+  uint4 pz[2], py[2], px[2];
+  auto prefetch = [&](int tile) {
+    const int g0 = tile * V6_OUT - 1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int gr = g0 + rq + 16 * q;
+      const bool ok = gr >= 0 && gr < a.M;
+      const size_t o = (size_t)gr * V2_C + c0;
+      pz[q] = ok ? *reinterpret_cast<const uint4*>(a.dZ + o) : make_uint4(0, 0, 0, 0);
+      py[q] = ok ? *reinterpret_cast<const uint4*>(a.Y + o) : make_uint4(0, 0, 0, 0);
+      px[q] = ok ? *reinterpret_cast<const uint4*>(a.X + o) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) prefetch(tile);
+  __syncthreads();
+  float sc[4], sh[4], wd[KD][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    sc[i] = cst[3 * V2_C + c4 + i]; sh[i] = cst[4 * V2_C + c4 + i];
+#pragma unroll
+    for (int k = 0; k < KD; ++k) wd[k][i] = cst[(7 + k) * V2_C + c4 + i];
+  }
+  float gw[KD][4], gb[4], s1[4], s2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    gb[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KD; ++k) gw[k][i] = 0.f;
+  }
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    const int g0 = tile * V6_OUT - 1;          // global row of tile row 0
+    __syncthreads();   // (1) the previous tile's stencil is done with Dt / Xs, its MFMAs with Pt
+    // ---- BN backward on load -> Pt;  raw X rows -> Xs
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = rq + 16 * q, gr = g0 + r;
+      float z[8], y[8];
+      unpack8(pz[q], z);
+      unpack8(py[q], y);
+      if (gr >= 0 && gr < a.M) {
+        const float* kk = cst + c0;          // k0, k1, k2 from LDS: the registers go to the stencil window
+#pragma unroll
+        for (int i = 0; i < 8; ++i) z[i] = kk[i] * z[i] + kk[V2_C + i] * y[i] + kk[2 * V2_C + i];
+      }
+      store8(Pt + r * V2_AP + c0, z);
+      *reinterpret_cast<uint4*>(Xs + r * V2_C + c0) = px[q];
+    }
+    if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
+    __syncthreads();   // (2)
+    // ---- dD = dY * W : 32 rows x this wave's 32 input channels
+    {
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const bf16_t* brow = Pt + (lane & 31) * V2_AP + half * 8;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], *reinterpret_cast<const bf16x8_t*>(brow + ks * 16), acc, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 w;
+        w.x = f2bf_pk(acc[4 * g], acc[4 * g + 1]);
+        w.y = f2bf_pk(acc[4 * g + 2], acc[4 * g + 3]);
+        *reinterpret_cast<uint2*>(Dt + (lane & 31) * V2_AP + wave * 32 + 8 * g + 4 * half) = w;
+      }
+    }
+    __syncthreads();   // (3)
+    // ---- transposed stencil + activation backward: wave = strip of 4 output rows (tile rows 1 + 4*wave ..), lane = 4 channels
+    {
+      const int i0 = 1 + 4 * wave;               // first output row of the strip (tile row index)
+      const int gfirst = g0 + i0 - 1, glast = g0 + i0 + 4;     // window rows i0-1 .. i0+4
+      const bool fast = i0 + 4 <= V6_OUT + 1 && gfirst >= 0 && glast < a.M && (gfirst % a.T) + 5 < a.T;   // wave-uniform
+      auto ldD = [&](int i, float* D) { unpack4(*reinterpret_cast<const uint2*>(Dt + i * V2_AP + c4), D); };
+      auto ldX = [&](int i, float* Yr) { unpack4(*reinterpret_cast<const uint2*>(Xs + i * V2_C + c4), Yr); };
+      uint2 addv[4];
+      if (HAS_ADD) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int gr = g0 + i0 + q;
+          addv[q] = (i0 + q <= V6_OUT && gr >= 0 && gr < a.M) ? *reinterpret_cast<const uint2*>(a.ADD + (size_t)gr * V2_C + c4) : make_uint2(0, 0);
+        }
+      }
+      if (fast) {
+        // rolling 3-row window (slots j % 3): every window row is loaded, unpacked and activated once
+        float D[3][4], A[3][4], Yr[3][4];
+        auto place = [&](int j, int slot) {
+          ldD(i0 - 1 + j, D[slot]);
+          ldX(i0 - 1 + j, Yr[slot]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) A[slot][i] = Yr[slot][i];
+          act4_t<FL>(A[slot], sc, sh, dkey, dthr, (uint32_t)(gfirst + j), c4);
+        };
+        place(0, 0);
+        place(1, 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int P = q % 3, C_ = (q + 1) % 3, N = (q + 2) % 3;
+          place(q + 2, N);
+          float dA[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            gb[i] += D[C_][i];
+            dA[i] = wd[1][i] * D[C_][i];
+            dA[i] = fmaf(wd[0][i], D[N][i], dA[i]);
+            dA[i] = fmaf(wd[2][i], D[P][i], dA[i]);
+            gw[0][i] = fmaf(D[C_][i], A[P][i], gw[0][i]);
+            gw[1][i] = fmaf(D[C_][i], A[C_][i], gw[1][i]);
+            gw[2][i] = fmaf(D[C_][i], A[N][i], gw[2][i]);
+          }
+          if (HAS_ADD) {
+            float ad[4];
+            unpack4(addv[q], ad);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dA[i] += ad[i];
+          }
+          if (HAS_MASK) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float m = (FL & 2) ? ((A[C_][i] > 0.f) ? mscale : 0.f) : mscale;
+              dA[i] *= m;
+              s1[i] += dA[i];
+              s2[i] = fmaf(dA[i], Yr[C_][i], s2[i]);
+            }
+          }
+          uint2 ov;
+          ov.x = f2bf_pk(dA[0], dA[1]);
+          ov.y = f2bf_pk(dA[2], dA[3]);
+          *reinterpret_cast<uint2*>(a.OUT + (size_t)(g0 + i0 + q) * V2_C + c4) = ov;
+          __builtin_amdgcn_sched_barrier(0);       // rows in order: bounds the live temporaries
+        }
+      } else {
+        // boundary strips (utterance edges, ends of the batch, the short last strip): per-row wave-uniform tests
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+          const int i = i0 + q, gr = g0 + i;
+          if (i > V6_OUT || gr < 0 || gr >= a.M) continue;
+          const int t = gr % a.T;
+          float Dc[4], Dn[4], Dp[4], Ac[4], An[4], Ap[4], Yc[4], dA[4];
+          ldD(i, Dc); ldX(i, Yc);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) Ac[c] = Yc[c];
+          act4_t<FL>(Ac, sc, sh, dkey, dthr, (uint32_t)gr, c4);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            gb[c] += Dc[c];
+            dA[c] = wd[1][c] * Dc[c];
+            gw[1][c] = fmaf(Dc[c], Ac[c], gw[1][c]);
+          }
+          if (t + 1 < a.T && gr + 1 < a.M) {      // next row belongs to the same utterance (tile row i + 1 <= 31 exists)
+            ldD(i + 1, Dn); ldX(i + 1, An);
+            act4_t<FL>(An, sc, sh, dkey, dthr, (uint32_t)(gr + 1), c4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { dA[c] = fmaf(wd[0][c], Dn[c], dA[c]); gw[2][c] = fmaf(Dc[c], An[c], gw[2][c]); }
+          }
+          if (t > 0) {
+            ldD(i - 1, Dp); ldX(i - 1, Ap);
+            act4_t<FL>(Ap, sc, sh, dkey, dthr, (uint32_t)(gr - 1), c4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { dA[c] = fmaf(wd[2][c], Dp[c], dA[c]); gw[0][c] = fmaf(Dc[c], Ap[c], gw[0][c]); }
+          }
+          if (HAS_ADD) {
+            float ad[4];
+            unpack4(*reinterpret_cast<const uint2*>(a.ADD + (size_t)gr * V2_C + c4), ad);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dA[c] += ad[c];
+          }
+          if (HAS_MASK) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float m = (FL & 2) ? ((Ac[c] > 0.f) ? mscale : 0.f) : mscale;
+              dA[c] *= m;
+              s1[c] += dA[c];
+              s2[c] = fmaf(dA[c], Yc[c], s2[c]);
+            }
+          }
+          uint2 ov;
+          ov.x = f2bf_pk(dA[0], dA[1]);
+          ov.y = f2bf_pk(dA[2], dA[3]);
+          *reinterpret_cast<uint2*>(a.OUT + (size_t)gr * V2_C + c4) = ov;
+        }
+      }
+    }
+  }
+  // s2 was accumulated against the RAW x:  sum dA * xhat = rstd * sum dA*x - mean*rstd * sum dA
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s2[i] = cst[6 * V2_C + c4 + i] * s2[i] - cst[5 * V2_C + c4 + i] * s1[i];
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);       // [8 waves][KD + 3][256] (inside the tiles; cst stays intact)
+  {
+    float* mine = red + (size_t)wave * (KD + 3) * V2_C + c4;
+#pragma unroll
+    for (int k = 0; k < KD; ++k) *reinterpret_cast<float4*>(mine + k * V2_C) = make_float4(gw[k][0], gw[k][1], gw[k][2], gw[k][3]);
+    *reinterpret_cast<float4*>(mine + KD * V2_C) = make_float4(gb[0], gb[1], gb[2], gb[3]);
+    *reinterpret_cast<float4*>(mine + (KD + 1) * V2_C) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+    *reinterpret_cast<float4*>(mine + (KD + 2) * V2_C) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+  }
+  __syncthreads();
+  const int rep = blockIdx.x % TN_NREP;
+  for (int i = tid; i < (KD + 3) * V2_C; i += NT) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += red[(size_t)w * (KD + 3) * V2_C + i];
+    const int k = i / V2_C, c = i % V2_C;
+    if (k <= KD) atomic_add_f32(&a.gacc[(size_t)(rep * (KD + 1) + k) * V2_C + c], v);
+    else if (a.bsumsX && HAS_MASK) atomic_add_f32(&a.bsumsX[(size_t)(rep * 2 + (k - KD - 1)) * V2_C + c], v);
+  }
+}
+
+template <int FL>
+inline int launch_dgrad_dw_v6_t(DgradDwArgs a, int grid, size_t smem, hipStream_t st) {
+  auto kern = dgrad_dw_v6_kernel<FL>;
+  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
+  return (int)hipGetLastError();
+}
+// -1000: no specialisation for this flag combination (caller runs dgrad_v2 + dw_bwd_v4)
+inline int launch_dgrad_dw_v6(DgradDwArgs a, int max_wgs, hipStream_t st) {
+  if (!a.Wswz) return -1000;
+  a.ntiles = (a.M + V6_OUT - 1) / V6_OUT;
+  const int grid = a.ntiles < max_wgs ? a.ntiles : max_wgs;
+  const size_t tiles = (size_t)(2 * V6_R * V2_AP + V6_R * V2_C) * sizeof(bf16_t);
+  const size_t red = (size_t)8 * 6 * V2_C * sizeof(float);
+  const size_t smem = (tiles > red ? tiles : red) + (size_t)10 * V2_C * sizeof(float);
+  const int fl = (a.actX.mode != 0 ? 1 : 0) | (a.actX.relu ? 2 : 0) | (a.actX.drop_thr ? 4 : 0) | (a.ADD ? 8 : 0);
+  switch (fl) {
+    case 7: return launch_dgrad_dw_v6_t<7>(a, grid, smem, st);
+    case 3: return launch_dgrad_dw_v6_t<3>(a, grid, smem, st);
+    case 8: return launch_dgrad_dw_v6_t<8>(a, grid, smem, st);
+    case 11: return launch_dgrad_dw_v6_t<11>(a, grid, smem, st);
+    default: return -1000;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // dgrad_wide_v2: data gradient of a 1x1 conv whose OUTPUT side is the 1536-wide tensor (the epilog conv):
 //   dX[M][256] = BatchNorm-backward-on-load(dZ, Y)[M][KW] * W^T        (K = KW = 1536 = 6 slabs of 256)
