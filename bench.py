@@ -39,10 +39,10 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 ALG_BYTES_PER_UTT_BF16 = 70.66e6   # 7,065,600 elements x 5 passes x 2 B (S/17, T=300, fwd+bwd)
 
-PROF_CLASSES = {1: "fwd_subblock_gemm", 2: "bwd_pointwise_wgrad", 3: "bwd_pointwise_dgrad", 4: "bwd_depthwise"}
+PROF_CLASSES = {1: "fwd_subblock_gemm", 2: "bwd_pointwise_wgrad", 3: "bwd_skip_dgrad", 4: "bwd_subblock_dgrad_depthwise"}
 # kernel behind each class on the headline shape (for the PMC traffic lookup)
 PROF_KERNELS = {1: "sub_fwd_v5_kernel<3, true, 7>", 2: "wgrad_batched_v2_kernel<3, false>", 3: "dgrad_v2_kernel<64>",
-                4: "dw_bwd_v4_kernel<3, 7>"}
+                4: "dgrad_dw_v6_kernel<7>"}
 
 
 def _pmc_file():
@@ -85,7 +85,8 @@ def kernel_own_bytes(cls, rows, hidden, esz):
         1: 3 * t,                          # read input rows once, write raw output once + the kept depthwise output (for wgrad)
         2: 3 * t + hidden * hidden * 4,    # read dYbn, Y (BN backward on load), the kept depthwise output; write dW
         3: 3 * t,                          # read dYbn, Y; write dD
-        4: 3 * t,                          # read dD, previous raw output; write dYbn(prev)
+        4: 4 * t * 32 // 30,               # fused data gradient + depthwise backward: read dYbn, Y, previous raw output; write
+                                           # dYbn(prev); 32-row tiles yield 30 rows (the overlap is re-read)
     }[cls]
 
 
@@ -95,7 +96,7 @@ def kernel_attributed_bytes(cls, rows, hidden, esz):
     data-gradient pass and never materialises the depthwise output or its gradient, so it attributes NOTHING to a separate
     weight-gradient launch and only one tensor to the depthwise backward."""
     t = rows * hidden * esz
-    return {1: 2 * t, 2: 0, 3: 2 * t, 4: 1 * t}[cls]
+    return {1: 2 * t, 2: 0, 3: 2 * t, 4: 3 * t}[cls]
 
 
 def stream_ceiling(dev, rows=256 * 300, hidden=256, sets=10, reps=40):

@@ -194,14 +194,25 @@ int tn_head_backward(int32_t loss_type, int32_t batch, int32_t emb, int32_t n_cl
  * waveforms.  waves: float32 [batch][n_samples]; out: float32 [batch][n_mels][frames],
  * frames = 1 + n_samples / hop_length (center=True), i.e. exactly the tensor tn_forward consumes.
  * masks: int32 [batch][4] = {f_start, f_end, t_start, t_end} (zeros = no mask) or NULL; the mask draws
- * (torchaudio.functional.mask_along_axis) stay on the host.  The phase-vocoder TimeStretch of the
- * reference's SpecAugment branch (src/transforms.py:168-175) is not implemented. */
+ * (torchaudio.functional.mask_along_axis) stay on the host.  Time stretch, several masks per axis and ragged batches:
+ * tn_mel_forward_batch below. */
 typedef struct tn_mel tn_mel;
 int tn_mel_create(int32_t sample_rate, int32_t n_fft, int32_t win_length, int32_t hop_length, int32_t n_mels, tn_mel** out);
 void tn_mel_destroy(tn_mel* m);
 int64_t tn_mel_num_frames(const tn_mel* m, int64_t n_samples);
 int tn_mel_forward(tn_mel* m, const float* waves, int32_t batch, int64_t n_samples, const int32_t* masks, float* out,
                    void* stream);
+/* Batched form for variable-length utterances with the full SpecAugment branch (reference src/transforms.py:168-201):
+ * waves float32 [batch][n_samples_max] (utterance b uses its first lengths[b] samples: its own frame count
+ * 1 + lengths[b] / hop and reflect padding); lengths int64 [batch] DEVICE or NULL (= n_samples_max);
+ * rates float64 [batch] DEVICE or NULL: time-stretch rate of torchaudio.transforms.TimeStretch — the reference takes
+ * .abs().pow(2) of the phase vocoder's output, so the magnitude interpolation of the vocoder is what is computed;
+ * utterance b then has ceil(frames / rate) frames; freq_mask uint8 [batch][n_mels], time_mask uint8 [batch][frames_out]
+ * DEVICE or NULL: non-zero = masked (the union of any number of mask_along_axis intervals, drawn on the host);
+ * out float32 [batch][n_mels][frames_out], zero beyond an utterance's last frame (the collate_fn layout). */
+int tn_mel_forward_batch(tn_mel* m, const float* waves, int32_t batch, int64_t n_samples_max, const int64_t* lengths,
+                         const double* rates, const uint8_t* freq_mask, const uint8_t* time_mask, int32_t frames_out, float* out,
+                         void* stream);
 
 /* ---- per-kernel timing with HIP events on the launch stream (roofline measurement) ----------------
  * Kernel classes: the heavy kernels of one mega-block sub-block (there are n_mega_blocks*n_sub_blocks
@@ -210,7 +221,9 @@ int tn_mel_forward(tn_mel* m, const float* waves, int32_t batch, int64_t n_sampl
 #define TN_PROF_FWD_SUBBLOCK 1 /* act-on-load + depthwise stencil + pointwise MFMA GEMM + BN statistics */
 #define TN_PROF_BWD_WGRAD 2    /* pointwise weight gradient (TN MFMA GEMM, recomputes the depthwise output) */
 #define TN_PROF_BWD_DGRAD 3    /* BN-backward-on-load + pointwise data-gradient MFMA GEMM */
-#define TN_PROF_BWD_DW 4       /* depthwise backward stencil + activation backward + BN backward sums */
+#define TN_PROF_BWD_DW 4       /* depthwise backward stencil + activation backward + BN backward sums; on the 256-wide bf16
+                                  path fused with the sub-block's pointwise data gradient (dgrad_dw_v6), class 3 is then the
+                                  skip-connection data gradient only */
 /* Start bracketing every launch of `kernel_class` with hipEvents (TN_PROF_NONE stops). */
 int tn_profile_begin(tn_plan* p, int32_t kernel_class);
 /* Waits for the recorded events; returns the summed kernel time and launch count since begin. */

@@ -13,8 +13,14 @@ published definitions (``torchaudio.functional.melscale_fbanks`` HTK scale / nor
 ``amplitude_to_DB`` with multiplier 10, amin 1e-10, ref 1.0, top_db None; ``mask_along_axis``).  The
 STFT itself IS pinned: ``tests/test_mel_oracle.py`` checks it against ``torch.stft`` with the exact
 argument set torchaudio's Spectrogram uses (hann periodic window zero-padded to n_fft, center=True,
-reflect padding, onesided).  The SpecAugment time-stretch (phase vocoder, transforms.py:168-175) is not
-restated (out of scope this round; parameters.yml enables only "chunk").
+reflect padding, onesided).  The torchaudio-defined pieces are additionally held to hand-computed known
+answers of their published formulas (tests/test_mel_oracle.py): HTK mel points, triangle values and their
+partition of unity, the dB constants, the mask index arithmetic, the phase vocoder's time grid.
+
+The SpecAugment time stretch (torchaudio.transforms.TimeStretch -> functional.phase_vocoder,
+transforms.py:168-175) is followed by ``.abs().pow(2)`` in the reference (:177), so only the vocoder's
+MAGNITUDE path reaches the output: mag[j] = alpha_j |S[idx_j + 1]| + (1 - alpha_j) |S[idx_j]| on the time
+grid j * rate (the accumulated phase is discarded by the abs) — ``time_stretch_power`` below.
 """
 import numpy as np
 
@@ -49,6 +55,25 @@ def stft_power(wave, n_fft=512, win_length=400, hop_length=160):
     return (spec.real ** 2 + spec.imag ** 2).T
 
 
+def stft_magnitude(wave, n_fft=512, win_length=400, hop_length=160):
+    return np.sqrt(stft_power(wave, n_fft, win_length, hop_length))
+
+
+def time_stretch_power(mag, rate):
+    """|phase_vocoder(S, rate)|^2 for S with magnitudes ``mag`` [n_freq, T] (torchaudio.functional.phase_vocoder):
+    time_steps = arange(0, T, rate); idx = floor(time_steps); alpha = time_steps % 1; S is zero-padded by two frames;
+    mag_out = alpha * |S[idx + 1]| + (1 - alpha) * |S[idx]|.  rate == 1 returns mag^2 unchanged (torchaudio short-cuts)."""
+    if rate == 1.0:
+        return mag ** 2
+    T = mag.shape[1]
+    steps = np.arange(0, T, rate, dtype=np.float64)
+    idx = np.floor(steps).astype(np.int64)
+    alpha = steps - idx
+    padded = np.concatenate([mag, np.zeros((mag.shape[0], 2))], axis=1)
+    out = alpha[None, :] * padded[:, idx + 1] + (1.0 - alpha[None, :]) * padded[:, idx]
+    return out ** 2
+
+
 def melscale_fbanks(n_freqs=257, f_min=0.0, f_max=8000.0, n_mels=80, sample_rate=16000):
     """HTK mel triangles, norm=None (torchaudio.functional.melscale_fbanks definition): [n_freqs, n_mels]."""
     all_freqs = np.linspace(0, sample_rate // 2, n_freqs)
@@ -64,10 +89,15 @@ def melscale_fbanks(n_freqs=257, f_min=0.0, f_max=8000.0, n_mels=80, sample_rate
 
 
 def mel_spectrogram(wave, sample_rate=16000, n_fft=512, win_length=400, hop_length=160, n_mels=80,
-                    freq_mask=None, time_mask=None):
+                    freq_mask=None, time_mask=None, rate=None, freq_masks=(), time_masks=()):
     """[n_mels, frames] float64: power mel spectrogram in dB, L2-normalised over the mel axis per frame,
-    then optional masks given as (start, end) index pairs (reference transforms.py:177-201)."""
-    power = stft_power(wave, n_fft, win_length, hop_length)
+    then optional masks given as (start, end) index pairs (reference transforms.py:177-201).
+    rate: SpecAugment time-stretch rate (frames become ceil(T / rate)); freq_masks / time_masks: any number of
+    (start, end) intervals applied in sequence (specaugment_*_mask_num > 1, transforms.py:189-201)."""
+    if rate is None or rate == 1.0:
+        power = stft_power(wave, n_fft, win_length, hop_length)
+    else:
+        power = time_stretch_power(stft_magnitude(wave, n_fft, win_length, hop_length), rate)
     fb = melscale_fbanks(n_fft // 2 + 1, 0.0, sample_rate / 2.0, n_mels, sample_rate)
     mel = fb.T @ power                                            # [n_mels, T]
     db = 10.0 * np.log10(np.maximum(mel, 1e-10))                  # AmplitudeToDB(power, ref=1, top_db=None)
@@ -77,6 +107,10 @@ def mel_spectrogram(wave, sample_rate=16000, n_fft=512, win_length=400, hop_leng
         out[freq_mask[0]:freq_mask[1], :] = 0.0
     if time_mask is not None:
         out[:, time_mask[0]:time_mask[1]] = 0.0
+    for f in freq_masks:
+        out[f[0]:f[1], :] = 0.0
+    for t in time_masks:
+        out[:, t[0]:t[1]] = 0.0
     return out
 
 

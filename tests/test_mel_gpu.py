@@ -26,23 +26,72 @@ def test_mel_matches_oracle(n_samples):
 
 
 def test_mel_masks_and_example_protocol():
+    """the reference's per-example transform protocol incl. the whole SpecAugment branch (time stretch, 2 + 2 masks)"""
     import random
     from titanet_amd.transforms import MelSpectrogram
     rng = np.random.default_rng(5)
     wave = torch.from_numpy(rng.normal(0, 0.05, (1, 32000)).astype(np.float32))
-    mel = MelSpectrogram(16000, n_fft=512, win_length=400, hop_length=160, n_mels=80, specaugment_probability=1.0)
+    mel = MelSpectrogram(16000, n_fft=512, win_length=400, hop_length=160, n_mels=80, specaugment_probability=1.0,
+                         specaugment_freq_mask_num=2, specaugment_time_mask_num=2)
     random.seed(0); torch.manual_seed(0)
     ex = mel({"waveform": wave, "sample_rate": 16000, "speaker": 3})
     spec = ex["spectrogram"].cpu().numpy()
-    assert spec.shape == (1, 80, 201) and ex["speaker"] == 3
-    # replay the same draws on the host and compare against the oracle with those masks
+    # replay the same draws on the host and compare against the oracle with that rate and those masks
     random.seed(0); torch.manual_seed(0)
-    random.random(); random.uniform(0.95, 1.05)
-    f = MelSpectrogram._mask_bounds(80, 0.35 * 80)
-    t = MelSpectrogram._mask_bounds(201, 0.15 * 201)
-    want = MO.mel_spectrogram(wave[0].numpy().astype(np.float64), freq_mask=f, time_mask=t)
-    assert rel_err(spec[0], want) < 1e-3
-    assert (spec[0][f[0]:f[1]] == 0).all() and (spec[0][:, t[0]:t[1]] == 0).all()
+    random.random()
+    rate = random.uniform(0.95, 1.05)
+    T = mel.n_frames(32000, rate)
+    assert spec.shape == (1, 80, T) and ex["speaker"] == 3 and T != 201
+    fms = [MelSpectrogram._mask_bounds(80, 0.35 * 80) for _ in range(2)]
+    tms = [MelSpectrogram._mask_bounds(T, 0.15 * T) for _ in range(2)]
+    want = MO.mel_spectrogram(wave[0].numpy().astype(np.float64), rate=rate, freq_masks=fms, time_masks=tms)
+    assert want.shape == (80, T)
+    assert rel_err(spec[0], want) < 1e-3, rel_err(spec[0], want)
+    for f in fms:
+        assert (spec[0][f[0]:f[1]] == 0).all()
+    for t in tms:
+        assert (spec[0][:, t[0]:t[1]] == 0).all()
+
+
+@pytest.mark.parametrize("rate", [0.95, 1.0, 1.05, 1.3])
+def test_time_stretch_matches_vocoder_magnitudes(rate):
+    from titanet_amd.transforms import MelSpectrogram
+    rng = np.random.default_rng(11)
+    wave = rng.normal(0, 0.05, (2, 20000)).astype(np.float32)
+    mel = MelSpectrogram(16000, n_fft=512, win_length=400, hop_length=160, n_mels=80, specaugment_probability=0.0)
+    out = mel.batch(torch.from_numpy(wave), rates=[rate, rate]).cpu().numpy()
+    for b in range(2):
+        want = MO.mel_spectrogram(wave[b].astype(np.float64), rate=rate)
+        assert out[b].shape == want.shape
+        assert rel_err(out[b], want) < 1e-3, rel_err(out[b], want)
+
+
+def test_ragged_batch_equals_each_utterance_alone():
+    """variable-length batch (BASELINE configs[3]): zero-padded waveforms + lengths -> the collate_fn layout, every
+    utterance with its own frame count and its own reflect padding, zeros beyond its end"""
+    from titanet_amd.transforms import MelSpectrogram
+    rng = np.random.default_rng(3)
+    lens = [32000, 16000 + 77, 48000, 700]
+    A = max(lens)
+    waves = np.zeros((4, A), dtype=np.float32)
+    for b, n in enumerate(lens):
+        waves[b, :n] = rng.normal(0, 0.05, n)
+    mel = MelSpectrogram(16000, n_fft=512, win_length=400, hop_length=160, n_mels=80, specaugment_probability=0.0)
+    out = mel.batch(torch.from_numpy(waves), lengths=lens).cpu().numpy()
+    assert out.shape == (4, 80, 1 + A // 160)
+    for b, n in enumerate(lens):
+        t = 1 + n // 160
+        want = MO.mel_spectrogram(waves[b, :n].astype(np.float64))
+        assert rel_err(out[b, :, :t], want) < 1e-3
+        assert (out[b, :, t:] == 0).all()
+    # and the network consumes it with the matching frame lengths (padding mask)
+    from titanet_amd import TitaNet
+    m = TitaNet.get_titanet(n_mega_blocks=1, model_size="s", device="cuda").eval()
+    frames = torch.tensor([1 + n // 160 for n in lens])
+    with torch.no_grad():
+        e = m(torch.from_numpy(out).cuda(), lengths=frames)
+        alone = m(torch.from_numpy(out[1:2, :, :frames[1]]).contiguous().cuda())
+    assert float((e[1:2] - alone).abs().max()) < 1e-5
 
 
 def test_mel_feeds_the_network():

@@ -389,7 +389,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         }
         int rc;
         {
-          ProfScope ps(p, TN_PROF_BWD_DGRAD, st);
+          ProfScope ps(p, TN_PROF_BWD_DW, st);
           rc = launch_dgrad_dw_v6(fa, 256, st);
         }
         if (rc > 0) return rc;

@@ -85,6 +85,126 @@ __global__ void mel_frame_kernel(const float* __restrict__ waves, int64_t n_samp
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Batched form (BASELINE.json configs[3]: variable-length utterances, SpecAugment on the GPU): utterance b has lengths[b]
+// samples (its frames, its reflect padding), an optional time-stretch rate and boolean frequency / time masks (any number
+// of mask_along_axis intervals folded into one byte vector per axis).  The reference takes .abs().pow(2) right after the
+// phase vocoder (src/transforms.py:173-177), so only the vocoder's magnitude path matters:
+//   |out[j]| = alpha |S[idx + 1]| + (1 - alpha) |S[idx]|,  j * rate = idx + alpha,  S zero beyond its last frame.
+// One workgroup produces FT = 16 consecutive frames and stores them through an LDS tile, so the [B, n_mels, T] output
+// is written in 64-byte runs along T instead of one float per (mel, frame) at stride T.
+// ------------------------------------------------------------------------------------------
+#define MEL_FT 16
+__device__ void mel_fft_magnitude(const float* __restrict__ wave, int64_t len, int frame, int n_frames, int n_fft, int log2n, int hop,
+                                  int n_freqs, const float* __restrict__ window, const float* __restrict__ twiddle, float* re, float* im,
+                                  float* mag, bool squared) {
+  const int tid = threadIdx.x, half_n = n_fft >> 1;
+  if (frame >= n_frames) {       // beyond the utterance: the vocoder's zero padding
+    for (int k = tid; k < n_freqs; k += blockDim.x) mag[k] = 0.f;
+    __syncthreads();
+    return;
+  }
+  for (int n = tid; n < n_fft; n += blockDim.x) {
+    int64_t s = (int64_t)frame * hop - half_n + n;
+    if (s < 0) s = -s;
+    if (s >= len) s = 2 * (len - 1) - s;
+    if (s < 0) s = 0;
+    const unsigned r = __brev((unsigned)n) >> (32 - log2n);
+    re[r] = wave[s] * window[n];
+    im[r] = 0.f;
+  }
+  __syncthreads();
+  for (int st = 0; st < log2n; ++st) {
+    const int half = 1 << st, len2 = half << 1;
+    for (int j = tid; j < half_n; j += blockDim.x) {
+      const int grp = j >> st, pos = j & (half - 1);
+      const int i0 = grp * len2 + pos, i1 = i0 + half;
+      const int tw = pos << (log2n - 1 - st);
+      const float c = twiddle[2 * tw], sn = twiddle[2 * tw + 1];
+      const float xr = re[i1] * c - im[i1] * sn, xi = re[i1] * sn + im[i1] * c;
+      const float ar = re[i0], ai = im[i0];
+      re[i0] = ar + xr; im[i0] = ai + xi;
+      re[i1] = ar - xr; im[i1] = ai - xi;
+    }
+    __syncthreads();
+  }
+  for (int k = tid; k < n_freqs; k += blockDim.x) {
+    const float p = re[k] * re[k] + im[k] * im[k];
+    mag[k] = squared ? p : sqrtf(p);
+  }
+  __syncthreads();
+}
+
+__global__ void mel_batch_kernel(const float* __restrict__ waves, int64_t n_samples_max, const int64_t* __restrict__ lengths,
+                                 const double* __restrict__ rates, const uint8_t* __restrict__ fmask, const uint8_t* __restrict__ tmask,
+                                 int T_out, int n_fft, int log2n, int hop, int n_mels, int n_freqs, const float* __restrict__ window,
+                                 const float* __restrict__ fb, const int* __restrict__ range, const float* __restrict__ twiddle,
+                                 float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* re = reinterpret_cast<float*>(smem);
+  float* im = re + n_fft;
+  float* p0 = im + n_fft;             // [n_freqs + 3]
+  float* p1 = p0 + n_freqs + 3;       // [n_freqs + 3]
+  float* mel = p1 + n_freqs + 3;      // [n_mels]
+  float* tile = mel + n_mels;         // [n_mels][MEL_FT + 1]
+  __shared__ float s_norm;
+  const int b = blockIdx.y, tid = threadIdx.x, j0 = blockIdx.x * MEL_FT;
+  const float* wave = waves + (size_t)b * n_samples_max;
+  const int64_t len = lengths ? lengths[b] : n_samples_max;
+  const int n_frames = (int)(1 + len / hop);
+  const double rate = rates ? rates[b] : 1.0;
+  int n_out = n_frames;
+  if (rate != 1.0) n_out = (int)ceil((double)n_frames / rate);     // len(arange(0, n_frames, rate))
+  for (int jj = 0; jj < MEL_FT; ++jj) {
+    const int j = j0 + jj;
+    if (j >= n_out || j >= T_out) {
+      for (int m = tid; m < n_mels; m += blockDim.x) tile[m * (MEL_FT + 1) + jj] = 0.f;
+      continue;       // uniform over the workgroup
+    }
+    if (rate == 1.0) {
+      mel_fft_magnitude(wave, len, j, n_frames, n_fft, log2n, hop, n_freqs, window, twiddle, re, im, p0, true);
+    } else {
+      const double pos = (double)j * rate;
+      const int idx = (int)floor(pos);
+      const float alpha = (float)(pos - (double)idx);
+      mel_fft_magnitude(wave, len, idx, n_frames, n_fft, log2n, hop, n_freqs, window, twiddle, re, im, p0, false);
+      mel_fft_magnitude(wave, len, idx + 1, n_frames, n_fft, log2n, hop, n_freqs, window, twiddle, re, im, p1, false);
+      for (int k = tid; k < n_freqs; k += blockDim.x) {
+        const float v = alpha * p1[k] + (1.f - alpha) * p0[k];
+        p0[k] = v * v;
+      }
+      __syncthreads();
+    }
+    for (int m = tid; m < n_mels; m += blockDim.x) {
+      float s = 0.f;
+      const int lo = range[2 * m], hi = range[2 * m + 1];
+      for (int k = lo; k < hi; ++k) s = fmaf(fb[(size_t)m * n_freqs + k], p0[k], s);
+      mel[m] = 10.f * log10f(fmaxf(s, 1e-10f));
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float q = 0.f;
+      for (int m = tid; m < n_mels; m += 64) q += mel[m] * mel[m];
+      q = wave_sum(q);
+      if (tid == 0) s_norm = fmaxf(sqrtf(q), 1e-12f);
+    }
+    __syncthreads();
+    const bool tm = tmask && tmask[(size_t)b * T_out + j];
+    const float inv = 1.f / s_norm;
+    for (int m = tid; m < n_mels; m += blockDim.x) {
+      float v = mel[m] * inv;
+      if (tm || (fmask && fmask[(size_t)b * n_mels + m])) v = 0.f;
+      tile[m * (MEL_FT + 1) + jj] = v;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int i = tid; i < n_mels * MEL_FT; i += blockDim.x) {
+    const int m = i / MEL_FT, jj = i % MEL_FT;
+    if (j0 + jj < T_out) out[((size_t)b * n_mels + m) * T_out + j0 + jj] = tile[m * (MEL_FT + 1) + jj];
+  }
+}
+
 extern "C" int tn_mel_create(int32_t sample_rate, int32_t n_fft, int32_t win_length, int32_t hop_length, int32_t n_mels,
                              tn_mel** out) {
   if (!out || n_fft < 16 || n_fft > 4096 || (n_fft & (n_fft - 1)) || win_length <= 0 || win_length > n_fft || hop_length <= 0 ||
@@ -141,6 +261,18 @@ extern "C" void tn_mel_destroy(tn_mel* m) {
 }
 
 extern "C" int64_t tn_mel_num_frames(const tn_mel* m, int64_t n_samples) { return m ? 1 + n_samples / m->hop : 0; }
+
+extern "C" int tn_mel_forward_batch(tn_mel* m, const float* waves, int32_t batch, int64_t n_samples_max, const int64_t* lengths,
+                                    const double* rates, const uint8_t* freq_mask, const uint8_t* time_mask, int32_t frames_out,
+                                    float* out, void* stream) {
+  if (!m || !waves || !out || batch <= 0 || n_samples_max <= 0 || frames_out <= 0) return TN_E_BADARG;
+  const size_t smem = (size_t)(2 * m->n_fft + 2 * (m->n_freqs + 3) + m->n_mels + m->n_mels * (MEL_FT + 1)) * sizeof(float);
+  const int threads = m->n_fft / 2 < 64 ? 64 : (m->n_fft / 2 > 1024 ? 1024 : m->n_fft / 2);
+  hipLaunchKernelGGL(mel_batch_kernel, dim3((frames_out + MEL_FT - 1) / MEL_FT, batch), dim3(threads), smem, (hipStream_t)stream, waves,
+                     n_samples_max, lengths, rates, freq_mask, time_mask, frames_out, m->n_fft, m->log2n, m->hop, m->n_mels, m->n_freqs,
+                     m->window, m->fb, m->range, m->twiddle, out);
+  return (int)hipGetLastError();
+}
 
 extern "C" int tn_mel_forward(tn_mel* m, const float* waves, int32_t batch, int64_t n_samples, const int32_t* masks, float* out,
                               void* stream) {

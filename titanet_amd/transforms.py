@@ -3,11 +3,12 @@
 Mirrors ``transforms.MelSpectrogram`` (reference src/transforms.py:111-203): same constructor arguments,
 same ``__call__(example)`` contract (``example["waveform"]`` ``[1, A]`` -> ``new_example["spectrogram"]``
 ``[1, n_mels, 1 + A // hop]``), same Python-``random`` / ``torch.rand`` draws for the SpecAugment
-decisions and the mask bounds of ``torchaudio.functional.mask_along_axis``.  The arithmetic is the HIP
-kernel behind ``tn_mel_forward`` (include/titanet_amd.h).  Deviation: the phase-vocoder ``TimeStretch`` of
-the SpecAugment branch (src/transforms.py:168-175) is not implemented — the stretch rate is drawn (to keep
-the random stream aligned) and ignored.  ``Resample`` (src/transforms.py:320-341) is the identity at the
-target rate and refuses anything else.
+decisions and the mask bounds of ``torchaudio.functional.mask_along_axis`` (any number of masks per axis).
+The arithmetic is the HIP kernel behind ``tn_mel_forward_batch`` (include/titanet_amd.h), including the
+SpecAugment time stretch: the reference squares the magnitude of the phase vocoder's output right away
+(src/transforms.py:173-177), so the vocoder's magnitude interpolation on the stretched time grid is what
+reaches the spectrogram, and that is what the kernel computes.  ``Resample`` (src/transforms.py:320-341) is
+the identity at the target rate and refuses anything else.
 """
 import ctypes as C
 import random
@@ -65,45 +66,74 @@ class MelSpectrogram:
         start = int(min_value.long())
         return start, start + int(value.long())
 
-    def batch(self, waveforms, masks=None):
-        """[B, A] float waveforms (equal length) -> [B, n_mels, 1 + A // hop] on the GPU.
-        masks: optional int32 [B, 4] = (f_start, f_end, t_start, t_end)."""
+    def batch(self, waveforms, masks=None, lengths=None, rates=None, freq_masks=None, time_masks=None):
+        """[B, A] float waveforms -> [B, n_mels, frames] on the GPU (the collate_fn layout, zero beyond an utterance's end).
+
+        masks: optional int32 [B, 4] = (f_start, f_end, t_start, t_end), one interval per axis (``tn_mel_forward``).
+        lengths: int64 [B] valid samples of each zero-padded waveform (ragged batch); rates: float64 [B] SpecAugment
+        time-stretch rates; freq_masks / time_masks: bool [B, n_mels] / [B, frames] unions of mask intervals."""
         if waveforms.dim() != 2:
             raise ValueError("expected waveforms of shape [B, A]")
         if not torch.cuda.is_available():
             raise RuntimeError("titanet_amd.transforms.MelSpectrogram needs a ROCm device; there is no CPU execution path")
         w = waveforms.to(device=self.device, dtype=torch.float32).contiguous()
         B, A = w.shape
-        T = 1 + A // self.hop_length
-        out = torch.empty(B, self.n_mels, T, dtype=torch.float32, device=self.device)
-        m = None
-        if masks is not None:
-            m = masks.to(device=self.device, dtype=torch.int32).contiguous()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         vp = C.c_void_p
-        check(self._lib.tn_mel_forward(self._mel(), vp(w.data_ptr()), B, A, vp(m.data_ptr() if m is not None else 0),
-                                       vp(out.data_ptr()), vp(stream)), "tn_mel_forward")
+        if lengths is None and rates is None and freq_masks is None and time_masks is None:
+            T = 1 + A // self.hop_length
+            out = torch.empty(B, self.n_mels, T, dtype=torch.float32, device=self.device)
+            m = masks.to(device=self.device, dtype=torch.int32).contiguous() if masks is not None else None
+            check(self._lib.tn_mel_forward(self._mel(), vp(w.data_ptr()), B, A, vp(m.data_ptr() if m is not None else 0),
+                                           vp(out.data_ptr()), vp(stream)), "tn_mel_forward")
+            return out
+        assert masks is None, "interval masks go with the equal-length entry point; pass freq_masks / time_masks here"
+        ln = torch.as_tensor(lengths if lengths is not None else [A] * B, dtype=torch.int64)
+        rt = torch.as_tensor(rates if rates is not None else [1.0] * B, dtype=torch.float64)
+        frames = [self.n_frames(int(n), float(r)) for n, r in zip(ln.tolist(), rt.tolist())]
+        T = max(frames)
+        if time_masks is not None:
+            T = max(T, time_masks.shape[1])
+        out = torch.empty(B, self.n_mels, T, dtype=torch.float32, device=self.device)
+        ln_d, rt_d = ln.to(self.device), rt.to(self.device)
+        fm = freq_masks.to(device=self.device, dtype=torch.uint8).contiguous() if freq_masks is not None else None
+        tm = None
+        if time_masks is not None:
+            tm = torch.zeros(B, T, dtype=torch.uint8, device=self.device)
+            tm[:, :time_masks.shape[1]] = time_masks.to(device=self.device, dtype=torch.uint8)
+        check(self._lib.tn_mel_forward_batch(self._mel(), vp(w.data_ptr()), B, A, vp(ln_d.data_ptr()), vp(rt_d.data_ptr()),
+                                             vp(fm.data_ptr() if fm is not None else 0), vp(tm.data_ptr() if tm is not None else 0),
+                                             T, vp(out.data_ptr()), vp(stream)), "tn_mel_forward_batch")
+        self.last_frames = frames
         return out
+
+    def n_frames(self, n_samples, rate=1.0):
+        """frames of an utterance: 1 + n // hop (center=True), then ceil(. / rate) under a time stretch"""
+        import math
+        t = 1 + n_samples // self.hop_length
+        return t if rate == 1.0 else int(math.ceil(t / rate))
 
     def __call__(self, example):
         assert isinstance(example, dict) and "waveform" in example, "Wrong input structure"
         new_example = copy_example(example)
         wave = new_example["waveform"]
         apply_specaugment = random.random() < self.specaugment_probability
-        masks = None
-        if apply_specaugment:
-            random.uniform(self.specaugment_min_speed, self.specaugment_max_speed)   # time-stretch rate: drawn, not applied
-            T = 1 + wave.shape[-1] // self.hop_length
-            f0 = f1 = t0 = t1 = 0
-            # the reference applies `num` masks in sequence; with the default num = 1 that is one interval per axis
-            for _ in range(self.specaugment_freq_mask_num):
-                f0, f1 = self._mask_bounds(self.n_mels, self.specaugment_freq_mask_ratio * self.n_mels)
-            for _ in range(self.specaugment_time_mask_num):
-                t0, t1 = self._mask_bounds(T, self.specaugment_time_mask_ratio * T)
-            if self.specaugment_freq_mask_num > 1 or self.specaugment_time_mask_num > 1:
-                raise NotImplementedError("more than one mask per axis is not supported by tn_mel_forward yet")
-            masks = torch.tensor([[f0, f1, t0, t1]], dtype=torch.int32)
-        new_example["spectrogram"] = self.batch(wave.reshape(1, -1), masks)
+        if not apply_specaugment:
+            new_example["spectrogram"] = self.batch(wave.reshape(1, -1))
+            return new_example
+        # reference src/transforms.py:168-201: stretch rate, then `num` frequency masks, then `num` time masks, each
+        # mask_along_axis call drawing its own two uniforms
+        rate = random.uniform(self.specaugment_min_speed, self.specaugment_max_speed)
+        T = self.n_frames(wave.shape[-1], rate)
+        fm = torch.zeros(1, self.n_mels, dtype=torch.bool)
+        tm = torch.zeros(1, T, dtype=torch.bool)
+        for _ in range(self.specaugment_freq_mask_num):
+            f0, f1 = self._mask_bounds(self.n_mels, self.specaugment_freq_mask_ratio * self.n_mels)
+            fm[0, f0:f1] = True
+        for _ in range(self.specaugment_time_mask_num):
+            t0, t1 = self._mask_bounds(T, self.specaugment_time_mask_ratio * T)
+            tm[0, t0:t1] = True
+        new_example["spectrogram"] = self.batch(wave.reshape(1, -1), rates=[rate], freq_masks=fm, time_masks=tm)
         return new_example
 
 
