@@ -226,6 +226,9 @@ int tn_mel_forward_batch(tn_mel* m, const float* waves, int32_t batch, int64_t n
                                   skip-connection data gradient only */
 /* Start bracketing every launch of `kernel_class` with hipEvents (TN_PROF_NONE stops). */
 int tn_profile_begin(tn_plan* p, int32_t kernel_class);
+/* Bracket only every `every_n`-th launch of the class (default 1): two event records per launch cost ~2.5 us of stream time,
+ * which a class with ~50 launches per step would otherwise add to the step it is measuring. */
+int tn_profile_sample(tn_plan* p, int32_t every_n);
 /* Waits for the recorded events; returns the summed kernel time and launch count since begin. */
 int tn_profile_read(tn_plan* p, double* total_ms, int64_t* launches);
 

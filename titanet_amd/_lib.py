@@ -16,7 +16,7 @@ EXPORTS = [
     "tn_model_create", "tn_model_destroy", "tn_model_param_floats", "tn_model_buffer_floats", "tn_model_num_bn",
     "tn_model_num_tensors", "tn_model_tensor_info", "tn_plan_create", "tn_plan_destroy", "tn_plan_workspace_bytes",
     "tn_plan_bind", "tn_forward", "tn_backward", "tn_adam_step", "tn_debug_fetch", "tn_version", "tn_profile_begin",
-    "tn_profile_read", "tn_mel_create", "tn_mel_destroy", "tn_mel_num_frames", "tn_mel_forward", "tn_mel_forward_batch", "tn_plan_step_tick",
+    "tn_profile_read", "tn_profile_sample", "tn_mel_create", "tn_mel_destroy", "tn_mel_num_frames", "tn_mel_forward", "tn_mel_forward_batch", "tn_plan_step_tick",
     "tn_plan_step_set", "tn_adam_step_plan", "tn_plan_set_lr", "tn_head_save_floats", "tn_head_forward", "tn_head_backward",
     "tn_forward_masked", "tn_plan_set_grad_groups", "tn_plan_num_grad_buckets", "tn_plan_grad_bucket", "tn_plan_wait_grad_bucket",
 ]
@@ -89,6 +89,7 @@ def load():
     lib.tn_head_backward.argtypes = [i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp]
     lib.tn_debug_fetch.argtypes = [vp, C.c_char_p, vp, i64, vp]
     lib.tn_profile_begin.argtypes = [vp, i32]
+    lib.tn_profile_sample.argtypes = [vp, i32]
     lib.tn_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
     lib.tn_mel_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
     lib.tn_mel_destroy.argtypes = [vp]

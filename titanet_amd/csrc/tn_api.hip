@@ -206,7 +206,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   for (int i = 0; i < m->n_bn; ++i) p->bsums[i] = b.take((size_t)TN_NREP * 2 * m->all_bn[i].C * sizeof(float));
   {
     const size_t hs = std::max<size_t>(H / 256, 1);
-    p->wg2_count = b.take(sizeof(int) * (size_t)(c.n_mega_blocks * (c.n_sub_blocks + 1) * hs * hs + (D / 256 + 1) * hs + 1));
+    p->wg2_count = b.take(sizeof(int) * (size_t)(c.n_mega_blocks * (c.n_sub_blocks + 1) * hs * hs + (D / 256 + 1) * hs + 2 * (D / 256) + 1));
   }
   p->dw_gacc = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * TN_NREP * (c.kernel + 1) * H * sizeof(float));
   p->bzero_bytes = ((b.off + 255) & ~(size_t)255) - p->bzero_begin;
@@ -252,7 +252,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     p->fp8_table = b.take(sizeof(Fp8CastDesc) * (size_t)std::max(1, c.n_mega_blocks * c.n_sub_blocks));
   }
   p->E = b.take(M * D * e);
-  p->HID = b.take(M * A * e);
+  p->HID = b.take(M * A * e + 512);      // + slack: the batched weight-gradient units read it 256 wide (row stride 128)
   p->EN = b.take(M * D * e);
   p->pooled = b.take((size_t)batch * 2 * D * 4);
   p->smax = b.take((size_t)batch * D * 4);
@@ -275,7 +275,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   p->dXs = b.take(M * H * e);
   p->dE = b.take(M * D * e);
   p->dEbn = b.take(M * D * e);
-  p->dHP = b.take(M * A * e);
+  p->dHP = b.take(M * A * e + 512);
   p->dpooled = b.take((size_t)batch * 2 * D * 4);
   p->wepi_swz = b.take(D * H * 2);
   p->mu = b.take((size_t)batch * D * 4);
@@ -300,6 +300,10 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     // the epilog conv's weight gradient rides along as (D / 256) x (H / 256) slabs of 256 x 256
     p->wg2_epi_slabs = (c.n_mega_blocks > 0 && D % 256 == 0 && ((p->use_v2 & 16) || p->wide_wgrad)) ? (int)(D / 256) * hs : 0;
     p->wg2_layers += p->wg2_epi_slabs;
+    // ... and the two weight gradients of the attentive pooling (D x 128 and 128 x D): one unit per 256-channel slab of D,
+    // the 128-wide operand read as 256 (half of the unit's output is dropped by the reduction)
+    p->wg2_asp_units = (p->wg2_epi_slabs > 0 && (p->use_v2 & 16) && H == 256 && A == 128 && !c.simple_pool) ? 2 * (int)(D / 256) : 0;
+    p->wg2_layers += p->wg2_asp_units;
     p->wg2_grid = 256;
     p->wg2_desc = b.take((size_t)p->wg2_layers * 256);   // >= sizeof(WgradV2Desc) each (checked at upload)
     p->wg2_out = b.take((size_t)p->wg2_layers * 32);
@@ -358,7 +362,7 @@ void plan_layout_tail(tn_plan* p) {
     const int per_blk = (c.n_sub_blocks + 1) * p->wg2_upl;
     int maxparts = 1;
     for (const auto& bk : p->buckets) {
-      const int layers = (bk.blk_hi >= bk.blk_lo ? (bk.blk_hi - bk.blk_lo + 1) * per_blk : 0) + (bk.tail ? p->wg2_epi_slabs : 0);
+      const int layers = (bk.blk_hi >= bk.blk_lo ? (bk.blk_hi - bk.blk_lo + 1) * per_blk : 0) + (bk.tail ? p->wg2_epi_slabs + p->wg2_asp_units : 0);
       if (layers == 0) continue;
       const long total = (long)layers * chunks;
       const int upw = (int)((total + p->wg2_grid - 1) / p->wg2_grid);
@@ -417,6 +421,13 @@ extern "C" int tn_profile_begin(tn_plan* p, int32_t kernel_class) {
   if (!p || kernel_class < 0 || kernel_class > 4) return TN_E_BADARG;
   p->prof_class = kernel_class;
   p->prof_used = 0;
+  return 0;
+}
+
+extern "C" int tn_profile_sample(tn_plan* p, int32_t every_n) {
+  if (!p || every_n < 1) return TN_E_BADARG;
+  p->prof_stride = every_n;
+  p->prof_counter = 0;
   return 0;
 }
 

@@ -104,7 +104,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     if (batched_wgrad) {
       const int upb = per_blk * p->wg2_upl;      // weight-gradient units per mega block
       int first = has_blocks ? bk.blk_lo * upb : nb * upb;
-      int count = (has_blocks ? (bk.blk_hi - bk.blk_lo + 1) * upb : 0) + (bk.tail ? p->wg2_epi_slabs : 0);
+      int count = (has_blocks ? (bk.blk_hi - bk.blk_lo + 1) * upb : 0) + (bk.tail ? p->wg2_epi_slabs + p->wg2_asp_units : 0);
       if (has_blocks && bk.tail && bk.blk_hi != nb - 1) { rc_fin = TN_E_STATE; return; }   // ranges must be contiguous
       if (count > 0) {
         const int chunks = (M + 31) / 32;
@@ -211,8 +211,9 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
                        (const AT*)(ws + p->EN), T, D, 1e-6f, (const float*)(ws + p->pooled), (const float*)(ws + p->qv),
                        (const float*)(ws + p->smax), (const float*)(ws + p->sinv), (const float*)(ws + p->dpooled),
                        (AT*)(ws + p->dE), (AT*)(ws + p->dEbn), grads + m->asp_bout);
-    // d W_out[c][a] = sum_r dEN[r][c] * hid[r][a]
-    {
+    // d W_out[c][a] = sum_r dEN[r][c] * hid[r][a]      (units of the batched weight-gradient launch when that runs)
+    const bool asp_batched = batched_wgrad && p->wg2_asp_units > 0;
+    if (!asp_batched) {
       ProdPlain::Args pa{ws + p->dE, D, identity_act()};
       ProdPlain::Args qa{ws + p->HID, A, identity_act()};
       int rc = launch_wgrad<AT, ProdPlain, ProdPlain>(M, D, A, pa, qa, 0, slabs, p->slab_bytes, grads + m->asp_wout, st);
@@ -236,7 +237,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       if (rc) return rc;
     }
     // d W_in[a][c] = sum_r dHP[r][a] * x[r][c],  x = act(E)
-    {
+    if (!asp_batched) {
       ProdPlain::Args pa{ws + p->dHP, A, identity_act()};
       ProdPlain::Args qa{ws + p->E, D, acte};
       int rc = launch_wgrad<AT, ProdPlain, ProdPlain>(M, A, D, pa, qa, 0, slabs, p->slab_bytes, grads + m->asp_win, st);
@@ -589,6 +590,28 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
         for (int qo = 0; qo < hs; ++qo)
           add(p->dEbn, p->E, m->epi_bn, c.enc_out, (const void*)(p->ws + p->blk[c.n_mega_blocks - 1].OUT), identity_act(), H, 0, -1, -1,
               m->epi_w, po, qo);
+    if (p->wg2_asp_units > 0) {
+      const int D = c.enc_out, A = c.attn_hidden;
+      auto add_plain = [&](const bf16_t* P, int ldp, const bf16_t* Q, int ldq, int q0, const BnAct& aq, float* out, int ld, int lim) {
+        WgradV2Desc d;
+        memset(&d, 0, sizeof(d));
+        d.dZ = P; d.ldp = ldp; d.statC = 256;
+        d.inv_n = 1.f / (float)M; d.eps = 1e-5f; d.batch = 1.f;
+        d.X = Q; d.actX = aq; d.ldq = ldq; d.q0 = q0;
+        d.slabs = (float*)(p->ws + p->wg2_slabs) + wd.size() * slab_stride;
+        wd.push_back(d);
+        wo.push_back(WgradV2Out{d.slabs, out, ld, lim});
+      };
+      const BnAct acte = make_act(p, m->epi_bn, M, 1, 1, 0.f, 0, 0);
+      // d W_out[c][a] = sum_r dEN[r][c] hid[r][a]: P = 256-channel slab of dEN, Q = hid (128 wide, read as 256)
+      for (int s = 0; s < D / 256; ++s)
+        add_plain((const bf16_t*)(p->ws + p->dE) + s * 256, D, (const bf16_t*)(p->ws + p->HID), A, 0, identity_act(),
+                  p->grads + m->asp_wout + (int64_t)s * 256 * A, A, 256 | (A << 16));
+      // d W_in[a][c] = sum_r dHP[r][a] x[r][c], x = relu(BN(E)): P = dHP (128 wide, read as 256), Q = slab of E
+      for (int s = 0; s < D / 256; ++s)
+        add_plain((const bf16_t*)(p->ws + p->dHP), A, (const bf16_t*)(p->ws + p->E), D, s * 256, acte,
+                  p->grads + m->asp_win + (int64_t)s * 256, D, A | (256 << 16));
+    }
     if ((int)wd.size() != p->wg2_layers) return TN_E_STATE;
     if (sizeof(WgradV2Desc) > 256 || sizeof(WgradV2Out) > 32) return TN_E_STATE;
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_desc, wd.data(), wd.size() * sizeof(WgradV2Desc), hipMemcpyHostToDevice, st));

@@ -128,7 +128,7 @@ struct tn_plan {
   size_t bwd_table, bwd_table_eval, se_table;
   size_t wg2_desc, wg2_out, wg2_count, wg2_slabs;   // batched weight-gradient launch (v2)
   size_t dw_gacc, dw_table;                         // depthwise gradient accumulators [layer][NREP][KD+1][256] + finalize table
-  int wg2_layers = 0, wg2_maxparts = 0, wg2_units_per_wg = 0, wg2_grid = 0, wg2_epi_slabs = 0;
+  int wg2_layers = 0, wg2_maxparts = 0, wg2_units_per_wg = 0, wg2_grid = 0, wg2_epi_slabs = 0, wg2_asp_units = 0;
   int wg2_upl = 1;              // units per pointwise layer: (hidden / 256)^2 output slabs of 256 x 256
   bool wide_wgrad = false;      // hidden = 512 / 1024 (TitaNet-M / -L), bf16: generic forward / data-gradient kernels, but the
                                 // pointwise weight gradients run as slab units of the batched launch
@@ -150,6 +150,8 @@ struct tn_plan {
   std::vector<hipEvent_t> fork_events;
   // per-kernel event timing (tn_profile_*)
   int prof_class = 0;
+  int prof_stride = 1;            // tn_profile_sample: bracket every n-th launch of the class
+  unsigned prof_counter = 0;
   std::vector<hipEvent_t> prof_events;
   size_t prof_used = 0;
   // variable-length batches (tn_forward_masked): valid frames per utterance
@@ -179,6 +181,7 @@ struct ProfScope {
   hipStream_t st;
   bool on;
   ProfScope(tn_plan* plan, int cls, hipStream_t s) : p(plan), st(s), on(plan && cls != 0 && plan->prof_class == cls) {
+    if (on) on = (p->prof_counter++ % p->prof_stride) == 0;      // sampled: every prof_stride-th launch of the class
     if (on) {
       if (p->prof_used + 2 > p->prof_events.size()) {
         for (int i = 0; i < 256; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } p->prof_events.push_back(e); }

@@ -37,7 +37,7 @@ __device__ __forceinline__ bf16x8_t wg_frag_v2(const bf16_t* tile, int k0, int c
 
 struct WgradV2Desc {
   const bf16_t* dZ;
-  const bf16_t* Y;
+  const bf16_t* Y;       // null (with fstats null): P = dZ as stored (no BatchNorm between the gradient and the GEMM)
   const float* fstats;   // BN of Y: forward sums
   const float* bsums;    // BN of Y: backward sums (complete before this launch)
   const float* gamma;
@@ -90,7 +90,7 @@ __device__ __forceinline__ void wg2_chunks(const WgradV2Desc& d, const WgSeg& sg
       const int gr = r0 + rq + 16 * q;
       if (gr < M) {
         pz[q] = *reinterpret_cast<const uint4*>(d.dZ + (size_t)gr * d.ldp + c0);
-        py[q] = *reinterpret_cast<const uint4*>(d.Y + (size_t)gr * d.ldp + c0);
+        py[q] = d.Y ? *reinterpret_cast<const uint4*>(d.Y + (size_t)gr * d.ldp + c0) : make_uint4(0, 0, 0, 0);
       } else {
         pz[q] = make_uint4(0, 0, 0, 0); py[q] = make_uint4(0, 0, 0, 0);
       }
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(V2_NT, 2) void wgrad_batched_v2_kernel(const WgradV
     if (tid < V2_C) {
       BnBwd bb;
       bb.fstats = d.fstats; bb.bsums = d.bsums; bb.gamma = d.gamma; bb.inv_n = d.inv_n; bb.eps = d.eps; bb.batch = d.batch;
-      float k0, k1, k2, s, h;
-      bn_bwd_coefs(bb, d.statC, d.chan0 + tid, k0, k1, k2);
+      float k0 = 1.f, k1 = 0.f, k2 = 0.f, s, h;
+      if (d.fstats) bn_bwd_coefs(bb, d.statC, d.chan0 + tid, k0, k1, k2);
       bn_scale_shift(d.actX, d.ldq, d.q0 + tid, s, h);
       cst[tid] = k0; cst[V2_C + tid] = k1; cst[2 * V2_C + tid] = k2; cst[3 * V2_C + tid] = s; cst[4 * V2_C + tid] = h;
       cst[5 * V2_C + tid] = dw ? d.bdw[tid] : 0.f;
@@ -297,12 +297,14 @@ struct WgradV2Out {
   const float* slabs;
   float* out;        // first element of this unit's 256 x 256 block of the weight gradient
   int ld;            // its row stride (256, or the layer's input width for slabs of a wider weight)
-  int pad_;
+  int lim;           // 0 = the whole 256 x 256 unit, else rows | cols << 16 actually wanted (a 128-wide operand read as 256)
 };
 __global__ void wgrad_v2_reduce_kernel(const WgradV2Out* __restrict__ outs, const int* __restrict__ part_count) {
   const WgradV2Out o = outs[blockIdx.y];
   const int parts = part_count[blockIdx.y];
+  const int nrow = o.lim ? (o.lim & 0xffff) : V2_C, ncol = o.lim ? (o.lim >> 16) : V2_C;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V2_C * V2_C; i += gridDim.x * blockDim.x) {
+    if ((i >> 8) >= nrow || (i & 255) >= ncol) continue;
     float s = 0.f;
     for (int k = 0; k < parts; ++k) s += o.slabs[(size_t)k * V2_C * V2_C + i];
     o.out[(size_t)(i >> 8) * o.ld + (i & 255)] = s;

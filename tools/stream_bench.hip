@@ -61,6 +61,27 @@ __global__ __launch_bounds__(256) void rw_k(const uint4* __restrict__ a, const u
   }
 }
 
+
+// each workgroup (256 threads) walks `blocks` of blk16 uint4: contiguous range per workgroup (mode 0) or interleaved (mode 1)
+__global__ __launch_bounds__(256) void read_blocks_k(const uint4* __restrict__ a, size_t n, int blk16, int mode, uint32_t* sink) {
+  const size_t nblk = n / blk16;
+  const size_t per = (nblk + gridDim.x - 1) / gridDim.x;
+  uint32_t s = 0;
+  for (size_t k = 0; k < per; ++k) {
+    const size_t b = mode ? k * gridDim.x + blockIdx.x : blockIdx.x * per + k;
+    if (b >= nblk) break;
+    const uint4* src = a + b * blk16;
+    for (int i = threadIdx.x; i < blk16; i += 1024) {
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (i + u * 256 < blk16) ? src[i + u * 256] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+  }
+  if (s == 0x12345678u) *sink = s;
+}
+
 // ---- LDS-DMA streaming read: persistent workgroups of 256 threads, ring of NS slots x 16 KB; every wave issues its 4
 // 1-KB pieces of slot s + DEPTH, waits (counted vmcnt) for slot s, workgroup barrier, folds the slot from LDS.
 template <int NS, int DEPTH>
@@ -180,6 +201,49 @@ int main(int argc, char** argv) {
         printf("%-22s %-4s grid %5d x256thr: U=4 %7.2f us (%5.2f TB/s)   U=8 %7.2f us (%5.2f TB/s)\n", names[kind], hot ? "hot" : "cold", grid,
                u4, passes[kind] * bytes / u4 / 1e6, u8, passes[kind] * bytes / u8 / 1e6);
       }
+  if (argc > 1 && atoi(argv[1]) == 1) {
+    // long launches: ONE kernel over 32 x 39.3 MB = 1.26 GB per stream (what a 1-2 ms kernel of the step can reach, without
+    // the ramp-up / drain of a 39 MB launch)
+    const size_t big = bytes * 32, nb = big / 16;
+    uint4 *A, *B2, *D2, *O;
+    CK(hipMalloc(&A, big)); CK(hipMalloc(&B2, big)); CK(hipMalloc(&D2, big)); CK(hipMalloc(&O, big));
+    CK(hipMemset(A, 1, big)); CK(hipMemset(B2, 1, big)); CK(hipMemset(D2, 1, big)); CK(hipMemset(O, 1, big));
+    for (int grid : {256, 512, 1024, 4096, 16384}) {
+      float t[5];
+      for (int kind = 0; kind < 5; ++kind) {
+        float best = 1e30f;
+        for (int rep = 0; rep < 4; ++rep) {
+          CK(hipEventRecord(ev[0], 0));
+          switch (kind) {
+            case 0: hipLaunchKernelGGL(read_k<8>, dim3(grid), dim3(256), 0, 0, A, nb, sink); break;
+            case 1: hipLaunchKernelGGL(write_k<8>, dim3(grid), dim3(256), 0, 0, O, nb); break;
+            case 2: hipLaunchKernelGGL((rw_k<4, 1>), dim3(grid), dim3(256), 0, 0, A, B2, D2, O, nb); break;
+            case 3: hipLaunchKernelGGL((rw_k<4, 2>), dim3(grid), dim3(256), 0, 0, A, B2, D2, O, nb); break;
+            case 4: hipLaunchKernelGGL((rw_k<4, 3>), dim3(grid), dim3(256), 0, 0, A, B2, D2, O, nb); break;
+          }
+          CK(hipEventRecord(ev[1], 0));
+          CK(hipEventSynchronize(ev[1]));
+          float ms; CK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+          if (rep > 0 && ms < best) best = ms;
+        }
+        t[kind] = passes[kind] * (float)big / best / 1e9f;
+      }
+      printf("long launch (1.26 GB/stream) grid %5d: read %5.2f  write %5.2f  copy %5.2f  2r1w %5.2f  3r1w %5.2f TB/s\n", grid, t[0], t[1], t[2], t[3], t[4]);
+    }
+    for (int blk16 : {1024, 4096}) for (int mode = 0; mode < 2; ++mode) for (int grid : {256, 512}) {
+      float best = 1e30f;
+      for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(ev[0], 0));
+        hipLaunchKernelGGL(read_blocks_k, dim3(grid), dim3(256), 0, 0, A, nb, blk16, mode, sink);
+        CK(hipEventRecord(ev[1], 0));
+        CK(hipEventSynchronize(ev[1]));
+        float ms; CK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+        if (rep > 0 && ms < best) best = ms;
+      }
+      printf("long read, %3d KB blocks, %s, grid %d: %5.2f TB/s\n", blk16 / 64, mode ? "interleaved over workgroups" : "one contiguous range per workgroup", grid, (float)big / best / 1e9f);
+    }
+    return 0;
+  }
   for (int hot = 0; hot < 2; ++hot)
     for (int grid : {256, 512, 1024}) {
       Ctx c{bufs, n, hot ? 1 : NSET, grid, 0, sink};
