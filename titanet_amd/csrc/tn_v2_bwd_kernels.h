@@ -83,27 +83,27 @@ __device__ __forceinline__ void wg2_chunks(const WgradV2Desc& d, const WgSeg& sg
   const int vc = tid & 31, rq = tid >> 5, c0 = vc * 8;
   const int wa = wave >> 2, wb = wave & 3;
   uint4 pz[2], py[2], px[3];
-  auto prefetch = [&](int chunk) {
-    const int r0 = chunk * WG2_RK;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int gr = r0 + rq + 16 * q;
-      if (gr < M) {
-        pz[q] = *reinterpret_cast<const uint4*>(d.dZ + (size_t)gr * d.ldp + c0);
-        py[q] = d.Y ? *reinterpret_cast<const uint4*>(d.Y + (size_t)gr * d.ldp + c0) : make_uint4(0, 0, 0, 0);
-      } else {
-        pz[q] = make_uint4(0, 0, 0, 0); py[q] = make_uint4(0, 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int i = rq + 16 * q;               // Xa row 0 .. 47 (need < 32 + KD - 1)
-      const int gr = r0 - PADR + i;
-      if (i < WG2_RK + KD - 1 && gr >= 0 && gr < M) px[q] = *reinterpret_cast<const uint4*>(d.X + (size_t)gr * d.ldq + d.q0 + c0);
-      else px[q] = make_uint4(0, 0, 0, 0);
+  // every prefetch register is refilled (for the next chunk) right after it was consumed, so that the memory pipe is
+  // never empty: 5 - 7 loads per thread are in flight at any time, also while the tiles are transformed
+  auto load_p = [&](int chunk, int q) {
+    const int gr = chunk * WG2_RK + rq + 16 * q;
+    if (gr < M) {
+      pz[q] = *reinterpret_cast<const uint4*>(d.dZ + (size_t)gr * d.ldp + c0);
+      py[q] = d.Y ? *reinterpret_cast<const uint4*>(d.Y + (size_t)gr * d.ldp + c0) : make_uint4(0, 0, 0, 0);
+    } else {
+      pz[q] = make_uint4(0, 0, 0, 0); py[q] = make_uint4(0, 0, 0, 0);
     }
   };
-  prefetch(chunk0);
+  auto load_x = [&](int chunk, int q) {
+    const int i = rq + 16 * q;               // Xa row 0 .. 47 (need < 32 + KD - 1)
+    const int gr = chunk * WG2_RK - PADR + i;
+    if (i < WG2_RK + KD - 1 && gr >= 0 && gr < M) px[q] = *reinterpret_cast<const uint4*>(d.X + (size_t)gr * d.ldq + d.q0 + c0);
+    else px[q] = make_uint4(0, 0, 0, 0);
+  };
+#pragma unroll
+  for (int q = 0; q < 2; ++q) load_p(chunk0, q);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) load_x(chunk0, q);
   for (int ch = 0; ch < nchunks; ++ch) {
     const int r0 = (chunk0 + ch) * WG2_RK;
     const bool interior = r0 - PADR >= 0 && r0 + WG2_RK + PADR <= M;               // workgroup-uniform
@@ -122,6 +122,7 @@ __device__ __forceinline__ void wg2_chunks(const WgradV2Desc& d, const WgSeg& sg
         for (int i = 0; i < 8; ++i) z[i] = cst[c0 + i] * z[i] + cst[V2_C + c0 + i] * y[i] + cst[2 * V2_C + c0 + i];
       }
       store8(Pt + r * WG2_PITCH + c0, z);
+      if (ch + 1 < nchunks) load_p(chunk0 + ch + 1, q);
       __builtin_amdgcn_sched_barrier(0);   // bound the live temporaries (the 128 accumulators leave ~100 VGPRs)
     }
     // ---- activated input rows (with halo)
@@ -135,9 +136,9 @@ __device__ __forceinline__ void wg2_chunks(const WgradV2Desc& d, const WgSeg& sg
         if (DW) store8(Xa + i * V2_C + c0, v);
         else if (i >= PADR && i < PADR + WG2_RK) store8(Qt + (i - PADR) * WG2_PITCH + c0, v);   // plain 1x1: Q row r = input row r
       }
+      if (ch + 1 < nchunks) load_x(chunk0 + ch + 1, q);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (ch + 1 < nchunks) prefetch(chunk0 + ch + 1);
     __syncthreads();
     if (DW) {
       if (one_utt) {
@@ -1159,10 +1160,21 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
       float z[8], y[8];
       unpack8(pz[q], z);
       unpack8(py[q], y);
-      if (gr >= 0 && gr < a.M) {
-        const float* kk = cst + c0;          // k0, k1, k2 from LDS: the registers go to the stencil window
+      {
+        // k0, k1, k2 from LDS (the registers go to the stencil window): unconditional 16-byte reads, then a select
+        float k0v[8], k1v[8], k2v[8];
+        *reinterpret_cast<float4*>(k0v) = *reinterpret_cast<const float4*>(cst + c0);
+        *reinterpret_cast<float4*>(k0v + 4) = *reinterpret_cast<const float4*>(cst + c0 + 4);
+        *reinterpret_cast<float4*>(k1v) = *reinterpret_cast<const float4*>(cst + V2_C + c0);
+        *reinterpret_cast<float4*>(k1v + 4) = *reinterpret_cast<const float4*>(cst + V2_C + c0 + 4);
+        *reinterpret_cast<float4*>(k2v) = *reinterpret_cast<const float4*>(cst + 2 * V2_C + c0);
+        *reinterpret_cast<float4*>(k2v + 4) = *reinterpret_cast<const float4*>(cst + 2 * V2_C + c0 + 4);
+        const bool ok = gr >= 0 && gr < a.M;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) z[i] = kk[i] * z[i] + kk[V2_C + i] * y[i] + kk[2 * V2_C + i];
+        for (int i = 0; i < 8; ++i) {
+          const float v = fmaf(k0v[i], z[i], fmaf(k1v[i], y[i], k2v[i]));
+          z[i] = ok ? v : z[i];
+        }
       }
       store8(Pt + r * V2_AP + c0, z);
       *reinterpret_cast<uint4*>(Xs + r * V2_C + c0) = px[q];
@@ -1188,9 +1200,13 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
     __syncthreads();   // (3)
     // ---- transposed stencil + activation backward: wave = strip of 4 output rows (tile rows 1 + 4*wave ..), lane = 4 channels
     {
-      const int i0 = 1 + 4 * wave;               // first output row of the strip (tile row index)
-      const int gfirst = g0 + i0 - 1, glast = g0 + i0 + 4;     // window rows i0-1 .. i0+4
-      const bool fast = i0 + 4 <= V6_OUT + 1 && gfirst >= 0 && glast < a.M && (gfirst % a.T) + 5 < a.T;   // wave-uniform
+      // 30 output rows over 8 waves: strips of 4, 4, 4, 4, 4, 4, 3, 3 rows (a 2-row leftover strip would always take the
+      // slow path and every wave would wait for it at the next barrier)
+      const bool nr4 = wave < 6;
+      const int NR = nr4 ? 4 : 3;
+      const int i0 = nr4 ? 1 + 4 * wave : 25 + 3 * (wave - 6);     // first output row of the strip (tile row index)
+      const int gfirst = g0 + i0 - 1, glast = g0 + i0 + NR;        // window rows i0-1 .. i0+NR
+      const bool fast = gfirst >= 0 && glast < a.M && (gfirst % a.T) + NR + 1 < a.T;   // wave-uniform
       auto ldD = [&](int i, float* D) { unpack4(*reinterpret_cast<const uint2*>(Dt + i * V2_AP + c4), D); };
       auto ldX = [&](int i, float* Yr) { unpack4(*reinterpret_cast<const uint2*>(Xs + i * V2_C + c4), Yr); };
       uint2 addv[4];
@@ -1198,7 +1214,7 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int gr = g0 + i0 + q;
-          addv[q] = (i0 + q <= V6_OUT && gr >= 0 && gr < a.M) ? *reinterpret_cast<const uint2*>(a.ADD + (size_t)gr * V2_C + c4) : make_uint2(0, 0);
+          addv[q] = (q < NR && gr >= 0 && gr < a.M) ? *reinterpret_cast<const uint2*>(a.ADD + (size_t)gr * V2_C + c4) : make_uint2(0, 0);
         }
       }
       if (fast) {
@@ -1215,6 +1231,7 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
         place(1, 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          if (q == 3 && !nr4) break;
           const int P = q % 3, C_ = (q + 1) % 3, N = (q + 2) % 3;
           place(q + 2, N);
           float dA[4];
@@ -1252,7 +1269,7 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
       } else {
         // boundary strips (utterance edges, ends of the batch, the short last strip): per-row wave-uniform tests
 #pragma unroll 1
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NR; ++q) {
           const int i = i0 + q, gr = g0 + i;
           if (i > V6_OUT || gr < 0 || gr >= a.M) continue;
           const int t = gr % a.T;
@@ -1326,6 +1343,7 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
     else if (a.bsumsX && HAS_MASK) atomic_add_f32(&a.bsumsX[(size_t)(rep * 2 + (k - KD - 1)) * V2_C + c], v);
   }
 }
+
 
 template <int FL>
 inline int launch_dgrad_dw_v6_t(DgradDwArgs a, int grid, size_t smem, hipStream_t st) {

@@ -1,0 +1,60 @@
+// Timing harness for dgrad_dw_v6 / v7 (tuning tool): same data, rotating buffer sets (cold), variants by -DV7_EXP=n.
+#include "../titanet_amd/csrc/tn_v2_bwd_kernels.h"
+#include <string.h>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %d at %s\n", (int)e, #x); return 1; } } while (0)
+int main(int argc, char** argv) {
+  const int M = 256 * 300, C = 256, T = 300, NSET = 8;
+  std::vector<bf16_t*> dZ(NSET), Y(NSET), X(NSET), OUT(NSET);
+  bf16_t* W; float *stats, *bs, *gamma, *beta, *wdw, *gacc, *bsx;
+  std::vector<unsigned short> hx((size_t)M * C);
+  for (size_t i = 0; i < hx.size(); ++i) hx[i] = (unsigned short)((0x3c00 + (i * 7919u) % 0x300) ^ ((i & 1) << 15));
+  for (int s = 0; s < NSET; ++s) {
+    CK(hipMalloc(&dZ[s], (size_t)M * C * 2)); CK(hipMalloc(&Y[s], (size_t)M * C * 2)); CK(hipMalloc(&X[s], (size_t)M * C * 2)); CK(hipMalloc(&OUT[s], (size_t)M * C * 2));
+    CK(hipMemcpy(dZ[s], hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(Y[s], hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(X[s], hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+  }
+  CK(hipMalloc(&W, C * C * 2)); CK(hipMemcpy(W, hx.data(), C * C * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc(&stats, 8 * 2 * C * 4)); CK(hipMalloc(&bs, 8 * 2 * C * 4)); CK(hipMalloc(&gamma, C * 4)); CK(hipMalloc(&beta, C * 4));
+  CK(hipMalloc(&wdw, C * 3 * 4)); CK(hipMalloc(&gacc, 8 * 4 * C * 4)); CK(hipMalloc(&bsx, 8 * 2 * C * 4));
+  std::vector<float> ones(C * 3, 0.3f); CK(hipMemcpy(gamma, ones.data(), C * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(beta, ones.data(), C * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(wdw, ones.data(), C * 3 * 4, hipMemcpyHostToDevice));
+  { std::vector<float> hs(8 * 2 * C, 0.f); for (int c = 0; c < C; ++c) { hs[c] = 0.1f * M; hs[C + c] = 1.5f * M; } CK(hipMemcpy(stats, hs.data(), hs.size() * 4, hipMemcpyHostToDevice)); }
+  CK(hipMemset(bs, 0, 8 * 2 * C * 4)); CK(hipMemset(gacc, 0, 8 * 4 * C * 4)); CK(hipMemset(bsx, 0, 8 * 2 * C * 4));
+  uint4* swz; CK(hipMalloc(&swz, C * C * 2));
+  hipLaunchKernelGGL(dgrad_wide_swizzle_kernel, dim3(32), dim3(256), 0, 0, W, C, swz);
+  DgradDwArgs a; memset(&a, 0, sizeof(a));
+  a.bn.fstats = stats; a.bn.bsums = bs; a.bn.gamma = gamma; a.bn.inv_n = 1.f / M; a.bn.eps = 1e-5f; a.bn.batch = 1.f;
+  a.Wswz = swz; a.wdw = wdw; a.gacc = gacc; a.bsumsX = bsx; a.M = M; a.T = T;
+  a.actX.mode = 1; a.actX.stats = stats; a.actX.gamma = gamma; a.actX.beta = beta; a.actX.inv_n = 1.f / M; a.actX.eps = 1e-5f; a.actX.relu = 1;
+  a.actX.drop_thr = 6554; a.actX.inv_keep = 1.f / 0.9f; a.actX.drop_key = 12345;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int which = 0; which < 2; ++which) {
+    auto go = [&](int it) { const int s = it % NSET; a.dZ = dZ[s]; a.Y = Y[s]; a.X = X[s]; a.OUT = OUT[s];
+                            return which ? launch_dgrad_dw_v7(a, 256, 0) : launch_dgrad_dw_v6(a, 256, 0); };
+    for (int it = 0; it < 4; ++it) { int rc = go(it); if (rc) { printf("launch rc %d\n", rc); return 1; } }
+    CK(hipDeviceSynchronize());
+    hipEventRecord(e0, 0);
+    for (int it = 0; it < 40; ++it) go(it);
+    hipEventRecord(e1, 0); CK(hipEventSynchronize(e1));
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%s<7>: %.2f us per launch (%.2f TB/s over 4 passes)\n", which ? "dgrad_dw_v7" : "dgrad_dw_v6", ms * 1e3f / 40, 4.0 * M * C * 2 / (ms * 1e-3 / 40) / 1e12);
+  }
+  // checksum of the two outputs on the same inputs
+  a.dZ = dZ[0]; a.Y = Y[0]; a.X = X[0]; a.OUT = OUT[0]; launch_dgrad_dw_v6(a, 256, 0);
+  a.OUT = OUT[1]; if (argc > 1) launch_dgrad_dw_v6(a, 256, 0); else launch_dgrad_dw_v7(a, 256, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<unsigned short> o0((size_t)M * C), o1((size_t)M * C);
+  CK(hipMemcpy(o0.data(), OUT[0], o0.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(o1.data(), OUT[1], o1.size() * 2, hipMemcpyDeviceToHost));
+  size_t diff = 0; for (size_t i = 0; i < o0.size(); ++i) diff += o0[i] != o1[i];
+#if defined(V7_EXP) && (V7_EXP == 9)
+  { std::vector<unsigned long long> d(16 * 8 * 8); CK(hipMemcpyFromSymbol(d.data(), HIP_SYMBOL(v7_dbg), d.size() * 8));
+    for (int it : {4, 5}) for (int w = 0; w < 8; ++w) { const unsigned long long* r = &d[(it * 8 + w) * 8];
+      printf("wave %d it %d: bar1 %5lld | vmwait %5lld | transform %5lld | bar2 %5lld | dma+mfma %5lld | bar3 %5lld | stencil->next top %5lld\n", w, it,
+             r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4], r[6] - r[5], (it < 9 ? d[((it + 1) * 8 + w) * 8] : r[7]) - r[6]); }
+    const unsigned long long* q = &d[(15 * 8 + 0) * 8];
+    printf("wave 0: prologue %lld | loop %lld | epilogue %lld cycles\n", q[1] - q[0], q[2] - q[1], q[3] - q[2]); }
+#endif
+  printf("v6 vs v7 outputs: %zu of %zu elements differ\n", diff, o0.size());
+  return 0;
+}
