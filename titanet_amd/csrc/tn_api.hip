@@ -228,6 +228,15 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   p->wwout = wc(D, A);
   // ---- activations
   p->Y0 = b.take(M * H * e);
+  {
+    const char* pt = getenv("TN_PROLOG_TAPS");
+    p->prolog_taps = precision == TN_PREC_BF16 && c.n_mels % 8 == 0 && !(pt && atoi(pt) == 0);
+    if (p->prolog_taps) {
+      p->x0 = b.take(M * (size_t)c.n_mels * e + 64);
+      p->wprolog_taps = b.take(H * (size_t)c.n_mels * c.prolog_kernel * e);
+      p->prolog_gtmp = b.take(H * (size_t)c.n_mels * c.prolog_kernel * sizeof(float));
+    }
+  }
   p->blk.resize(c.n_mega_blocks);
   for (auto& bw : p->blk) {
     for (int j = 0; j < c.n_sub_blocks; ++j) { bw.Y.push_back(b.take(M * H * e)); bw.wpw.push_back(wc(H, H)); }
@@ -633,7 +642,19 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
                        (float* const*)(ws + p->stats_ptr_table));
   }
   // ---- prolog: dense k=3 conv as an im2col GEMM (reference src/models.py:370, :398)
-  {
+  if (p->prolog_taps) {
+    // packed operand: one transposing cast of the input, then the GEMM reads 16-byte vectors (a scalar gather from the
+    // [B][C][T] float layout cost 100 us here, and 190 us in the weight gradient)
+    const size_t tile = (size_t)c.n_mels * 65 * sizeof(float);
+    hipLaunchKernelGGL(prolog_pack_kernel<AT>, dim3((T + 63) / 64, B), dim3(256), tile, st, spec, c.n_mels, T, rm.len, (AT*)(ws + p->x0));
+    hipLaunchKernelGGL(prolog_weight_taps_kernel<AT>, dim3(64), dim3(256), 0, st, params + m->prolog_w, H, c.n_mels, c.prolog_kernel,
+                       (AT*)(ws + p->wprolog_taps));
+    GemmShape g{M, H, c.n_mels * c.prolog_kernel, ws + p->wprolog_taps};
+    ProdTaps::Args pa{ws + p->x0, c.n_mels, c.prolog_kernel, T};
+    EpiStoreArgs ea{ws + p->Y0, H, params + m->prolog_b, statp(m->prolog_bn), rm};
+    int rc = gemm_store<AT, ProdTaps>(g, pa, ea, 0, st);
+    if (rc) return rc;
+  } else {
     GemmShape g{M, H, c.n_mels * c.prolog_kernel, wsel<AT>(p, m->prolog_w, p->wprolog)};
     ProdIm2col::Args pa{spec, c.n_mels, c.prolog_kernel, T, rm.len};
     EpiStoreArgs ea{ws + p->Y0, H, params + m->prolog_b, statp(m->prolog_bn), rm};

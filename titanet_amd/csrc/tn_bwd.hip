@@ -93,9 +93,18 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     if (bk.prolog) {
       const int cur_ = p->prolog_cur;
       ProdDy::Args pa{ws + p->dA[cur_], ws + p->Y0, H, make_bnbwd(p, m->prolog_bn, M, training)};
-      ProdIm2col::Args qa{p->last_input, c.n_mels, c.prolog_kernel, T, plan_row_mask(p).len};
-      int rc = launch_wgrad<AT, ProdDy, ProdIm2col>(M, H, c.n_mels * c.prolog_kernel, pa, qa, 0, slabs, p->slab_bytes,
-                                                   grads + m->prolog_w, st);
+      int rc;
+      if (p->prolog_taps) {
+        ProdTaps::Args qa{ws + p->x0, c.n_mels, c.prolog_kernel, T};
+        rc = launch_wgrad<AT, ProdDy, ProdTaps>(M, H, c.n_mels * c.prolog_kernel, pa, qa, 0, slabs, p->slab_bytes,
+                                                (float*)(ws + p->prolog_gtmp), st);
+        hipLaunchKernelGGL(prolog_wgrad_untap_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + p->prolog_gtmp), H, c.n_mels,
+                           c.prolog_kernel, grads + m->prolog_w);
+      } else {
+        ProdIm2col::Args qa{p->last_input, c.n_mels, c.prolog_kernel, T, plan_row_mask(p).len};
+        rc = launch_wgrad<AT, ProdDy, ProdIm2col>(M, H, c.n_mels * c.prolog_kernel, pa, qa, 0, slabs, p->slab_bytes,
+                                                  grads + m->prolog_w, st);
+      }
       if (rc) { rc_fin = rc; return; }
     }
     if (v2_bwd && has_blocks)

@@ -360,6 +360,15 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int splits, 
   }
 }
 
+// gradient of the prolog weight computed in [out][tap][ci] order (ProdTaps) -> the reference layout [out][ci][tap]
+__global__ void prolog_wgrad_untap_kernel(const float* __restrict__ g_taps, int H, int C, int KP, float* __restrict__ g_w) {
+  const int n = H * C * KP;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int h = i / (C * KP), r = i - h * C * KP, ci = r / KP, j = r - ci * KP;   // i indexes the reference layout [h][ci][j]
+    g_w[i] = g_taps[(size_t)h * C * KP + j * C + ci];
+  }
+}
+
 template <typename AT, typename ProdP, typename ProdQ>
 inline int launch_wgrad(int M, int CA, int CB, const typename ProdP::Args& pa, const typename ProdQ::Args& qa, int KD,
                         float* slabs, size_t slab_bytes, float* out, hipStream_t st, tn_plan* prof_plan = nullptr,

@@ -31,6 +31,40 @@ __global__ void cast_params_kernel(const CastDesc* descs) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Packed prolog operand (ProdTaps, tn_gemm.h): the reference-layout input [B][C][T] float32 -> X0[B*T][C] AT (frames beyond
+// an utterance's valid length written as zero), the prolog weight [H][C][KP] -> [H][KP][C] AT, and the way back for its
+// gradient.  grid = (ceil(T / 64), B) x 256 threads; LDS tile [C][65] floats.
+// ------------------------------------------------------------------------------------------
+template <typename AT>
+__global__ __launch_bounds__(256) void prolog_pack_kernel(const float* __restrict__ x, int C, int T, const int* __restrict__ len,
+                                                          AT* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tile = reinterpret_cast<float*>(smem);      // [C][65]
+  const int b = blockIdx.y, t0 = blockIdx.x * 64;
+  const int L = len ? len[b] : T;
+  const float* xb = x + (size_t)b * C * T;
+  for (int i = threadIdx.x; i < C * 64; i += 256) {
+    const int ci = i >> 6, tl = i & 63, t = t0 + tl;
+    tile[ci * 65 + tl] = (t < L) ? xb[(size_t)ci * T + t] : 0.f;        // t < L <= T
+  }
+  __syncthreads();
+  const int rows = min(64, T - t0);
+  AT* ob = out + ((size_t)b * T + t0) * C;
+  for (int i = threadIdx.x; i < rows * C; i += 256) {
+    const int tl = i / C, ci = i - tl * C;
+    ob[i] = Elem<AT>::from_f(tile[ci * 65 + tl]);
+  }
+}
+template <typename AT>
+__global__ void prolog_weight_taps_kernel(const float* __restrict__ w, int H, int C, int KP, AT* __restrict__ out) {
+  const int n = H * C * KP;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int h = i / (C * KP), r = i - h * C * KP, j = r / C, ci = r - j * C;     // i indexes the OUTPUT [h][j][ci]
+    out[i] = Elem<AT>::from_f(w[(size_t)h * C * KP + ci * KP + j]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // fp8 (OCP e4m3) helpers and the per-step weight cast of the TN_PREC_FP8 plan: W8[n][:] = e4m3(W[n][:] / s[n]) with
 // s[n] = max|W[n][:]| / 448 (the largest finite e4m3), one workgroup (one wave) per output row.
 // ------------------------------------------------------------------------------------------

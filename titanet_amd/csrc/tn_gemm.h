@@ -286,6 +286,44 @@ struct ProdIm2col {
   }
 };
 
+// P_TAPS: the same im2col operand from a PACKED copy of the input: X0[row][C] (row = b*T + t, element type AT, written by
+// prolog_pack_kernel) with the K axis in TAP-major order, A[r][j*C + ci] = X0[r + j - pad][ci] — i.e. row r of the operand
+// is KP*C contiguous elements of X0 starting at row r - pad, so the fill is 16-byte vector loads like a plain operand
+// (the weight is used in the matching [out][tap][ci] order).  Taps outside the utterance read as zero; frames beyond an
+// utterance's valid length are already zero in X0.  C must be a multiple of 8.
+struct ProdTaps {
+  struct Args {
+    const void* X0;   // [M][C]
+    int C, KP, T;
+  };
+  __host__ __device__ static size_t scratch_bytes(int, int, int, int, size_t) { return 16; }
+  template <typename AT, int NT, int CW>
+  __device__ __forceinline__ void init(const Args&, int, int, char*, int) { __syncthreads(); }
+  template <typename AT, int ROWS, int NT, int CW, int PITCH>
+  __device__ __forceinline__ void fill(AT* As, const Args& a, int M, int K, int tid, int r0, int kc) {
+    constexpr int BKP = PITCH, VC = CW / 8, RL = NT / VC, BM = ROWS;
+    const int vc = tid % VC, rl = tid / VC;
+    const int k = kc + vc * 8;
+    const int j = k / a.C, ci = k - j * a.C, dj = j - (a.KP - 1) / 2;
+    const AT* X0 = reinterpret_cast<const AT*>(a.X0);
+    for (int r = rl; r < BM; r += RL) {
+      float v[8];
+      const int gr = r0 + r;
+      bool ok = gr < M && k < K;
+      if (ok) {
+        const int tt = gr % a.T + dj;
+        ok = tt >= 0 && tt < a.T;
+      }
+      if (ok) load8(X0 + (size_t)(gr + dj) * a.C + ci, v);
+      else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+      }
+      store8_lds(As + r * BKP + vc * 8, v);
+    }
+  }
+};
+
 // ------------------------------------------------------------------------------------------
 // epilogues
 // ------------------------------------------------------------------------------------------

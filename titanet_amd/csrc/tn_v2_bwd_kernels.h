@@ -991,18 +991,18 @@ __global__ __launch_bounds__(V2_NT, (R == 32 ? 4 : 2)) void dgrad_v2_kernel(Dgra
     }
   }
   uint4 pz[NQ], py[NQ];
-  auto prefetch = [&](int tile) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int gr = tile * R + rq + 16 * q;
-      const bool ok = gr < a.M;
-      const size_t o = (size_t)gr * V2_C + c0;
-      pz[q] = ok ? *reinterpret_cast<const uint4*>(a.dZ + o) : make_uint4(0, 0, 0, 0);
-      py[q] = ok ? *reinterpret_cast<const uint4*>(a.Y + o) : make_uint4(0, 0, 0, 0);
-    }
+  auto prefetch_q = [&](int tile, int q) {
+    const int gr = tile * R + rq + 16 * q;
+    const bool ok = gr < a.M;
+    const size_t o = (size_t)gr * V2_C + c0;
+    pz[q] = ok ? *reinterpret_cast<const uint4*>(a.dZ + o) : make_uint4(0, 0, 0, 0);
+    py[q] = ok ? *reinterpret_cast<const uint4*>(a.Y + o) : make_uint4(0, 0, 0, 0);
   };
   int tile = blockIdx.x;
-  if (tile < a.ntiles) prefetch(tile);
+  if (tile < a.ntiles) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) prefetch_q(tile, q);
+  }
   __syncthreads();
   float k0[8], k1[8], k2[8];
 #pragma unroll
@@ -1022,7 +1022,10 @@ __global__ __launch_bounds__(V2_NT, (R == 32 ? 4 : 2)) void dgrad_v2_kernel(Dgra
       }
       store8(Pt + r * V2_AP + c0, z);
     }
-    if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
+    if (tile + (int)gridDim.x < a.ntiles) {     // (refilling inside the loop above measured 2.5 us slower)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) prefetch_q(tile + gridDim.x, q);
+    }
     __syncthreads();   // (2)
     f32x16_t acc[NTILE];
 #pragma unroll
@@ -1121,20 +1124,17 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) wf[ks] = __builtin_bit_cast(bf16x8_t, a.Wswz[((size_t)wave * 16 + ks) * 64 + lane]);
   uint4 pz[2], py[2], px[2];
-  auto prefetch = [&](int tile) {
-    const int g0 = tile * V6_OUT - 1;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int gr = g0 + rq + 16 * q;
-      const bool ok = gr >= 0 && gr < a.M;
-      const size_t o = (size_t)gr * V2_C + c0;
-      pz[q] = ok ? *reinterpret_cast<const uint4*>(a.dZ + o) : make_uint4(0, 0, 0, 0);
-      py[q] = ok ? *reinterpret_cast<const uint4*>(a.Y + o) : make_uint4(0, 0, 0, 0);
-      px[q] = ok ? *reinterpret_cast<const uint4*>(a.X + o) : make_uint4(0, 0, 0, 0);
-    }
+  // each prefetch register is refilled for the next tile right after it was consumed: the memory pipe never runs empty
+  auto prefetch_q = [&](int tile, int q) {
+    const int gr = tile * V6_OUT - 1 + rq + 16 * q;
+    const bool ok = gr >= 0 && gr < a.M;
+    const size_t o = (size_t)gr * V2_C + c0;
+    pz[q] = ok ? *reinterpret_cast<const uint4*>(a.dZ + o) : make_uint4(0, 0, 0, 0);
+    py[q] = ok ? *reinterpret_cast<const uint4*>(a.Y + o) : make_uint4(0, 0, 0, 0);
+    px[q] = ok ? *reinterpret_cast<const uint4*>(a.X + o) : make_uint4(0, 0, 0, 0);
   };
   int tile = blockIdx.x;
-  if (tile < a.ntiles) prefetch(tile);
+  if (tile < a.ntiles) { prefetch_q(tile, 0); prefetch_q(tile, 1); }
   __syncthreads();
   float sc[4], sh[4], wd[KD][4];
 #pragma unroll
@@ -1178,8 +1178,8 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
       }
       store8(Pt + r * V2_AP + c0, z);
       *reinterpret_cast<uint4*>(Xs + r * V2_C + c0) = px[q];
+      if (tile + (int)gridDim.x < a.ntiles) prefetch_q(tile + gridDim.x, q);
     }
-    if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
     __syncthreads();   // (2)
     // ---- dD = dY * W : 32 rows x this wave's 32 input channels
     {
