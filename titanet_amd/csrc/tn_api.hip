@@ -835,9 +835,17 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   // ---- decoder tail + loss head (reference src/models.py:504-513, src/losses.py)
   {
     BnAct actp = c.simple_pool ? identity_act() : make_act(p, m->pool_bn, B, training, 0, 0.f, seed, 0);
-    hipLaunchKernelGGL(tail_linear_fwd_kernel, dim3((B + 3) / 4, (c.emb + 63) / 64), dim3(256), (size_t)4 * 2 * D * sizeof(float), st,
-                       (const float*)(ws + p->pooled), actp, B, 2 * D, c.emb, params + m->lin_w, params + m->lin_b,
-                       (float*)(ws + p->lin), statp(m->lin_bn));
+    if ((2 * D) % 1024 == 0 && p->slab_bytes >= (size_t)4 * D * sizeof(float)) {
+      float* scsh = (float*)(ws + p->slabs);       // scratch: the weight-gradient slabs are idle in the forward pass
+      hipLaunchKernelGGL(bn_scale_shift_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, st, actp, 2 * D, scsh);
+      hipLaunchKernelGGL(tail_linear_fwd2_kernel, dim3((B + 3) / 4, (c.emb + 63) / 64), dim3(256), (size_t)4 * 2 * D * sizeof(float), st,
+                         (const float*)(ws + p->pooled), (const float*)scsh, B, 2 * D, c.emb, params + m->lin_w, params + m->lin_b,
+                         (float*)(ws + p->lin), statp(m->lin_bn));
+    } else {
+      hipLaunchKernelGGL(tail_linear_fwd_kernel, dim3((B + 3) / 4, (c.emb + 63) / 64), dim3(256), (size_t)4 * 2 * D * sizeof(float), st,
+                         (const float*)(ws + p->pooled), actp, B, 2 * D, c.emb, params + m->lin_w, params + m->lin_b,
+                         (float*)(ws + p->lin), statp(m->lin_bn));
+    }
     HeadArgs ha;
     memset(&ha, 0, sizeof(ha));
     ha.lin = (const float*)(ws + p->lin);
