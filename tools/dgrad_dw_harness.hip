@@ -1,4 +1,4 @@
-// Timing harness for dgrad_dw_v6 / v7 (tuning tool): same data, rotating buffer sets (cold), variants by -DV7_EXP=n.
+// Timing harness for dgrad_dw_v6 (tuning tool): rotating buffer sets (cold).
 #include "../titanet_amd/csrc/tn_v2_bwd_kernels.h"
 #include <string.h>
 #include <vector>
