@@ -356,6 +356,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         va.dZ = (const bf16_t*)(ws + bw.dZk); va.Y = (const bf16_t*)(ws + bw.S); va.bn = pa.bn;
         va.Wt = (const bf16_t*)(ws + bw.wskip.wt); va.OUT = (bf16_t*)(ws + p->dXs); va.M = M;
         va.Wswz = bw.wskip.swt ? (const uint4*)(ws + bw.wskip.swt) : nullptr;
+        ProfScope ps(p, TN_PROF_BWD_DGRAD, st);
         rc = launch_dgrad_v2<64>(va, 256, st);
       } else {
         GemmShape g{M, H, H, wt(bw.wskip)};
