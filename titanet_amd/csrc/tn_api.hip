@@ -229,6 +229,8 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   // ---- activations
   p->Y0 = b.take(M * H * e);
   {
+    const char* wdb = getenv("TN_WIDE_DW_BWD");
+    p->wide_dw_bwd = !(wdb && atoi(wdb) == 0);
     const char* pt = getenv("TN_PROLOG_TAPS");
     p->prolog_taps = precision == TN_PREC_BF16 && c.n_mels % 8 == 0 && !(pt && atoi(pt) == 0);
     if (p->prolog_taps) {

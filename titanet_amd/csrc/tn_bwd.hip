@@ -466,8 +466,19 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         da.OUT = ws + p->dA[cur ^ 1];
         da.bsumsX = (i == 0) ? bsum(m->prolog_bn) : nullptr;
       }
-      int rc;
-      {
+      int rc = -1000;
+      if (sizeof(AT) == 2 && !p->masked && H % V2_C == 0 && (c.kernel == 7 || c.kernel == 11) && p->wide_dw_bwd) {
+        // wide models: streaming slab kernel with the tap windows in registers (tn_v2_bwd_kernels.h)
+        DwBwdSlabArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.dD = (const bf16_t*)da.dD; sa.X = (const bf16_t*)da.XRAW; sa.actX = da.actX; sa.ADD = (const bf16_t*)da.ADD;
+        sa.OUT = (bf16_t*)da.OUT; sa.wdw = da.wdw; sa.g_wdw = da.g_wdw; sa.g_bdw = da.g_bdw; sa.bsumsX = da.bsumsX;
+        sa.M = M; sa.T = T; sa.C = H;
+        ProfScope ps(p, TN_PROF_BWD_DW, st);
+        rc = c.kernel == 7 ? launch_dw_bwd_slab<7>(sa, 256, st) : launch_dw_bwd_slab<11>(sa, 256, st);
+        if (rc > 0) return rc;
+      }
+      if (rc == -1000) {
         ProfScope ps(p, TN_PROF_BWD_DW, st);
         rc = launch_dw_bwd<AT>(da, c.kernel, st);
       }

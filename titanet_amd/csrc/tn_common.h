@@ -135,6 +135,13 @@ __device__ __forceinline__ void tn_drop4(float v[4], uint32_t idx8, uint32_t hal
   v[0] = ((h0 & 0xffffu) >= thr) ? v[0] : 0.f; v[1] = ((h0 >> 16) >= thr) ? v[1] : 0.f;
   v[2] = ((h1 & 0xffffu) >= thr) ? v[2] : 0.f; v[3] = ((h1 >> 16) >= thr) ? v[3] : 0.f;
 }
+// the channel pair `pair` (0..3) of the group
+__device__ __forceinline__ void tn_drop2(float v[2], uint32_t idx8, uint32_t pair, uint32_t key, uint32_t thr) {
+  const uint32_t x = tn_drop_shared(idx8, key);
+  const uint32_t c = pair == 0 ? TN_DROP_C0 : (pair == 1 ? TN_DROP_C1 : (pair == 2 ? TN_DROP_C2 : TN_DROP_C3));
+  const uint32_t h = tn_drop_final(x, c);
+  v[0] = ((h & 0xffffu) >= thr) ? v[0] : 0.f; v[1] = ((h >> 16) >= thr) ? v[1] : 0.f;
+}
 __host__ __device__ __forceinline__ bool tn_keep_elem(uint32_t e, uint32_t key, uint32_t thr) {
   const uint32_t x = tn_drop_shared(e >> 3, key);
   const uint32_t cs[4] = {TN_DROP_C0, TN_DROP_C1, TN_DROP_C2, TN_DROP_C3};

@@ -108,6 +108,7 @@ struct tn_plan {
   std::vector<BlockWs> blk;
   size_t E, HID, EN, pooled, smax, sinv, qv, lin, emb, emb_norm, dlogits, dscale, logits, preds;
   WcRef wprolog, wepi, wwin, wwout;
+  bool wide_dw_bwd = true;         // TN_WIDE_DW_BWD=0: generic depthwise backward for the wide models (A/B)
   bool prolog_taps = false;        // bf16 plans: prolog GEMMs read a packed rows x n_mels copy of the input (ProdTaps)
   size_t x0 = 0, wprolog_taps = 0, prolog_gtmp = 0;
   size_t cast_table, bn_table, stats_ptr_table;

@@ -951,6 +951,340 @@ inline int launch_combine_bwd2_v2(const CombineBwd2V2Args& a, int B, hipStream_t
 }
 
 // ==========================================================================================
+// dw_bwd_slab: depthwise backward + activation backward for the WIDE models (hidden = 512 / 1024, K = 7 / 11 taps), one
+// 256-channel slab of the C-wide tensors per workgroup.  The generic dw_bwd_kernel (64 x 64 tiles, fp32 LDS, a boundary
+// test and two LDS reads per tap and output) ran at 1/6 of its memory time on TitaNet-L (617 us for 472 MB).  Here:
+//   * raw dD and X rows of a 64-row tile (+ K - 1 halo rows) are moved by LDS-DMA into one of two LDS buffers while the
+//     previous tile is processed (no staging registers: the tap windows below need them);
+//   * a wave owns a strip of 8 output rows, a lane 4 channels; the K-row window of dD lives in REGISTERS and rolls down
+//     the strip (slots = row index mod K, all compile-time): a window row is read from LDS and unpacked once per strip
+//     instead of once per tap, and ONE window serves both the data gradient and the tap-weight gradient (see the fast
+//     path); 2 K FMAs per output and channel remain, which is what bounds the kernel at K = 11;
+//   * strips whose window crosses an utterance / batch boundary take a per-tap path with wave-uniform tests.
+// FL bits as in dw_bwd_v4: 1 BatchNorm on load of X, 2 ReLU, 4 dropout, 8 skip-path addend.
+// ==========================================================================================
+typedef __attribute__((address_space(3))) char tn_lds_char;
+__device__ __forceinline__ void tn_dma16(const void* gptr, unsigned lds_addr) {
+  unsigned keep;
+  // hidden from hipcc's waitcnt bookkeeping (cdna_hip_programming.md: M0 written in the statement that reads it)
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gptr), "s"(lds_addr) : "memory");
+}
+template <int FL, int CH>
+__device__ __forceinline__ void act_c(float (&v)[CH], const float (&sc)[CH], const float (&sh)[CH], uint32_t key, uint32_t thr, uint32_t row, int C, int c) {
+  if (FL & 1) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
+  }
+  if (FL & 2) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) v[i] = fmaxf(v[i], 0.f);
+  }
+  if (FL & 4) {
+    const uint32_t e = row * (uint32_t)C + (uint32_t)c;
+    if (CH == 4) tn_drop4(v, e >> 3, (uint32_t)(c >> 2) & 1u, key, thr);
+    else tn_drop2(v, e >> 3, (uint32_t)(c >> 1) & 3u, key, thr);
+  }
+}
+// CH consecutive bf16 channels <-> floats
+template <int CH>
+__device__ __forceinline__ void ld_ch(const bf16_t* p, float (&v)[CH]) {
+  if (CH == 4) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+  } else {
+    const uint32_t r = *reinterpret_cast<const uint32_t*>(p);
+    v[0] = __uint_as_float(r << 16); v[1] = __uint_as_float(r & 0xffff0000u);
+  }
+}
+template <int CH>
+__device__ __forceinline__ void st_ch(bf16_t* p, const float (&v)[CH]) {
+  if (CH == 4) {
+    uint2 o;
+    o.x = f2bf_pk(v[0], v[1]); o.y = f2bf_pk(v[2], v[3]);
+    *reinterpret_cast<uint2*>(p) = o;
+  } else {
+    *reinterpret_cast<uint32_t*>(p) = f2bf_pk(v[0], v[1]);
+  }
+}
+// wait until at most n (wave-uniform, even, <= 10) younger vector-memory operations are outstanding, naming the registers of
+// the asm loads this retires (so that no consumer is scheduled above the wait)
+template <int RS>
+__device__ __forceinline__ void tn_wait_add(int n, uint32_t (&r)[RS]) {
+#define TN_WAIT_NAMED(N)                                                                                            \
+  do {                                                                                                              \
+    asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4 % RS]), "+v"(r[5 % RS]), "+v"(r[6 % RS]), "+v"(r[7 % RS])); \
+    if (RS > 8) asm volatile("" : "+v"(r[8 % RS]), "+v"(r[9 % RS]), "+v"(r[10 % RS]), "+v"(r[11 % RS]), "+v"(r[12 % RS]), "+v"(r[13 % RS]), "+v"(r[14 % RS]), "+v"(r[15 % RS])); \
+  } while (0)
+  switch (n) {
+    case 0: TN_WAIT_NAMED(0); break;
+    case 2: TN_WAIT_NAMED(2); break;
+    case 4: TN_WAIT_NAMED(4); break;
+    case 6: TN_WAIT_NAMED(6); break;
+    case 8: TN_WAIT_NAMED(8); break;
+    default: TN_WAIT_NAMED(10); break;
+  }
+#undef TN_WAIT_NAMED
+}
+struct DwBwdSlabArgs {
+  const bf16_t* dD; const bf16_t* X; BnAct actX;
+  const bf16_t* ADD;   // or null
+  bf16_t* OUT;
+  const float* wdw;    // [C][KD]
+  float* g_wdw;        // [C][KD] (atomic accumulate, pre-zeroed)
+  float* g_bdw;        // [C]
+  float* bsumsX;       // [TN_NREP][2][C] or null
+  int M, T, C, ntiles;
+};
+// CH = channels per lane: 4 (one wave per strip of 8 output rows) or 2 (two waves per strip of 16 rows: half the window /
+// weight / accumulator registers per lane, which is what K = 11 needs to stay out of scratch)
+template <int KD, int FL, int CH>
+__global__ __launch_bounds__(512, 2) void dw_bwd_slab_kernel(DwBwdSlabArgs a) {
+  constexpr int PADR = (KD - 1) / 2, ROWS = 64 + KD - 1, NT = 512;
+  constexpr int TILE_B = ROWS * 512;                        // bytes of one stream's tile
+  constexpr int WPS = 4 / CH, RS = 8 * WPS;                 // waves per strip, output rows per strip
+  constexpr bool HAS_MASK = (FL & 7) != 0, HAS_ADD = (FL & 8) != 0;
+  static_assert(KD % 2 == 1 && KD <= 15 && (CH == 2 || CH == 4), "odd tap counts up to 15; 2 or 4 channels per lane");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [2 buffers][dD | X][ROWS][256] bf16 raw, then mean*rstd, rstd : [2][256].  The start-up constants sc, sh, wd[KD]
+  // ([2 + KD][256] floats) sit in buffer 1 until they are in registers (its first DMA is issued after that).
+  float* fin = reinterpret_cast<float*>(smem + 4 * TILE_B);
+  float* cst = reinterpret_cast<float*>(smem + 2 * TILE_B);
+  const unsigned ring_lds = (unsigned)(uintptr_t)(tn_lds_char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cl = (wave % WPS) * 64 * CH + lane * CH;           // first channel of the lane inside the slab
+  const int strip = wave / WPS;
+  const int nslab = a.C / V2_C;
+  const int slab = blockIdx.x % nslab, first = blockIdx.x / nslab, stride = gridDim.x / nslab;
+  const int cb = slab * V2_C;                                  // first channel of the slab
+  const float mscale = (FL & 4) ? a.actX.inv_keep : 1.f;
+  const uint32_t dkey = tn_act_key(a.actX), dthr = a.actX.drop_thr;
+  if (tid < V2_C) {
+    float s = 1.f, h = 0.f, mean = 0.f, rstd = 1.f;
+    if (FL & 1) { bn_scale_shift(a.actX, a.C, cb + tid, s, h); bn_mean_rstd(a.actX, a.C, cb + tid, mean, rstd); }
+    cst[tid] = s; cst[V2_C + tid] = h; fin[tid] = mean * rstd; fin[V2_C + tid] = rstd;
+#pragma unroll
+    for (int k = 0; k < KD; ++k) cst[(2 + k) * V2_C + tid] = a.wdw[(size_t)(cb + tid) * KD + k];
+  }
+  // every compiler-visible load is complete before the first DMA: the waits below are plain vmcnt(0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // this wave's rows of a tile: 2 rows (1 KB) per instruction, rows 2 * (wave + 8 i)
+  auto dma_tile = [&](int tile, int buf) {
+    const int raw0 = tile * 64 - PADR;
+#pragma unroll
+    for (int i = 0; i < (ROWS / 2 + 7) / 8; ++i) {
+      const int r = 2 * (wave + 8 * i);
+      if (r < ROWS) {
+        int gr = raw0 + r + (lane >> 5);
+        gr = gr < 0 ? 0 : (gr >= a.M ? a.M - 1 : gr);          // rows outside the tensor: any valid row (never used)
+        const size_t o = (size_t)gr * a.C + cb + (lane & 31) * 8;
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(ring_lds + buf * 2 * TILE_B + r * 512));
+        tn_dma16(a.dD + o, dst);
+        tn_dma16(a.X + o, dst + TILE_B);
+      }
+    }
+  };
+  if (first < a.ntiles) dma_tile(first, 0);
+  __syncthreads();
+  float sc[CH], sh[CH], wd[KD][CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    sc[i] = cst[cl + i]; sh[i] = cst[V2_C + cl + i];
+#pragma unroll
+    for (int k = 0; k < KD; ++k) wd[k][i] = cst[(2 + k) * V2_C + cl + i];
+  }
+  float gw[KD][CH], gb[CH], s1[CH], s2[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    gb[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KD; ++k) gw[k][i] = 0.f;
+  }
+  int buf = 0;
+  for (int tile = first; tile < a.ntiles; tile += stride, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this tile's DMA (and the previous tile's stores)
+    __builtin_amdgcn_s_barrier();                              // every wave's part landed; the other buffer is free again
+    const int out0 = tile * 64, raw0 = out0 - PADR;
+    const int l0 = strip * RS;                                 // LDS row of the strip's first window row
+    // skip-path addend rows of the strip.  A load hipcc counts would be waited for with vmcnt(its later loads), and the
+    // DMA instructions issued below — which hipcc does not see — would then have to retire first (in-order counter): the
+    // next tile's DMA serialised with this tile's arithmetic (+70 % on this variant).  So: asm loads issued BEFORE the DMA,
+    // waited for with vmcnt(number of DMA instructions this wave issues after them), their registers named in the wait.
+    constexpr int NADD = HAS_ADD ? RS * CH / 2 : 2;           // 32-bit words per lane
+    uint32_t addr_[NADD];
+    if constexpr (HAS_ADD) {
+#pragma unroll
+      for (int o = 0; o < RS; ++o) {
+        int gr = out0 + l0 + o;
+        gr = gr < a.M ? gr : a.M - 1;
+        const bf16_t* src = a.ADD + (size_t)gr * a.C + cb + cl;
+#pragma unroll
+        for (int h = 0; h < CH / 2; ++h) asm volatile("global_load_dword %0, %1, off" : "=v"(addr_[o * (CH / 2) + h]) : "v"(src + 2 * h));
+      }
+    }
+    const bool more = tile + stride < a.ntiles;
+    if (more) dma_tile(tile + stride, buf ^ 1);
+    float addv[HAS_ADD ? RS : 1][CH];
+    if constexpr (HAS_ADD) {
+      // DMA instructions this wave just issued: 2 per 2-row piece, pieces r = 2 (wave + 8 i) < ROWS
+      const int n_dma = more ? 2 * ((ROWS / 2 - wave + 7) / 8) : 0;
+      tn_wait_add<NADD>(__builtin_amdgcn_readfirstlane(n_dma), addr_);
+#pragma unroll
+      for (int o = 0; o < RS; ++o)
+#pragma unroll
+        for (int h = 0; h < CH / 2; ++h) {
+          addv[o][2 * h] = __uint_as_float(addr_[o * (CH / 2) + h] << 16);
+          addv[o][2 * h + 1] = __uint_as_float(addr_[o * (CH / 2) + h] & 0xffff0000u);
+        }
+    }
+    const bf16_t* Ds = reinterpret_cast<const bf16_t*>(smem + buf * 2 * TILE_B);
+    const bf16_t* Xs = reinterpret_cast<const bf16_t*>(smem + buf * 2 * TILE_B + TILE_B);
+    const int g_first = raw0 + l0, g_last = g_first + KD + RS - 2;   // window rows l0 .. l0 + KD + RS - 2
+    const bool fast = g_first >= 0 && g_last < a.M && (g_first % a.T) + KD + RS - 2 < a.T;   // wave-uniform
+    if (fast) {
+      // d w[k] = sum_r dD[r] A[r + k - pad] is summed here over the A rows of the strip (r' = r + k - pad): its dD operand is
+      // then dD[r' - k + pad], the SAME row the data gradient of output row r' multiplies with w[k] — one window (of dD) serves
+      // both sums and the activation is evaluated once per output row, not once per window row.
+      float D[KD][CH];
+#pragma unroll
+      for (int j = 0; j < KD - 1; ++j) ld_ch<CH>(Ds + (l0 + j) * V2_C + cl, D[j % KD]);
+#pragma unroll
+      for (int o = 0; o < RS; ++o) {
+        ld_ch<CH>(Ds + (l0 + o + KD - 1) * V2_C + cl, D[(o + KD - 1) % KD]);
+        float y[CH], Ac[CH], dA[CH];
+        ld_ch<CH>(Xs + (l0 + o + PADR) * V2_C + cl, y);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) { Ac[i] = y[i]; dA[i] = 0.f; }
+        act_c<(FL & 7), CH>(Ac, sc, sh, dkey, dthr, (uint32_t)(g_first + o + PADR), a.C, cb + cl);
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+          const int sl = (o + KD - 1 - k) % KD;
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            dA[i] = fmaf(wd[k][i], D[sl][i], dA[i]);
+            gw[k][i] = fmaf(Ac[i], D[sl][i], gw[k][i]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) gb[i] += D[(o + PADR) % KD][i];
+        const size_t oo = (size_t)(out0 + l0 + o) * a.C + cb + cl;
+        if (HAS_ADD) {
+#pragma unroll
+          for (int i = 0; i < CH; ++i) dA[i] += addv[o][i];
+        }
+        if (HAS_MASK) {
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            const float m = (FL & 2) ? ((Ac[i] > 0.f) ? mscale : 0.f) : mscale;
+            dA[i] *= m;
+            s1[i] += dA[i];
+            s2[i] = fmaf(dA[i], y[i], s2[i]);
+          }
+        }
+        st_ch<CH>(a.OUT + oo, dA);
+        __builtin_amdgcn_sched_barrier(0);       // rows in order: bounds the live temporaries
+      }
+    } else {
+      // boundary strips: per-tap tests (wave-uniform), the dD rows straight from LDS
+#pragma unroll 1
+      for (int o = 0; o < RS; ++o) {
+        const int gr = out0 + l0 + o;
+        if (gr >= a.M) break;
+        const int t = gr % a.T;
+        float Dc[CH], dA[CH], Ac[CH], Yc[CH];
+        ld_ch<CH>(Ds + (l0 + o + PADR) * V2_C + cl, Dc);
+        ld_ch<CH>(Xs + (l0 + o + PADR) * V2_C + cl, Yc);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) { dA[i] = 0.f; gb[i] += Dc[i]; Ac[i] = Yc[i]; }
+        act_c<(FL & 7), CH>(Ac, sc, sh, dkey, dthr, (uint32_t)gr, a.C, cb + cl);
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+          const int tb = t - k + PADR;               // frame of dD[gr - k + PADR]: inside this utterance?
+          if (tb >= 0 && tb < a.T) {
+            float v[CH];
+            ld_ch<CH>(Ds + (l0 + o + KD - 1 - k) * V2_C + cl, v);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) { dA[i] = fmaf(wd[k][i], v[i], dA[i]); gw[k][i] = fmaf(Ac[i], v[i], gw[k][i]); }
+          }
+        }
+        const size_t oo = (size_t)gr * a.C + cb + cl;
+        if (HAS_ADD) {
+          float ad[CH];
+          ld_ch<CH>(a.ADD + oo, ad);
+#pragma unroll
+          for (int i = 0; i < CH; ++i) dA[i] += ad[i];
+        }
+        if (HAS_MASK) {
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            const float m = (FL & 2) ? ((Ac[i] > 0.f) ? mscale : 0.f) : mscale;
+            dA[i] *= m;
+            s1[i] += dA[i];
+            s2[i] = fmaf(dA[i], Yc[i], s2[i]);
+          }
+        }
+        st_ch<CH>(a.OUT + oo, dA);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // s2 was accumulated against the RAW x:  sum dA * xhat = rstd * sum dA*x - mean*rstd * sum dA
+#pragma unroll
+  for (int i = 0; i < CH; ++i) s2[i] = fin[V2_C + cl + i] * s2[i] - fin[cl + i] * s1[i];
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);       // [strips][KD + 3][256] inside the tile buffers
+  {
+    float* mine = red + (size_t)strip * (KD + 3) * V2_C + cl;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+#pragma unroll
+      for (int k = 0; k < KD; ++k) mine[k * V2_C + i] = gw[k][i];
+      mine[KD * V2_C + i] = gb[i]; mine[(KD + 1) * V2_C + i] = s1[i]; mine[(KD + 2) * V2_C + i] = s2[i];
+    }
+  }
+  __syncthreads();
+  const int rep = (blockIdx.x / nslab) % TN_NREP;
+  for (int i = tid; i < (KD + 3) * V2_C; i += NT) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8 / WPS; ++w) v += red[(size_t)w * (KD + 3) * V2_C + i];
+    const int k = i / V2_C, c = cb + i % V2_C;
+    if (k < KD) atomic_add_f32(&a.g_wdw[(size_t)c * KD + k], v);
+    else if (k == KD) atomic_add_f32(&a.g_bdw[c], v);
+    else if (a.bsumsX && HAS_MASK) atomic_add_f32(&a.bsumsX[(size_t)(rep * 2 + (k - KD - 1)) * a.C + c], v);
+  }
+}
+template <int KD, int FL>
+inline int launch_dw_bwd_slab_t(DwBwdSlabArgs a, int grid, hipStream_t st) {
+  constexpr int ROWS = 64 + KD - 1;
+  const size_t tiles = (size_t)4 * ROWS * 512, red = (size_t)8 * (KD + 3) * V2_C * sizeof(float);
+  const size_t smem = (tiles > red ? tiles : red) + (size_t)2 * V2_C * sizeof(float);
+  auto kern = dw_bwd_slab_kernel<KD, FL, (KD >= 7 ? 2 : 4)>;
+  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a);
+  return (int)hipGetLastError();
+}
+// -1000: no specialisation for this (taps, flags) combination (caller runs the generic dw_bwd_kernel)
+template <int KD>
+inline int launch_dw_bwd_slab(DwBwdSlabArgs a, int max_wgs, hipStream_t st) {
+  if (a.C % V2_C != 0) return -1000;
+  a.ntiles = (a.M + 63) / 64;
+  const int nslab = a.C / V2_C;
+  int per = max_wgs / nslab;
+  if (per < 1) per = 1;
+  if (per > a.ntiles) per = a.ntiles;
+  const int grid = per * nslab;
+  const int fl = (a.actX.mode != 0 ? 1 : 0) | (a.actX.relu ? 2 : 0) | (a.actX.drop_thr ? 4 : 0) | (a.ADD ? 8 : 0);
+  switch (fl) {
+    case 7: return launch_dw_bwd_slab_t<KD, 7>(a, grid, st);
+    case 11: return launch_dw_bwd_slab_t<KD, 11>(a, grid, st);
+    case 8: return launch_dw_bwd_slab_t<KD, 8>(a, grid, st);
+    default: return -1000;
+  }
+}
+
+// ==========================================================================================
 // Pointwise data gradient, lean version:  dD = BatchNorm-backward-on-load(dZ, Y) * W
 // (the 1x1-conv dgrad of sub-blocks and skip connections).  R rows per tile; R = 32 keeps the kernel
 // under 128 VGPRs so TWO workgroups (16 waves) share a CU and overlap each other's load / transform /
