@@ -64,6 +64,50 @@ struct ProdDy {
     for (int c = tid; c < K; c += NT) bn_bwd_coefs(a.bn, K, c, k0[c], k1[c], k2[c]);
     __syncthreads();
   }
+  // bf16 pipelined loop of gemm_nt_kernel (tn_gemm.h)
+  static constexpr bool kRaw = true;
+  template <int N> struct Regs { uint4 z[N]; uint4 y[N]; };
+  template <int ROWS, int NT, int CW, int N>
+  __device__ __forceinline__ void load_raw(Regs<N>& rg, const Args& a, int M, int K, int tid, int r0, int kc) {
+    constexpr int VC = CW / 8, RL = NT / VC;
+    const int vc = tid % VC, rl = tid / VC, k = kc + vc * 8;
+    const bf16_t* dZ = reinterpret_cast<const bf16_t*>(a.dZ);
+    const bf16_t* Y = reinterpret_cast<const bf16_t*>(a.Y);
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      const int gr = r0 + rl + q * RL;
+      const bool ok = gr < M && k < K;
+      const size_t o = (size_t)gr * a.ld + k;
+      rg.z[q] = ok ? *reinterpret_cast<const uint4*>(dZ + o) : make_uint4(0, 0, 0, 0);
+      rg.y[q] = ok ? *reinterpret_cast<const uint4*>(Y + o) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  template <int ROWS, int NT, int CW, int PITCH, int N>
+  __device__ __forceinline__ void commit_raw(bf16_t* As, const Regs<N>& rg, const Args& a, int M, int K, int tid, int r0, int kc) {
+    constexpr int VC = CW / 8, RL = NT / VC;
+    const int vc = tid % VC, rl = tid / VC, k = kc + vc * 8;
+    // coefficients of the thread's 8 columns: unconditional 16-byte LDS reads (K is a multiple of 8 on this path)
+    float c0[8], c1[8], c2[8];
+    const int kk = k < K ? k : 0;
+    *reinterpret_cast<float4*>(c0) = *reinterpret_cast<const float4*>(k0 + kk); *reinterpret_cast<float4*>(c0 + 4) = *reinterpret_cast<const float4*>(k0 + kk + 4);
+    *reinterpret_cast<float4*>(c1) = *reinterpret_cast<const float4*>(k1 + kk); *reinterpret_cast<float4*>(c1 + 4) = *reinterpret_cast<const float4*>(k1 + kk + 4);
+    *reinterpret_cast<float4*>(c2) = *reinterpret_cast<const float4*>(k2 + kk); *reinterpret_cast<float4*>(c2 + 4) = *reinterpret_cast<const float4*>(k2 + kk + 4);
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      const int r = rl + q * RL, gr = r0 + r;
+      const bool ok = gr < M && k < K && tn_row_valid(a.bn.rm, (uint32_t)gr);
+      const uint4 z = rg.z[q], y = rg.y[q];
+      const uint32_t zw[4] = {z.x, z.y, z.z, z.w}, yw[4] = {y.x, y.y, y.z, y.w};
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a0 = fmaf(c0[2 * i], __uint_as_float(zw[i] << 16), fmaf(c1[2 * i], __uint_as_float(yw[i] << 16), c2[2 * i]));
+        const float a1 = fmaf(c0[2 * i + 1], __uint_as_float(zw[i] & 0xffff0000u), fmaf(c1[2 * i + 1], __uint_as_float(yw[i] & 0xffff0000u), c2[2 * i + 1]));
+        v[2 * i] = ok ? a0 : 0.f; v[2 * i + 1] = ok ? a1 : 0.f;
+      }
+      store8(As + r * PITCH + vc * 8, v);
+    }
+  }
   template <typename AT, int ROWS, int NT, int CW, int PITCH>
   __device__ __forceinline__ void fill(AT* As, const Args& a, int M, int K, int tid, int r0, int kc) {
     constexpr int VC = CW / 8, RL = NT / VC;

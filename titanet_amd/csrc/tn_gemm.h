@@ -59,7 +59,7 @@ __device__ __forceinline__ void fill_tile_plain(AT* dst, const AT* __restrict__ 
 // the kernel
 // ------------------------------------------------------------------------------------------
 template <typename AT, int WM, int WN, typename Prod, typename Epi>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 4 : 3)) void gemm_nt_kernel(GemmShape g, typename Prod::Args pa,
+__global__ __launch_bounds__(WM* WN * 64, ((sizeof(AT) == 2 && Prod::kRaw) ? 2 : (WM * WN >= 8 ? 4 : 3))) void gemm_nt_kernel(GemmShape g, typename Prod::Args pa,
                                                                typename Epi::Args ea) {
   constexpr int BM = WM * 64, BN = WN * 64, BK = Elem<AT>::BK, BKP = BK + Elem<AT>::PAD, NT = WM * WN * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -83,10 +83,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 4 : 3)) void gemm_nt_k
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const AT* W = reinterpret_cast<const AT*>(g.W);
-  for (int kc = 0; kc < g.K; kc += BK) {
-    fill_tile_plain<AT, BN, NT>(Bs, W, g.N, g.K, g.K, n0, kc, tid);
-    prod.template fill<AT, BM, NT, BK, BKP>(As, pa, g.M, g.K, tid, r0, kc);   // result in As; may sync internally
-    __syncthreads();
+  auto mma_tile = [&]() {
     const AT* arow0 = As + (wm * 64 + (lane & 31)) * BKP;
     const AT* brow0 = Bs + (wn * 64 + (lane & 31)) * BKP;
     const int half = lane >> 5;
@@ -101,7 +98,46 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 4 : 3)) void gemm_nt_k
       acc[1][0] = Mma<AT>::mma(a1, b0, acc[1][0]);
       acc[1][1] = Mma<AT>::mma(a1, b1, acc[1][1]);
     }
-    __syncthreads();
+  };
+  if constexpr (sizeof(AT) == 2 && Prod::kRaw) {
+    // bf16 operands that are (functions of) stored matrices: the raw 16-byte vectors of the NEXT K chunk are requested
+    // before this chunk's MFMAs and turned into LDS tiles after them (the weight tile is a straight copy) — the synchronous
+    // loop below spent as many VALU cycles on bf16 -> f32 -> bf16 round trips and exposed loads as on the MFMAs
+    // (TitaNet-L pointwise GEMMs: 354 / 435 us for 161 GFLOP)
+    constexpr int VC = BK / 8, RL = NT / VC, NW = BN / RL;
+    const int vc = tid % VC, rl = tid / VC;
+    uint4 wreg[NW];
+    typename Prod::template Regs<BM / RL> areg;
+    auto load_w = [&](int kc) {
+      const int k = kc + vc * 8;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        const int gn = n0 + rl + q * RL;
+        wreg[q] = (gn < g.N && k < g.K) ? *reinterpret_cast<const uint4*>(W + (size_t)gn * g.K + k) : make_uint4(0, 0, 0, 0);
+      }
+    };
+    load_w(0);
+    prod.template load_raw<BM, NT, BK>(areg, pa, g.M, g.K, tid, r0, 0);
+    for (int kc = 0; kc < g.K; kc += BK) {
+#pragma unroll
+      for (int q = 0; q < NW; ++q) *reinterpret_cast<uint4*>(Bs + (rl + q * RL) * BKP + vc * 8) = wreg[q];
+      prod.template commit_raw<BM, NT, BK, BKP>(reinterpret_cast<bf16_t*>(As), areg, pa, g.M, g.K, tid, r0, kc);
+      __syncthreads();
+      if (kc + BK < g.K) {
+        load_w(kc + BK);
+        prod.template load_raw<BM, NT, BK>(areg, pa, g.M, g.K, tid, r0, kc + BK);
+      }
+      mma_tile();
+      __syncthreads();
+    }
+  } else {
+    for (int kc = 0; kc < g.K; kc += BK) {
+      fill_tile_plain<AT, BN, NT>(Bs, W, g.N, g.K, g.K, n0, kc, tid);
+      prod.template fill<AT, BM, NT, BK, BKP>(As, pa, g.M, g.K, tid, r0, kc);   // result in As; may sync internally
+      __syncthreads();
+      mma_tile();
+      __syncthreads();
+    }
   }
   Epi::template run<AT, WM, WN>(acc, ea, g, smem, tid, r0, n0);
 }
@@ -136,6 +172,45 @@ struct ProdPlain {
     }
     __syncthreads();
   }
+  // bf16 pipelined loop of gemm_nt_kernel: raw vectors of a K chunk (requested early), then tile rows (after the MFMAs)
+  static constexpr bool kRaw = true;
+  template <int N> struct Regs { uint4 x[N]; };
+  template <int ROWS, int NT, int CW, int N>
+  __device__ __forceinline__ void load_raw(Regs<N>& rg, const Args& a, int M, int K, int tid, int r0, int kc) {
+    constexpr int VC = CW / 8, RL = NT / VC;
+    const int vc = tid % VC, rl = tid / VC, k = kc + vc * 8;
+    const bf16_t* X = reinterpret_cast<const bf16_t*>(a.X);
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      const int gr = r0 + rl + q * RL;
+      rg.x[q] = (gr < M && k < K) ? *reinterpret_cast<const uint4*>(X + (size_t)gr * a.ldx + k) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  template <int ROWS, int NT, int CW, int PITCH, int N>
+  __device__ __forceinline__ void commit_raw(bf16_t* As, const Regs<N>& rg, const Args& a, int M, int K, int tid, int r0, int kc) {
+    constexpr int VC = CW / 8, RL = NT / VC;
+    const int vc = tid % VC, rl = tid / VC, k = kc + vc * 8;
+    const bool plain = a.act.mode == 0 && !a.act.relu && !a.act.drop_thr && !a.act.rm.len;     // uniform
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      const int r = rl + q * RL, gr = r0 + r;
+      if (plain) {
+        *reinterpret_cast<uint4*>(As + r * PITCH + vc * 8) = rg.x[q];       // out-of-range vectors were loaded as zeros
+      } else {
+        float v[8];
+        v[0] = __uint_as_float(rg.x[q].x << 16); v[1] = __uint_as_float(rg.x[q].x & 0xffff0000u);
+        v[2] = __uint_as_float(rg.x[q].y << 16); v[3] = __uint_as_float(rg.x[q].y & 0xffff0000u);
+        v[4] = __uint_as_float(rg.x[q].z << 16); v[5] = __uint_as_float(rg.x[q].z & 0xffff0000u);
+        v[6] = __uint_as_float(rg.x[q].w << 16); v[7] = __uint_as_float(rg.x[q].w & 0xffff0000u);
+        if (gr < M && k < K) act8(v, sc + k, sh + k, a.act, (uint32_t)gr, K, k);
+        else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        }
+        store8(As + r * PITCH + vc * 8, v);
+      }
+    }
+  }
   template <typename AT, int ROWS, int NT, int CW, int PITCH>
   __device__ __forceinline__ void fill(AT* As, const Args& a, int M, int K, int tid, int r0, int kc) {
     constexpr int BKP = PITCH, VC = CW / 8, RL = NT / VC, BM = ROWS;
@@ -160,6 +235,7 @@ struct ProdPlain {
 // P_DW: A[r][c] = b_dw[c] + sum_j w_dw[c][j] * act(X)[r + j - pad][c]   (zero outside the utterance)
 // — the depthwise conv of reference src/modules.py:65-75 fused as the prologue of its pointwise GEMM.
 struct ProdDw {
+  static constexpr bool kRaw = false;
   struct Args {
     const void* X;
     int ldx;
@@ -249,6 +325,7 @@ struct ProdDw {
 // P_IM2COL (prolog): A[r][ci*KP + j] = x[b][ci][t + j - pad]; x is the float [B, n_mels, T] input of
 // TitaNet.forward (reference src/models.py:318-331, prolog conv :370).  K = n_mels * KP.
 struct ProdIm2col {
+  static constexpr bool kRaw = false;
   struct Args {
     const float* x;   // [B][n_mels][T] float32, T contiguous (reference layout)
     int n_mels, KP, T;
@@ -292,6 +369,7 @@ struct ProdIm2col {
 // (the weight is used in the matching [out][tap][ci] order).  Taps outside the utterance read as zero; frames beyond an
 // utterance's valid length are already zero in X0.  C must be a multiple of 8.
 struct ProdTaps {
+  static constexpr bool kRaw = false;
   struct Args {
     const void* X0;   // [M][C]
     int C, KP, T;
