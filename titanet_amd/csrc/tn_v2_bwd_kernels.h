@@ -1552,15 +1552,11 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
         }
       }
       if (fast) {
-        // rolling 3-row window (slots j % 3): every window row is loaded, unpacked and activated once
-        float D[3][4], A[3][4], Yr[3][4];
-        auto place = [&](int j, int slot) {
-          ldD(i0 - 1 + j, D[slot]);
-          ldX(i0 - 1 + j, Yr[slot]);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) A[slot][i] = Yr[slot][i];
-          act4_t<FL>(A[slot], sc, sh, dkey, dthr, (uint32_t)(gfirst + j), c4);
-        };
+        // rolling 3-row window of dD (slots j % 3).  The tap-weight gradient d w[k] = sum_r dD[r] A[r + k - 1] is summed over
+        // the A rows of the strip (r' = r + k - 1): its dD operand dD[r' - k + 1] is then a row of the SAME window the data
+        // gradient of output row r' uses, and the activation is evaluated for the output rows only (4 per strip, not 6).
+        float D[3][4];
+        auto place = [&](int j, int slot) { ldD(i0 - 1 + j, D[slot]); };
         place(0, 0);
         place(1, 1);
 #pragma unroll
@@ -1568,16 +1564,20 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
           if (q == 3 && !nr4) break;
           const int P = q % 3, C_ = (q + 1) % 3, N = (q + 2) % 3;
           place(q + 2, N);
-          float dA[4];
+          float Yr[4], Ac[4], dA[4];
+          ldX(i0 + q, Yr);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) Ac[i] = Yr[i];
+          act4_t<FL>(Ac, sc, sh, dkey, dthr, (uint32_t)(gfirst + q + 1), c4);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             gb[i] += D[C_][i];
             dA[i] = wd[1][i] * D[C_][i];
             dA[i] = fmaf(wd[0][i], D[N][i], dA[i]);
             dA[i] = fmaf(wd[2][i], D[P][i], dA[i]);
-            gw[0][i] = fmaf(D[C_][i], A[P][i], gw[0][i]);
-            gw[1][i] = fmaf(D[C_][i], A[C_][i], gw[1][i]);
-            gw[2][i] = fmaf(D[C_][i], A[N][i], gw[2][i]);
+            gw[0][i] = fmaf(Ac[i], D[N][i], gw[0][i]);
+            gw[1][i] = fmaf(Ac[i], D[C_][i], gw[1][i]);
+            gw[2][i] = fmaf(Ac[i], D[P][i], gw[2][i]);
           }
           if (HAS_ADD) {
             float ad[4];
@@ -1588,10 +1588,10 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
           if (HAS_MASK) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const float m = (FL & 2) ? ((A[C_][i] > 0.f) ? mscale : 0.f) : mscale;
+              const float m = (FL & 2) ? ((Ac[i] > 0.f) ? mscale : 0.f) : mscale;
               dA[i] *= m;
               s1[i] += dA[i];
-              s2[i] = fmaf(dA[i], Yr[C_][i], s2[i]);
+              s2[i] = fmaf(dA[i], Yr[i], s2[i]);
             }
           }
           uint2 ov;
@@ -1607,7 +1607,7 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
           const int i = i0 + q, gr = g0 + i;
           if (i > V6_OUT || gr < 0 || gr >= a.M) continue;
           const int t = gr % a.T;
-          float Dc[4], Dn[4], Dp[4], Ac[4], An[4], Ap[4], Yc[4], dA[4];
+          float Dc[4], Dn[4], Dp[4], Ac[4], Yc[4], dA[4];
           ldD(i, Dc); ldX(i, Yc);
 #pragma unroll
           for (int c = 0; c < 4; ++c) Ac[c] = Yc[c];
@@ -1616,19 +1616,17 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
           for (int c = 0; c < 4; ++c) {
             gb[c] += Dc[c];
             dA[c] = wd[1][c] * Dc[c];
-            gw[1][c] = fmaf(Dc[c], Ac[c], gw[1][c]);
+            gw[1][c] = fmaf(Ac[c], Dc[c], gw[1][c]);
           }
           if (t + 1 < a.T && gr + 1 < a.M) {      // next row belongs to the same utterance (tile row i + 1 <= 31 exists)
-            ldD(i + 1, Dn); ldX(i + 1, An);
-            act4_t<FL>(An, sc, sh, dkey, dthr, (uint32_t)(gr + 1), c4);
+            ldD(i + 1, Dn);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { dA[c] = fmaf(wd[0][c], Dn[c], dA[c]); gw[2][c] = fmaf(Dc[c], An[c], gw[2][c]); }
+            for (int c = 0; c < 4; ++c) { dA[c] = fmaf(wd[0][c], Dn[c], dA[c]); gw[0][c] = fmaf(Ac[c], Dn[c], gw[0][c]); }
           }
           if (t > 0) {
-            ldD(i - 1, Dp); ldX(i - 1, Ap);
-            act4_t<FL>(Ap, sc, sh, dkey, dthr, (uint32_t)(gr - 1), c4);
+            ldD(i - 1, Dp);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { dA[c] = fmaf(wd[2][c], Dp[c], dA[c]); gw[0][c] = fmaf(Dc[c], Ap[c], gw[0][c]); }
+            for (int c = 0; c < 4; ++c) { dA[c] = fmaf(wd[2][c], Dp[c], dA[c]); gw[2][c] = fmaf(Ac[c], Dp[c], gw[2][c]); }
           }
           if (HAS_ADD) {
             float ad[4];
