@@ -705,7 +705,17 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
           // wide models: the depthwise output is produced once by a streaming kernel (it is kept for the weight gradients
           // anyway) and the pointwise GEMM reads it as a plain operand
           uint8_t* q8 = (p->fp8 && sizeof(AT) == 2) ? (uint8_t*)(ws + p->q8) : nullptr;
-          rc = launch_dw_fwd<AT>((const AT*)cur, acur, params + sb.wdw, params + sb.bdw, (AT*)(ws + bw.Q[j]), M, T, H, c.kernel, st, q8);
+          rc = -1000;
+          if (sizeof(AT) == 2 && !p->masked && p->wide_dw_bwd) {
+            DwFwdSlabArgs fa;
+            memset(&fa, 0, sizeof(fa));
+            fa.X = (const bf16_t*)cur; fa.act = acur; fa.wdw = params + sb.wdw; fa.bdw = params + sb.bdw;
+            fa.Q = (bf16_t*)(ws + bw.Q[j]); fa.Q8 = q8; fa.M = M; fa.T = T; fa.C = H;
+            rc = launch_dw_fwd_slab(fa, c.kernel, st);
+            if (rc > 0) return rc;
+          }
+          if (rc == -1000)
+            rc = launch_dw_fwd<AT>((const AT*)cur, acur, params + sb.wdw, params + sb.bdw, (AT*)(ws + bw.Q[j]), M, T, H, c.kernel, st, q8);
           if (rc) return rc;
           if (q8) {
             // TN_PREC_FP8: e4m3 x e4m3 -> f32 on the fp8 matrix cores, per-output-channel weight scales in the epilogue

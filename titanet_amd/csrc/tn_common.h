@@ -281,3 +281,52 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
     hipError_t _e = (expr);                         \
     if (_e != hipSuccess) return (int)_e;           \
   } while (0)
+
+// ------------------------------------------------------------------------------------------
+// helpers of the slab kernels of the wide models (dw_bwd_slab, dw_fwd_slab): LDS-DMA, 2 / 4 channels per lane
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) char tn_lds_char;
+__device__ __forceinline__ void tn_dma16(const void* gptr, unsigned lds_addr) {
+  unsigned keep;
+  // hidden from hipcc's waitcnt bookkeeping (cdna_hip_programming.md: M0 written in the statement that reads it)
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gptr), "s"(lds_addr) : "memory");
+}
+template <int FL, int CH>
+__device__ __forceinline__ void act_c(float (&v)[CH], const float (&sc)[CH], const float (&sh)[CH], uint32_t key, uint32_t thr, uint32_t row, int C, int c) {
+  if (FL & 1) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
+  }
+  if (FL & 2) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) v[i] = fmaxf(v[i], 0.f);
+  }
+  if (FL & 4) {
+    const uint32_t e = row * (uint32_t)C + (uint32_t)c;
+    if (CH == 4) tn_drop4(v, e >> 3, (uint32_t)(c >> 2) & 1u, key, thr);
+    else tn_drop2(v, e >> 3, (uint32_t)(c >> 1) & 3u, key, thr);
+  }
+}
+// CH consecutive bf16 channels <-> floats
+template <int CH>
+__device__ __forceinline__ void ld_ch(const bf16_t* p, float (&v)[CH]) {
+  if (CH == 4) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+  } else {
+    const uint32_t r = *reinterpret_cast<const uint32_t*>(p);
+    v[0] = __uint_as_float(r << 16); v[1] = __uint_as_float(r & 0xffff0000u);
+  }
+}
+template <int CH>
+__device__ __forceinline__ void st_ch(bf16_t* p, const float (&v)[CH]) {
+  if (CH == 4) {
+    uint2 o;
+    o.x = f2bf_pk(v[0], v[1]); o.y = f2bf_pk(v[2], v[3]);
+    *reinterpret_cast<uint2*>(p) = o;
+  } else {
+    *reinterpret_cast<uint32_t*>(p) = f2bf_pk(v[0], v[1]);
+  }
+}

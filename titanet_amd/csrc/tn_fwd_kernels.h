@@ -175,6 +175,158 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const AT* __restrict__ X, B
   }
   }
 }
+// ------------------------------------------------------------------------------------------
+// dw_fwd_slab: the same depthwise producer for the wide bf16 models (C % 256 == 0, K = 7 / 11) in the structure of
+// dw_bwd_slab (tn_v2_bwd_kernels.h): one 256-channel slab per workgroup, raw X tiles of 64 + K - 1 rows by LDS-DMA into two
+// LDS buffers, a lane owns 2 channels and half a 16-row strip, the K-row window of ACTIVATED inputs rolls down the strip
+// in registers (a window row is read, unpacked and activated once per strip).  FL = activation flags of X (1 BN, 2 ReLU,
+// 4 dropout).  dw_fwd_kernel above: 169 us per TitaNet-L layer for 314 MB.
+// ------------------------------------------------------------------------------------------
+struct DwFwdSlabArgs {
+  const bf16_t* X; BnAct act;
+  const float* wdw;    // [C][KD]
+  const float* bdw;    // [C]
+  bf16_t* Q;           // [M][C]
+  uint8_t* Q8;         // [M][C] e4m3 copy for the fp8 pointwise GEMM (TN_PREC_FP8; needs 4 channels per lane) or null
+  int M, T, C, ntiles;
+};
+template <int KD, int FL, int CH>
+__global__ __launch_bounds__(512, 2) void dw_fwd_slab_kernel(DwFwdSlabArgs a) {
+  constexpr int PADR = (KD - 1) / 2, ROWS = 64 + KD - 1, WPS = 4 / CH, RS = 8 * WPS;
+  constexpr int TILE_B = ROWS * 512;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* cst = reinterpret_cast<float*>(smem + 2 * TILE_B);      // sc, sh, bias, wd[KD] : [3 + KD][256]
+  const unsigned ring_lds = (unsigned)(uintptr_t)(tn_lds_char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cl = (wave % WPS) * 64 * CH + lane * CH;             // first channel of the lane inside the slab
+  const int strip = wave / WPS;
+  const int nslab = a.C / 256;
+  const int slab = blockIdx.x % nslab, first = blockIdx.x / nslab, stride = gridDim.x / nslab;
+  const int cb = slab * 256;
+  const uint32_t dkey = tn_act_key(a.act), dthr = a.act.drop_thr;
+  if (tid < 256) {
+    float s = 1.f, h = 0.f;
+    if (FL & 1) bn_scale_shift(a.act, a.C, cb + tid, s, h);
+    cst[tid] = s; cst[256 + tid] = h; cst[512 + tid] = a.bdw[cb + tid];
+#pragma unroll
+    for (int k = 0; k < KD; ++k) cst[(3 + k) * 256 + tid] = a.wdw[(size_t)(cb + tid) * KD + k];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // compiler-visible loads done before the first DMA
+  auto dma_tile = [&](int tile, int buf) {
+    const int raw0 = tile * 64 - PADR;
+#pragma unroll
+    for (int i = 0; i < (ROWS / 2 + 7) / 8; ++i) {
+      const int r = 2 * (wave + 8 * i);
+      if (r < ROWS) {
+        int gr = raw0 + r + (lane >> 5);
+        gr = gr < 0 ? 0 : (gr >= a.M ? a.M - 1 : gr);            // rows outside the tensor: any valid row (never used)
+        tn_dma16(a.X + (size_t)gr * a.C + cb + (lane & 31) * 8,
+                 (unsigned)__builtin_amdgcn_readfirstlane((int)(ring_lds + buf * TILE_B + r * 512)));
+      }
+    }
+  };
+  if (first < a.ntiles) dma_tile(first, 0);
+  __syncthreads();
+  float sc[CH], sh[CH], bd[CH], wd[KD][CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    sc[i] = cst[cl + i]; sh[i] = cst[256 + cl + i]; bd[i] = cst[512 + cl + i];
+#pragma unroll
+    for (int k = 0; k < KD; ++k) wd[k][i] = cst[(3 + k) * 256 + cl + i];
+  }
+  int buf = 0;
+  for (int tile = first; tile < a.ntiles; tile += stride, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this tile's DMA (and the previous tile's stores)
+    __builtin_amdgcn_s_barrier();
+    if (tile + stride < a.ntiles) dma_tile(tile + stride, buf ^ 1);
+    const bf16_t* Xs = reinterpret_cast<const bf16_t*>(smem + buf * TILE_B);
+    const int out0 = tile * 64, raw0 = out0 - PADR;
+    const int l0 = strip * RS;
+    const int g_first = raw0 + l0, g_last = g_first + KD + RS - 2;
+    const bool fast = g_first >= 0 && g_last < a.M && (g_first % a.T) + KD + RS - 2 < a.T;   // wave-uniform
+    // one path: the window of activated rows rolls down the strip either way (a row is activated ONCE — with the dropout
+    // hash per tap the boundary strips, 9 % of them at T = 300, cost more than all the others together); strips whose window
+    // leaves the utterance of an output row only add a wave-uniform test per tap
+    {
+      float A[KD][CH];
+      auto place = [&](int j, int slot) {
+        const int gr = g_first + j;
+        if (fast || (gr >= 0 && gr < a.M)) {
+          ld_ch<CH>(Xs + (l0 + j) * 256 + cl, A[slot]);
+          act_c<FL, CH>(A[slot], sc, sh, dkey, dthr, (uint32_t)gr, a.C, cb + cl);
+        } else {
+#pragma unroll
+          for (int i = 0; i < CH; ++i) A[slot][i] = 0.f;
+        }
+      };
+#pragma unroll
+      for (int j = 0; j < KD - 1; ++j) place(j, j % KD);
+#pragma unroll
+      for (int o = 0; o < RS; ++o) {
+        place(o + KD - 1, (o + KD - 1) % KD);
+        const int gr = out0 + l0 + o;
+        float q[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) q[i] = bd[i];
+        if (fast) {
+#pragma unroll
+          for (int k = 0; k < KD; ++k)
+#pragma unroll
+            for (int i = 0; i < CH; ++i) q[i] = fmaf(wd[k][i], A[(o + k) % KD][i], q[i]);
+        } else {
+          const int t = gr % a.T;
+#pragma unroll
+          for (int k = 0; k < KD; ++k) {
+            const int tt = t + k - PADR;
+            if (tt >= 0 && tt < a.T) {
+#pragma unroll
+              for (int i = 0; i < CH; ++i) q[i] = fmaf(wd[k][i], A[(o + k) % KD][i], q[i]);
+            }
+          }
+        }
+        if (fast || gr < a.M) {
+          st_ch<CH>(a.Q + (size_t)gr * a.C + cb + cl, q);
+          if (CH == 4 && a.Q8) *reinterpret_cast<uint32_t*>(a.Q8 + (size_t)gr * a.C + cb + cl) = f2fp8x4(q[0], q[1], q[CH - 2], q[CH - 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+template <int KD, int FL>
+inline int launch_dw_fwd_slab_t(DwFwdSlabArgs a, int grid, hipStream_t st) {
+  const size_t smem = (size_t)2 * (64 + KD - 1) * 512 + (size_t)(3 + KD) * 256 * sizeof(float);
+  auto kern = dw_fwd_slab_kernel<KD, FL, 4>;       // 4 channels per lane (2 measured 140 vs 103 us with dropout: one hash per 8 channels)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -4;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a);
+  return (int)hipGetLastError();
+}
+// -1000: no specialisation (caller runs dw_fwd_kernel)
+inline int launch_dw_fwd_slab(DwFwdSlabArgs a, int KD, hipStream_t st) {
+  if (a.C % 256 != 0 || a.act.rm.len) return -1000;
+  a.ntiles = (a.M + 63) / 64;
+  const int nslab = a.C / 256;
+  int per = 256 / nslab;
+  if (per < 1) per = 1;
+  if (per > a.ntiles) per = a.ntiles;
+  const int grid = per * nslab;
+  const int fl = (a.act.mode != 0 ? 1 : 0) | (a.act.relu ? 2 : 0) | (a.act.drop_thr ? 4 : 0);
+#define TN_DWFS(K)                                                             \
+  case K:                                                                      \
+    switch (fl) {                                                              \
+      case 7: return launch_dw_fwd_slab_t<K, 7>(a, grid, st);                  \
+      case 3: return launch_dw_fwd_slab_t<K, 3>(a, grid, st);                  \
+      case 0: return launch_dw_fwd_slab_t<K, 0>(a, grid, st);                  \
+      default: return -1000;                                                   \
+    }
+  switch (KD) {
+    TN_DWFS(7)
+    TN_DWFS(11)
+    default: return -1000;
+  }
+#undef TN_DWFS
+}
+
 template <typename AT>
 inline int launch_dw_fwd(const AT* X, const BnAct& act, const float* wdw, const float* bdw, AT* Q, int M, int T, int C, int KD,
                          hipStream_t st, uint8_t* Q8 = nullptr) {
