@@ -58,10 +58,13 @@ __device__ __forceinline__ void fill_tile_plain(AT* dst, const AT* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------
-template <typename AT, int WM, int WN, typename Prod, typename Epi>
+// RH = row halves per wave: 1 -> a wave owns a 64 x 64 output tile (2 x 2 MFMA tiles); 2 -> 128 x 64 (rows wm*64 + i*32 of
+// BOTH 128-row halves of a 256-row workgroup tile): 6 fragment reads per 8 MFMAs instead of 4 per 4 — the 64 x 64 wave
+// tile is LDS-read-bound (1 KB of fragments per MFMA), and the epilogues run once per half unchanged
+template <typename AT, int WM, int WN, typename Prod, typename Epi, int RH = 1>
 __global__ __launch_bounds__(WM* WN * 64, ((sizeof(AT) == 2 && Prod::kRaw) ? 2 : (WM * WN >= 8 ? 4 : 3))) void gemm_nt_kernel(GemmShape g, typename Prod::Args pa,
                                                                typename Epi::Args ea) {
-  constexpr int BM = WM * 64, BN = WN * 64, BK = Elem<AT>::BK, BKP = BK + Elem<AT>::PAD, NT = WM * WN * 64;
+  constexpr int BM = WM * 64 * RH, BN = WN * 64, BK = Elem<AT>::BK, BKP = BK + Elem<AT>::PAD, NT = WM * WN * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   AT* As = reinterpret_cast<AT*>(smem);
   AT* Bs = As + BM * BKP;
@@ -74,13 +77,15 @@ __global__ __launch_bounds__(WM* WN * 64, ((sizeof(AT) == 2 && Prod::kRaw) ? 2 :
   Prod prod;
   prod.template init<AT, NT, BK>(pa, g.M, g.K, scratch, tid);   // ends with __syncthreads()
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[RH][2][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int h = 0; h < RH; ++h)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
 
   const AT* W = reinterpret_cast<const AT*>(g.W);
   auto mma_tile = [&]() {
@@ -89,14 +94,17 @@ __global__ __launch_bounds__(WM* WN * 64, ((sizeof(AT) == 2 && Prod::kRaw) ? 2 :
     const int half = lane >> 5;
 #pragma unroll
     for (int ks = 0; ks < BK / Elem<AT>::KM; ++ks) {
-      typename Mma<AT>::Frag a0 = Mma<AT>::load(arow0, ks, half);
-      typename Mma<AT>::Frag a1 = Mma<AT>::load(arow0 + 32 * BKP, ks, half);
       typename Mma<AT>::Frag b0 = Mma<AT>::load(brow0, ks, half);
       typename Mma<AT>::Frag b1 = Mma<AT>::load(brow0 + 32 * BKP, ks, half);
-      acc[0][0] = Mma<AT>::mma(a0, b0, acc[0][0]);
-      acc[0][1] = Mma<AT>::mma(a0, b1, acc[0][1]);
-      acc[1][0] = Mma<AT>::mma(a1, b0, acc[1][0]);
-      acc[1][1] = Mma<AT>::mma(a1, b1, acc[1][1]);
+#pragma unroll
+      for (int h = 0; h < RH; ++h) {
+        typename Mma<AT>::Frag a0 = Mma<AT>::load(arow0 + h * WM * 64 * BKP, ks, half);
+        typename Mma<AT>::Frag a1 = Mma<AT>::load(arow0 + (h * WM * 64 + 32) * BKP, ks, half);
+        acc[h][0][0] = Mma<AT>::mma(a0, b0, acc[h][0][0]);
+        acc[h][0][1] = Mma<AT>::mma(a0, b1, acc[h][0][1]);
+        acc[h][1][0] = Mma<AT>::mma(a1, b0, acc[h][1][0]);
+        acc[h][1][1] = Mma<AT>::mma(a1, b1, acc[h][1][1]);
+      }
     }
   };
   if constexpr (sizeof(AT) == 2 && Prod::kRaw) {
@@ -139,7 +147,11 @@ __global__ __launch_bounds__(WM* WN * 64, ((sizeof(AT) == 2 && Prod::kRaw) ? 2 :
       __syncthreads();
     }
   }
-  Epi::template run<AT, WM, WN>(acc, ea, g, smem, tid, r0, n0);
+#pragma unroll
+  for (int h = 0; h < RH; ++h) {
+    if (h > 0) __syncthreads();                 // the previous half's staging has been stored
+    Epi::template run<AT, WM, WN>(acc[h], ea, g, smem, tid, r0 + h * WM * 64, n0);
+  }
 }
 
 // LDS bytes needed by the main loop (without producer scratch)
@@ -510,7 +522,24 @@ using EpiStoreTanh = EpiStoreT<true>;
 template <typename AT, int WM, int WN, typename Prod, typename Epi>
 inline int launch_gemm(const GemmShape& g, const typename Prod::Args& pa, const typename Epi::Args& ea, int KD,
                        hipStream_t stream) {
-  constexpr int BM = WM * 64, BN = WN * 64;
+  constexpr int BN = WN * 64;
+  if constexpr (sizeof(AT) == 2 && Prod::kRaw && WM * WN == 8) {
+    // big problems (>= 4 tiles per CU): 256-row workgroup tiles, 128 x 64 per wave
+    const long tiles2 = (long)((g.M + 2 * WM * 64 - 1) / (2 * WM * 64)) * ((g.N + BN - 1) / BN);
+    if (tiles2 >= 1024) {
+      constexpr int BM = WM * 64 * 2;
+      size_t main_bytes = (size_t)(BM + BN) * (Elem<AT>::BK + Elem<AT>::PAD) * sizeof(AT) + Prod::scratch_bytes(g.K, KD, BM, Elem<AT>::BK, sizeof(AT));
+      size_t epi_bytes = Epi::template lds_bytes<AT, WM, WN>();
+      size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+      smem = (smem + 15) & ~(size_t)15;
+      auto kern = gemm_nt_kernel<AT, WM, WN, Prod, Epi, 2>;
+      TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN);
+      hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, g, pa, ea);
+      return (int)hipGetLastError();
+    }
+  }
+  constexpr int BM = WM * 64;
   size_t main_bytes = gemm_tile_bytes<AT, WM, WN>() + Prod::scratch_bytes(g.K, KD, BM, Elem<AT>::BK, sizeof(AT));
   size_t epi_bytes = Epi::template lds_bytes<AT, WM, WN>();
   size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
