@@ -557,8 +557,7 @@ __global__ __launch_bounds__(512) void combine_bwd2_kernel(const AT* __restrict_
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6, NW = NT >> 6;
   for (int j = wave; j < Hr; j += NW) {
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += W2[(size_t)c * Hr + j] * p2[c];
+    float s = lane < C ? tn_dot_batched(W2 + (size_t)lane * Hr + j, 64 * Hr, p2 + lane, 64, (C - lane + 63) / 64) : 0.f;
     s = wave_sum(s);
     if (lane == 0) {
       s = (hid[(size_t)b * Hr + j] > 0.f) ? s : 0.f;
@@ -569,8 +568,7 @@ __global__ __launch_bounds__(512) void combine_bwd2_kernel(const AT* __restrict_
   __syncthreads();
   const float invT = 1.f / (float)(act3.rm.len ? max(act3.rm.len[b], 1) : T);   // the SE mean ran over the valid frames
   for (int c = tid; c < C; c += NT) {
-    float s = 0.f;
-    for (int j = 0; j < Hr; ++j) s += W1[(size_t)j * C + c] * p1[j];
+    const float s = tn_dot_batched(W1 + c, C, p1, 1, Hr);
     dmT[c] = s * invT;
   }
   __syncthreads();
@@ -579,22 +577,40 @@ __global__ __launch_bounds__(512) void combine_bwd2_kernel(const AT* __restrict_
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-#pragma unroll 4
-    for (int t = tg; t < T; t += TG) {
-      const uint32_t row = (uint32_t)b * T + t;
-      const size_t o = (size_t)row * C + c0;
-      float d[8], y[8], m[8];
-      load8(dZ + o, d);
-      load8(Y3 + o, y);
-      act8_grad_mask(y, m, sc3 + c0, sh3 + c0, act3, row, C, c0);
+    // the thread's 8 channels are fixed: their constants live in registers (they were 32 scalar LDS reads per row), and 4
+    // rows of both streams are in flight per thread (one workgroup per utterance: one row at a time is a round trip per row)
+    float g8[8], dm8[8], m8[8], r8[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float v = (d[i] * gS[c0 + i] + dmT[c0 + i]) * m[i];
-        d[i] = v;
-        s1[i] += v;
-        s2[i] += v * (y[i] - m3[c0 + i]) * r3[c0 + i];
+    for (int i = 0; i < 8; ++i) { g8[i] = gS[c0 + i]; dm8[i] = dmT[c0 + i]; m8[i] = m3[c0 + i]; r8[i] = r3[c0 + i]; }
+    constexpr int U = 4;
+    for (int t0 = tg; t0 < T; t0 += TG * U) {
+      float d[U][8], y[U][8];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = t0 + u * TG;
+        if (t < T) {
+          const size_t o = ((size_t)b * T + t) * C + c0;
+          load8(dZ + o, d[u]);
+          load8(Y3 + o, y[u]);
+        }
       }
-      store8(dYbn + o, d);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = t0 + u * TG;
+        if (t < T) {
+          const uint32_t row = (uint32_t)b * T + t;
+          float m[8];
+          act8_grad_mask(y[u], m, sc3 + c0, sh3 + c0, act3, row, C, c0);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float v = (d[u][i] * g8[i] + dm8[i]) * m[i];
+            d[u][i] = v;
+            s1[i] += v;
+            s2[i] += v * (y[u][i] - m8[i]) * r8[i];
+          }
+          store8(dYbn + (size_t)row * C + c0, d[u]);
+        }
+      }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {

@@ -282,6 +282,20 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
     if (_e != hipSuccess) return (int)_e;           \
   } while (0)
 
+// sum_{i < n} w[i * ws] * x[i * xs]: the loads of 16 terms are issued together (a plain loop with a run-time trip count is
+// an L2 round trip per term — the SE mat-vecs of the generic tail kernels spent 60-80 us per utterance batch that way)
+__device__ __forceinline__ float tn_dot_batched(const float* __restrict__ w, int ws, const float* x, int xs, int n) {
+  float s = 0.f;
+  for (int i0 = 0; i0 < n; i0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = (i0 + u < n) ? w[(size_t)(i0 + u) * ws] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s = fmaf(v[u], (i0 + u < n) ? x[(i0 + u) * xs] : 0.f, s);
+  }
+  return s;
+}
+
 // ------------------------------------------------------------------------------------------
 // helpers of the slab kernels of the wide models (dw_bwd_slab, dw_fwd_slab): LDS-DMA, 2 / 4 channels per lane
 // ------------------------------------------------------------------------------------------
