@@ -562,63 +562,95 @@ inline int launch_gemm(const GemmShape& g, const typename Prod::Args& pa, const 
 // the tiles are straight 16-byte copies: half the operand bytes of the bf16 GEMM through HBM, L2 and LDS.  Same
 // tiling, fragment layout (8 K-elements per lane) and epilogue as gemm_nt_kernel; the epilogue applies the row scales.
 // ------------------------------------------------------------------------------------------
-template <int WM, int WN, typename Epi>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 4 : 3)) void gemm_fp8_nt_kernel(GemmShape g, const uint8_t* __restrict__ A8,
-                                                                                          typename Epi::Args ea) {
-  constexpr int BM = WM * 64, BN = WN * 64, BK = 128, BKP = BK + 16, NT = WM * WN * 64;
+template <int WM, int WN, typename Epi, int RH = 1>
+__global__ __launch_bounds__(WM* WN * 64, 2) void gemm_fp8_nt_kernel(GemmShape g, const uint8_t* __restrict__ A8, typename Epi::Args ea) {
+  // same loop as the bf16 raw path of gemm_nt_kernel: next K chunk requested before the MFMAs, RH row halves per wave
+  constexpr int BM = WM * 64 * RH, BN = WN * 64, BK = 128, BKP = BK + 16, NT = WM * WN * 64;
+  constexpr int VC = BK / 16, RL = NT / VC, NA = BM / RL, NW = BN / RL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint8_t* As = reinterpret_cast<uint8_t*>(smem);
   uint8_t* Bs = As + BM * BKP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int r0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  f32x16_t acc[2][2];
+  f32x16_t acc[RH][2][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int h = 0; h < RH; ++h)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
   const uint8_t* W8 = reinterpret_cast<const uint8_t*>(g.W);
-  auto fill = [&](uint8_t* dst, const uint8_t* src, int rows, int nrows, int row0, int kc) {
-    constexpr int VC = BK / 16;
-    for (int i = tid; i < rows * VC; i += NT) {
-      const int r = i / VC, v = i % VC, gr = row0 + r, k = kc + v * 16;
-      uint4 x = make_uint4(0, 0, 0, 0);
-      if (gr < nrows && k < g.K) x = *reinterpret_cast<const uint4*>(src + (size_t)gr * g.K + k);
-      *reinterpret_cast<uint4*>(dst + r * BKP + v * 16) = x;
+  const int vc = tid % VC, rl = tid / VC;
+  uint4 areg[NA], wreg[NW];
+  auto load = [&](int kc) {
+    const int k = kc + vc * 16;
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int gr = r0 + rl + q * RL;
+      areg[q] = (gr < g.M && k < g.K) ? *reinterpret_cast<const uint4*>(A8 + (size_t)gr * g.K + k) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const int gn = n0 + rl + q * RL;
+      wreg[q] = (gn < g.N && k < g.K) ? *reinterpret_cast<const uint4*>(W8 + (size_t)gn * g.K + k) : make_uint4(0, 0, 0, 0);
     }
   };
+  load(0);
   for (int kc = 0; kc < g.K; kc += BK) {
-    fill(Bs, W8, BN, g.N, n0, kc);
-    fill(As, A8, BM, g.M, r0, kc);
+#pragma unroll
+    for (int q = 0; q < NA; ++q) *reinterpret_cast<uint4*>(As + (rl + q * RL) * BKP + vc * 16) = areg[q];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) *reinterpret_cast<uint4*>(Bs + (rl + q * RL) * BKP + vc * 16) = wreg[q];
     __syncthreads();
+    if (kc + BK < g.K) load(kc + BK);
     const uint8_t* arow0 = As + (wm * 64 + (lane & 31)) * BKP + (lane >> 5) * 8;
     const uint8_t* brow0 = Bs + (wn * 64 + (lane & 31)) * BKP + (lane >> 5) * 8;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      const long a0 = *reinterpret_cast<const long*>(arow0 + ks * 16);
-      const long a1 = *reinterpret_cast<const long*>(arow0 + 32 * BKP + ks * 16);
       const long b0 = *reinterpret_cast<const long*>(brow0 + ks * 16);
       const long b1 = *reinterpret_cast<const long*>(brow0 + 32 * BKP + ks * 16);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int h = 0; h < RH; ++h) {
+        const long a0 = *reinterpret_cast<const long*>(arow0 + h * WM * 64 * BKP + ks * 16);
+        const long a1 = *reinterpret_cast<const long*>(arow0 + (h * WM * 64 + 32) * BKP + ks * 16);
+        acc[h][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b0, acc[h][0][0], 0, 0, 0);
+        acc[h][0][1] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b1, acc[h][0][1], 0, 0, 0);
+        acc[h][1][0] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b0, acc[h][1][0], 0, 0, 0);
+        acc[h][1][1] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b1, acc[h][1][1], 0, 0, 0);
+      }
     }
     __syncthreads();
   }
-  Epi::template run<bf16_t, WM, WN>(acc, ea, g, smem, tid, r0, n0);
+#pragma unroll
+  for (int h = 0; h < RH; ++h) {
+    if (h > 0) __syncthreads();
+    Epi::template run<bf16_t, WM, WN>(acc[h], ea, g, smem, tid, r0 + h * WM * 64, n0);
+  }
 }
 
 template <typename Epi>
 inline int launch_gemm_fp8(const GemmShape& g, const uint8_t* A8, const typename Epi::Args& ea, hipStream_t stream) {
-  constexpr int WM = 2, WN = 4, BM = WM * 64, BN = WN * 64;
+  constexpr int WM = 2, WN = 4, BN = WN * 64;
   if (g.K % 16) return -2;
-  size_t smem = (size_t)(BM + BN) * (128 + 16);
   const size_t epi = Epi::template lds_bytes<bf16_t, WM, WN>();
+  const long tiles2 = (long)((g.M + 255) / 256) * ((g.N + BN - 1) / BN);
+  if (tiles2 >= 1024) {                // big problems: 256-row workgroup tiles (see gemm_nt_kernel)
+    constexpr int BM = 256;
+    size_t smem = (size_t)(BM + BN) * (128 + 16);
+    if (epi > smem) smem = epi;
+    auto kern = gemm_fp8_nt_kernel<WM, WN, Epi, 2>;
+    TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, g, A8, ea);
+    return (int)hipGetLastError();
+  }
+  constexpr int BM = WM * 64;
+  size_t smem = (size_t)(BM + BN) * (128 + 16);
   if (epi > smem) smem = epi;
-  auto kern = gemm_fp8_nt_kernel<WM, WN, Epi>;
+  auto kern = gemm_fp8_nt_kernel<WM, WN, Epi, 1>;
   if (smem > 64 * 1024) TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN);
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, g, A8, ea);
