@@ -556,7 +556,8 @@ inline int launch_gemm(const GemmShape& g, const typename Prod::Args& pa, const 
 
 
 // ------------------------------------------------------------------------------------------
-// fp8 variant (TN_PREC_FP8): C[M x N] = A8[M x K] * W8[N x K]^T on v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3, f32 accumulate).
+// fp8 variant (TN_PREC_FP8): C[M x N] = A8[M x K] * W8[N x K]^T on v_mfma_scale_f32_32x32x64_f8f6f4 (OCP e4m3 operands, unit
+// block scales, f32 accumulate: twice the rate of the bf16 MFMA).
 // Both operands are plain fp8 matrices in HBM (the depthwise producer of the wide models writes its output in e4m3
 // beside the bf16 copy the weight gradients read; the weights are cast once per step with one scale per output row), so
 // the tiles are straight 16-byte copies: half the operand bytes of the bf16 GEMM through HBM, L2 and LDS.  Same
@@ -606,20 +607,29 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_fp8_nt_kernel(GemmShape g
     for (int q = 0; q < NW; ++q) *reinterpret_cast<uint4*>(Bs + (rl + q * RL) * BKP + vc * 16) = wreg[q];
     __syncthreads();
     if (kc + BK < g.K) load(kc + BK);
-    const uint8_t* arow0 = As + (wm * 64 + (lane & 31)) * BKP + (lane >> 5) * 8;
-    const uint8_t* brow0 = Bs + (wn * 64 + (lane & 31)) * BKP + (lane >> 5) * 8;
+    // v_mfma_scale_f32_32x32x64_f8f6f4 with e4m3 operands and unit block scales (E8M0 127): 64 k per instruction at twice the
+    // rate of the 32x32x16 fp8 MFMA.  A lane feeds 32 bytes of its row; any assignment of k to (lane half, byte) works as long
+    // as both operands use the same one (tools/f8_probe.hip): lane half h takes bytes [32 h, 32 h + 32) of the 64-k block.
+    typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+    auto frag = [&](const uint8_t* ptr) {
+      const uint4 lo = *reinterpret_cast<const uint4*>(ptr), hi = *reinterpret_cast<const uint4*>(ptr + 16);
+      i32x8_t f;
+      f[0] = (int)lo.x; f[1] = (int)lo.y; f[2] = (int)lo.z; f[3] = (int)lo.w; f[4] = (int)hi.x; f[5] = (int)hi.y; f[6] = (int)hi.z; f[7] = (int)hi.w;
+      return f;
+    };
+    const uint8_t* arow0 = As + (wm * 64 + (lane & 31)) * BKP + (lane >> 5) * 32;
+    const uint8_t* brow0 = Bs + (wn * 64 + (lane & 31)) * BKP + (lane >> 5) * 32;
+    constexpr int SC1 = 0x7f7f7f7f;
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const long b0 = *reinterpret_cast<const long*>(brow0 + ks * 16);
-      const long b1 = *reinterpret_cast<const long*>(brow0 + 32 * BKP + ks * 16);
+    for (int ks = 0; ks < BK / 64; ++ks) {
+      const i32x8_t b0 = frag(brow0 + ks * 64), b1 = frag(brow0 + 32 * BKP + ks * 64);
 #pragma unroll
       for (int h = 0; h < RH; ++h) {
-        const long a0 = *reinterpret_cast<const long*>(arow0 + h * WM * 64 * BKP + ks * 16);
-        const long a1 = *reinterpret_cast<const long*>(arow0 + (h * WM * 64 + 32) * BKP + ks * 16);
-        acc[h][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b0, acc[h][0][0], 0, 0, 0);
-        acc[h][0][1] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b1, acc[h][0][1], 0, 0, 0);
-        acc[h][1][0] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b0, acc[h][1][0], 0, 0, 0);
-        acc[h][1][1] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b1, acc[h][1][1], 0, 0, 0);
+        const i32x8_t a0 = frag(arow0 + h * WM * 64 * BKP + ks * 64), a1 = frag(arow0 + (h * WM * 64 + 32) * BKP + ks * 64);
+        acc[h][0][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b0, acc[h][0][0], 0, 0, 0, SC1, 0, SC1);
+        acc[h][0][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b1, acc[h][0][1], 0, 0, 0, SC1, 0, SC1);
+        acc[h][1][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b0, acc[h][1][0], 0, 0, 0, SC1, 0, SC1);
+        acc[h][1][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b1, acc[h][1][1], 0, 0, 0, SC1, 0, SC1);
       }
     }
     __syncthreads();
@@ -634,7 +644,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_fp8_nt_kernel(GemmShape g
 template <typename Epi>
 inline int launch_gemm_fp8(const GemmShape& g, const uint8_t* A8, const typename Epi::Args& ea, hipStream_t stream) {
   constexpr int WM = 2, WN = 4, BN = WN * 64;
-  if (g.K % 16) return -2;
+  if (g.K % 64) return -2;                  // whole 64-k MFMA blocks
   const size_t epi = Epi::template lds_bytes<bf16_t, WM, WN>();
   const long tiles2 = (long)((g.M + 255) / 256) * ((g.N + BN - 1) / BN);
   if (tiles2 >= 1024) {                // big problems: 256-row workgroup tiles (see gemm_nt_kernel)
