@@ -312,11 +312,30 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     const float inv_keep = (training && pd > 0.f) ? 1.f / (1.f - pd) : 1.f;
     const int CV = H / 8, TG = 512 / CV;
     {
-      size_t smem = (size_t)(4 * H + TG * 3 * H) * sizeof(float);
+      size_t smem = (size_t)(7 * H + TG * 3 * H) * sizeof(float);
       auto k1 = combine_bwd1_kernel<AT>;
       if (smem > 64 * 1024) TN_CHECK_HIP(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      hipLaunchKernelGGL(k1, dim3(B), dim3(512), smem, st, (const AT*)(ws + p->dA[cur]), (const AT*)(ws + bw.OUT),
-                         (const AT*)(ws + bw.Y[nsub - 1]), act3, (const AT*)(ws + bw.S), acts, T, H, inv_keep, (AT*)(ws + bw.dZk),
+      uint32_t othr = 0, okey = 0;
+      if (training && pd > 0.f) {
+        othr = (uint32_t)lrintf(pd * 65536.f);
+        okey = tn_layer_key(seed, (uint32_t)(i * (nsub + 1) + nsub));      // the block output's dropout stream (forward: combine)
+      }
+      int rc1 = -1000;
+      float* dgate_out = (float*)(ws + ((v2_bwd && Hr == 16) ? bw.dgate : bw.dpre2));
+      if (sizeof(AT) == 2 && v2_bwd && H == V2_C) {
+        CombineBwd1V2Args c1;
+        memset(&c1, 0, sizeof(c1));
+        c1.dOUT = (const bf16_t*)(ws + p->dA[cur]); c1.gate = (const float*)(ws + bw.g); c1.Y3 = (const bf16_t*)(ws + bw.Y[nsub - 1]);
+        c1.act3 = act3; c1.S = (const bf16_t*)(ws + bw.S); c1.actS = acts; c1.dZ = (bf16_t*)(ws + bw.dZk); c1.dgate = dgate_out;
+        c1.bsumsS = bsum(mb.bnskip); c1.T = T; c1.parts = 1; c1.inv_keep = inv_keep; c1.drop_thr = othr; c1.drop_key = okey;
+        c1.key_add = (const uint32_t*)(ws + p->step_state) + 2;
+        rc1 = launch_combine_bwd1_v2(c1, B, st);
+        if (rc1 > 0) return rc1;
+      }
+      if (rc1 == -1000)
+      hipLaunchKernelGGL(k1, dim3(B), dim3(512), smem, st, (const AT*)(ws + p->dA[cur]), (const float*)(ws + bw.g),
+                         (const AT*)(ws + bw.Y[nsub - 1]), act3, (const AT*)(ws + bw.S), acts, T, H, inv_keep, othr, okey,
+                         (const uint32_t*)(ws + p->step_state) + 2, (AT*)(ws + bw.dZk),
                          (float*)(ws + ((v2_bwd && Hr == 16) ? bw.dgate : bw.dpre2)), bsum(mb.bnskip));
       int rc2 = -1000;
       if (v2_bwd && Hr == 16) {

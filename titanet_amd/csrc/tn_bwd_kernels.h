@@ -457,50 +457,87 @@ inline int launch_wgrad(int M, int CA, int CB, const typename ProdP::Args& pa, c
 //                                                OUT > 0 <=> kept AND pre-activation > 0)
 //   dgate[b][c] = sum_t dZ * A3                 (A3 = act3(Y3), the SE input)
 //   skip-BN backward sums: sum dZ, sum dZ * shat
+// The mask is RECOMPUTED from what this pass reads anyway (Y3 and S, + the SE gate and the dropout hash of the block
+// output) instead of reading the block output back: one tensor pass less per mega block.
 // ------------------------------------------------------------------------------------------
 template <typename AT>
-__global__ __launch_bounds__(512) void combine_bwd1_kernel(const AT* __restrict__ dOUT, const AT* __restrict__ OUT,
+__global__ __launch_bounds__(512) void combine_bwd1_kernel(const AT* __restrict__ dOUT, const float* __restrict__ gate,
                                                            const AT* __restrict__ Y3, BnAct act3,
                                                            const AT* __restrict__ S, BnAct actS, int T, int C,
-                                                           float inv_keep, AT* __restrict__ dZ, float* __restrict__ dgate,
+                                                           float inv_keep, uint32_t drop_thr, uint32_t drop_key, const uint32_t* key_add,
+                                                           AT* __restrict__ dZ, float* __restrict__ dgate,
                                                            float* __restrict__ bsumsS) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sc3 = reinterpret_cast<float*>(smem);
   float* sh3 = sc3 + C;
   float* mS = sh3 + C;
   float* rS = mS + C;
-  float* part = rS + C;   // [TG][3][C]
+  float* scS = rS + C;
+  float* shS = scS + C;
+  float* gS = shS + C;
+  float* part = gS + C;   // [TG][3][C]
   const int tid = threadIdx.x, NT = blockDim.x, b = blockIdx.x;
   const int CV = C / 8, TG = NT / CV;
   for (int c = tid; c < C; c += NT) {
     bn_scale_shift(act3, C, c, sc3[c], sh3[c]);
     bn_mean_rstd(actS, C, c, mS[c], rS[c]);
+    bn_scale_shift(actS, C, c, scS[c], shS[c]);
+    gS[c] = gate[(size_t)b * C + c];
   }
   __syncthreads();
+  const uint32_t okey = key_add ? drop_key + *key_add : drop_key;
   const int vc = tid % CV, tg = tid / CV, c0 = vc * 8;
   if (tg < TG) {
     float dg[8], s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { dg[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
-#pragma unroll 4
-    for (int t = tg; t < T; t += TG) {
-      const uint32_t row = (uint32_t)b * T + t;
-      const size_t o = (size_t)row * C + c0;
-      float d[8], u[8], y[8], s[8];
-      load8(dOUT + o, d);
-      load8(OUT + o, u);
-      load8(Y3 + o, y);
-      load8(S + o, s);
-      act8(y, sc3 + c0, sh3 + c0, act3, row, C, c0);
+    // the thread's 8 channels are fixed: their constants in registers (40 scalar LDS reads per row otherwise)
+    float kS[8], hS[8], g8[8], m8[8], r8[8], k3[8], h3[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float z = (u[i] > 0.f) ? d[i] * inv_keep : 0.f;
-        d[i] = z;
-        dg[i] += z * y[i];
-        s1[i] += z;
-        s2[i] += z * (s[i] - mS[c0 + i]) * rS[c0 + i];
+    for (int i = 0; i < 8; ++i) {
+      kS[i] = scS[c0 + i]; hS[i] = shS[c0 + i]; g8[i] = gS[c0 + i]; m8[i] = mS[c0 + i]; r8[i] = rS[c0 + i];
+      k3[i] = sc3[c0 + i]; h3[i] = sh3[c0 + i];
+    }
+    constexpr int U = 2;
+    for (int t0 = tg; t0 < T; t0 += TG * U) {
+      float d[U][8], y[U][8], sv[U][8];
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        const int t = t0 + q * TG;
+        if (t < T) {
+          const size_t o = ((size_t)b * T + t) * C + c0;
+          load8(dOUT + o, d[q]);
+          load8(Y3 + o, y[q]);
+          load8(S + o, sv[q]);
+        }
       }
-      store8(dZ + o, d);
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        const int t = t0 + q * TG;
+        if (t < T) {
+          const uint32_t row = (uint32_t)b * T + t;
+          float u[8];
+          act8(y[q], k3, h3, act3, row, C, c0);
+          // u = 1 where the block output was positive: pre-activation > 0 (the forward's expression, up to its positive
+          // 1/(1-p) factor), the element survived the block's dropout, and the row is a valid frame
+#pragma unroll
+          for (int i = 0; i < 8; ++i) u[i] = (sv[q][i] * kS[i] + hS[i] + g8[i] * y[q][i] > 0.f) ? 1.f : 0.f;
+          if (drop_thr) tn_drop8(u, (row * (uint32_t)C + (uint32_t)c0) >> 3, okey, drop_thr);
+          if (act3.rm.len && !tn_row_valid(act3.rm, row)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) u[i] = 0.f;
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float z = (u[i] > 0.f) ? d[q][i] * inv_keep : 0.f;
+            d[q][i] = z;
+            dg[i] += z * y[q][i];
+            s1[i] += z;
+            s2[i] += z * (sv[q][i] - m8[i]) * r8[i];
+          }
+          store8(dZ + (size_t)row * C + c0, d[q]);
+        }
+      }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {

@@ -815,6 +815,115 @@ inline int launch_dw_bwd_v4(DwBwdV3Args a, int max_wgs, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
+// combine_bwd1_v2: pass 1 of the mega-block tail backward (combine_bwd1_kernel, tn_bwd_kernels.h) for hidden = 256, bf16:
+//   dZ = dOUT * [block output > 0] / (1 - p);  dgate[b][c] = sum_t dZ * act3(Y3);  skip-BN backward sums.
+// The mask is recomputed from Y3, S, the SE gate and the block output's dropout hash (the block output is not read back).
+// `parts` workgroups per utterance, a thread owns 8 fixed channels (constants in registers), 3 x 4 rows in flight.
+// ------------------------------------------------------------------------------------------
+struct CombineBwd1V2Args {
+  const bf16_t* dOUT; const float* gate;
+  const bf16_t* Y3; BnAct act3;
+  const bf16_t* S; BnAct actS;
+  bf16_t* dZ;
+  float* dgate;        // [B][256] (atomic accumulate when parts > 1: pre-zeroed by the caller then)
+  float* bsumsS;
+  int T, parts;
+  float inv_keep; uint32_t drop_thr, drop_key; const uint32_t* key_add;
+};
+template <int FL3, bool DROP>
+__global__ __launch_bounds__(512) void combine_bwd1_v2_kernel(CombineBwd1V2Args a) {
+  __shared__ float cst[6 * V2_C];        // sc3, sh3, scS, shS, meanS, rstdS
+  __shared__ float part[16][3][V2_C];
+  const int tid = threadIdx.x, vc = tid & 31, tg = tid >> 5, c0 = vc * 8;
+  const int b = blockIdx.x / a.parts, prt = blockIdx.x % a.parts;
+  const int per = (a.T + a.parts - 1) / a.parts;
+  const int t0 = prt * per, t1 = min(a.T, t0 + per);
+  if (tid < V2_C) {
+    float s = 1.f, h = 0.f, ss, hs, ms, rs;
+    if (FL3 & 1) bn_scale_shift(a.act3, V2_C, tid, s, h);
+    bn_scale_shift(a.actS, V2_C, tid, ss, hs);
+    bn_mean_rstd(a.actS, V2_C, tid, ms, rs);
+    cst[tid] = s; cst[V2_C + tid] = h; cst[2 * V2_C + tid] = ss; cst[3 * V2_C + tid] = hs; cst[4 * V2_C + tid] = ms; cst[5 * V2_C + tid] = rs;
+  }
+  __syncthreads();
+  float k3[8], h3[8], kS[8], hS[8], m8[8], r8[8], g8[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    k3[i] = cst[c0 + i]; h3[i] = cst[V2_C + c0 + i]; kS[i] = cst[2 * V2_C + c0 + i]; hS[i] = cst[3 * V2_C + c0 + i];
+    m8[i] = cst[4 * V2_C + c0 + i]; r8[i] = cst[5 * V2_C + c0 + i]; g8[i] = a.gate[(size_t)b * V2_C + c0 + i];
+  }
+  const uint32_t dkey3 = tn_act_key(a.act3), dthr3 = a.act3.drop_thr;
+  const uint32_t okey = a.key_add ? a.drop_key + *a.key_add : a.drop_key;
+  float dg[8], s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { dg[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
+  constexpr int U = 4;
+  for (int tb = t0 + tg; tb < t1; tb += 16 * U) {
+    uint4 rd[U], ry[U], rs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = tb + 16 * u;
+      if (t < t1) {
+        const size_t o = ((size_t)b * a.T + t) * V2_C + c0;
+        rd[u] = *reinterpret_cast<const uint4*>(a.dOUT + o);
+        ry[u] = *reinterpret_cast<const uint4*>(a.Y3 + o);
+        rs[u] = *reinterpret_cast<const uint4*>(a.S + o);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = tb + 16 * u;
+      if (t < t1) {
+        const uint32_t row = (uint32_t)b * a.T + t;
+        float d[8], y[8], sv[8], m[8];
+        unpack8(rd[u], d);
+        unpack8(ry[u], y);
+        unpack8(rs[u], sv);
+        act8_t<FL3>(y, k3, h3, dkey3, dthr3, row, c0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m[i] = (fmaf(sv[i], kS[i], fmaf(g8[i], y[i], hS[i])) > 0.f) ? a.inv_keep : 0.f;
+        if (DROP) tn_drop8(m, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, okey, a.drop_thr);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float z = d[i] * m[i];
+          d[i] = z;
+          dg[i] = fmaf(z, y[i], dg[i]);
+          s1[i] += z;
+          s2[i] = fmaf(z, (sv[i] - m8[i]) * r8[i], s2[i]);
+        }
+        store8(a.dZ + (size_t)row * V2_C + c0, d);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { part[tg][0][c0 + i] = dg[i]; part[tg][1][c0 + i] = s1[i]; part[tg][2][c0 + i] = s2[i]; }
+  __syncthreads();
+  const int rep = blockIdx.x % TN_NREP;
+  for (int i = tid; i < 3 * V2_C; i += 512) {
+    const int which = i / V2_C, c = i % V2_C;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += part[k][which][c];
+    if (which == 0) {
+      if (a.parts > 1) atomic_add_f32(&a.dgate[(size_t)b * V2_C + c], v);
+      else a.dgate[(size_t)b * V2_C + c] = v;
+    } else {
+      atomic_add_f32(&a.bsumsS[(size_t)(rep * 2 + which - 1) * V2_C + c], v);
+    }
+  }
+}
+// -1000: no specialisation for this flag combination
+inline int launch_combine_bwd1_v2(const CombineBwd1V2Args& a, int B, hipStream_t st) {
+  const int fl3 = (a.act3.mode != 0 ? 1 : 0) | (a.act3.relu ? 2 : 0) | (a.act3.drop_thr ? 4 : 0);
+  if (a.act3.rm.len) return -1000;
+  const dim3 grid(B * a.parts), blk(512);
+  if (fl3 == 7 && a.drop_thr) hipLaunchKernelGGL((combine_bwd1_v2_kernel<7, true>), grid, blk, 0, st, a);
+  else if (fl3 == 3 && !a.drop_thr) hipLaunchKernelGGL((combine_bwd1_v2_kernel<3, false>), grid, blk, 0, st, a);
+  else return -1000;
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // combine_bwd2_v2: mega-block tail backward, pass 2, for hidden = 256 / bf16 / Hr = 16: SE backward (tiny
 // mat-vecs, reference src/modules.py:182-189), then  dA3 = dZ * g + dmean / T ;  dY3bn = dA3 * d act3 / d bn
 // -> stored + BN3 backward sums.  `parts` workgroups per utterance (each repeats the tiny SE backward and streams
