@@ -62,3 +62,51 @@ def test_eval_forward_sizes():
             e = m(x.cuda())
             o = O.titanet_forward(sd, x.double(), oracle_cfg(case), training=False)
         assert rel_err(e.cpu().numpy(), o.normalized.numpy()) < 5e-5, size
+
+
+@pytest.mark.parametrize("size", ["m", "l"])
+def test_wide_slab_kernels_agree_with_generic_depthwise_path(size):
+    """dw_fwd_slab / dw_bwd_slab (LDS-DMA tiles, rolling register windows; the default for the wide bf16 models) against the
+    generic depthwise kernels (TN_WIDE_DW_BWD=0 at plan creation) on the same bf16 step, at a shape with interior strips
+    (T = 300) and utterance boundaries inside tiles, dropout on: outputs and every depthwise / pointwise gradient tensor."""
+    import os
+    case = _case(size, 1, 5, 300, 31)
+    x, y = case_inputs(case, torch.float32)
+    res = {}
+    for flag in ("0", "1"):
+        os.environ["TN_WIDE_DW_BWD"] = flag
+        try:
+            m = build(case, "ce", precision="bf16", dropout=0.1).train()
+            m._seed_base, m._step = 2024, 0
+            emb, preds, lv = m(x.cuda(), speakers=y.cuda())
+            lv.backward()
+            torch.cuda.synchronize()
+            res[flag] = (emb.detach().cpu().numpy(), {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters()})
+        finally:
+            os.environ.pop("TN_WIDE_DW_BWD", None)
+        del m
+    # reference: the float64 oracle with the same dropout masks
+    from tests.util import mask_fn_for
+    sd = case_state_dict(case, "ce", torch.float64)
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running_" not in k:
+            v.requires_grad_(True)
+    xo, yo = case_inputs(case, torch.float64)
+    out = O.titanet_forward(sd, xo, oracle_cfg(case, dropout=0.1), training=True, speakers=yo, loss="ce", mask_fn=mask_fn_for(2024, 0.1))
+    out.loss.backward()
+    e_emb = rel_err(res["1"][0], res["0"][0])
+    keys = [k for k in res["0"][1] if (".conv_block.0.conv." in k or "skip_connection.0" in k) and not k.endswith("conv.0.bias")]
+    # (the depthwise bias feeds a pointwise conv + BatchNorm: its true gradient is zero, both paths return rounding noise)
+    a1 = np.concatenate([res["1"][1][k].ravel() for k in keys]); a0 = np.concatenate([res["0"][1][k].ravel() for k in keys])
+    cos01 = float(a1 @ a0 / (np.linalg.norm(a1) * np.linalg.norm(a0)))
+    rows = []
+    for k in keys:
+        ref = sd[k].grad.numpy()
+        rows.append((k, rel_err(res["1"][1][k], ref), rel_err(res["0"][1][k], ref)))
+    worst = sorted(rows, key=lambda r: -r[1])[:3]
+    print(size, "emb rel (slab vs generic)", e_emb, "gradient cosine slab vs generic", cos01, "worst vs oracle (slab, generic)", worst)
+    assert e_emb < 3e-2, e_emb                                  # same bf16 storage, different summation order
+    assert cos01 > 0.98, cos01
+    # per tensor against the oracle: the slab path is no further from it than the generic path (bf16 noise level, DESIGN.md 4)
+    for k, e1, e0 in rows:
+        assert e1 < max(0.35, 1.5 * e0), (k, e1, e0)
