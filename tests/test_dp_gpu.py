@@ -6,7 +6,6 @@ one global batch with the overlapped bucketed all-reduce, and
   (iii) gradient grouping (the per-bucket weight-gradient launches behind the overlap) does not change the gradient.
 """
 import os
-import socket
 
 import pytest
 import torch
@@ -33,11 +32,10 @@ def _shard(rank, per=24, T=151):
     return x[rank * per:(rank + 1) * per].cuda(), y[rank * per:(rank + 1) * per].cuda()
 
 
-def _worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+def _worker(rank, world, init_file, q):
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # file rendezvous: no TCP-store port to lose between "pick a free port" and "bind it"
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     try:
         from titanet_amd.trainer import Trainer
         tr = Trainer(_model(seed=11 + rank), lr=1e-3, n_buckets=3)          # different inits: rank 0's weights must win
@@ -68,15 +66,15 @@ def _worker(rank, world, port, q):
         torch.cuda.synchronize()
         same = bool(torch.equal(others[0], others[1]))
         q.put((rank, err, same, losses, bool(torch.isfinite(flat).all())))
+        dist.barrier()                  # nobody tears its connections down while the peer is still in a collective
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_model_step_same_device():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+def test_two_rank_model_step_same_device(tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, str(tmp_path / "rendezvous"), q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
