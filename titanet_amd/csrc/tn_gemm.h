@@ -75,6 +75,25 @@ __global__ __launch_bounds__(WM* WN * 64, ((sizeof(AT) == 2 && Prod::kRaw) ? 2 :
   const int r0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
   Prod prod;
+  constexpr bool RAW = sizeof(AT) == 2 && Prod::kRaw;
+  // raw path: the first K chunk is requested BEFORE the producer's init (BatchNorm coefficients: 16 - 32 dependent-latency
+  // loads per channel, once per workgroup — 20 % of a K = 512 workgroup's life when it ran first)
+  constexpr int RVC = BK / 8, RRL = NT / RVC, RNW = BN / RRL;
+  uint4 wreg[RAW ? RNW : 1];
+  typename Prod::template Regs<RAW ? BM / RRL : 1> areg;
+  const AT* W = reinterpret_cast<const AT*>(g.W);
+  auto load_w = [&](int kc) {
+    const int k = kc + (tid % RVC) * 8, rl = tid / RVC;
+#pragma unroll
+    for (int q = 0; q < (RAW ? RNW : 1); ++q) {
+      const int gn = n0 + rl + q * RRL;
+      wreg[q] = (gn < g.N && k < g.K) ? *reinterpret_cast<const uint4*>(W + (size_t)gn * g.K + k) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  if constexpr (RAW) {
+    load_w(0);
+    prod.template load_raw<BM, NT, BK>(areg, pa, g.M, g.K, tid, r0, 0);
+  }
   prod.template init<AT, NT, BK>(pa, g.M, g.K, scratch, tid);   // ends with __syncthreads()
 
   f32x16_t acc[RH][2][2];
@@ -87,7 +106,6 @@ __global__ __launch_bounds__(WM* WN * 64, ((sizeof(AT) == 2 && Prod::kRaw) ? 2 :
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
 
-  const AT* W = reinterpret_cast<const AT*>(g.W);
   auto mma_tile = [&]() {
     const AT* arow0 = As + (wm * 64 + (lane & 31)) * BKP;
     const AT* brow0 = Bs + (wn * 64 + (lane & 31)) * BKP;
@@ -112,20 +130,8 @@ __global__ __launch_bounds__(WM* WN * 64, ((sizeof(AT) == 2 && Prod::kRaw) ? 2 :
     // before this chunk's MFMAs and turned into LDS tiles after them (the weight tile is a straight copy) — the synchronous
     // loop below spent as many VALU cycles on bf16 -> f32 -> bf16 round trips and exposed loads as on the MFMAs
     // (TitaNet-L pointwise GEMMs: 354 / 435 us for 161 GFLOP)
-    constexpr int VC = BK / 8, RL = NT / VC, NW = BN / RL;
+    constexpr int VC = RVC, RL = RRL, NW = RNW;
     const int vc = tid % VC, rl = tid / VC;
-    uint4 wreg[NW];
-    typename Prod::template Regs<BM / RL> areg;
-    auto load_w = [&](int kc) {
-      const int k = kc + vc * 8;
-#pragma unroll
-      for (int q = 0; q < NW; ++q) {
-        const int gn = n0 + rl + q * RL;
-        wreg[q] = (gn < g.N && k < g.K) ? *reinterpret_cast<const uint4*>(W + (size_t)gn * g.K + k) : make_uint4(0, 0, 0, 0);
-      }
-    };
-    load_w(0);
-    prod.template load_raw<BM, NT, BK>(areg, pa, g.M, g.K, tid, r0, 0);
     for (int kc = 0; kc < g.K; kc += BK) {
 #pragma unroll
       for (int q = 0; q < NW; ++q) *reinterpret_cast<uint4*>(Bs + (rl + q * RL) * BKP + vc * 8) = wreg[q];
@@ -248,6 +254,7 @@ struct ProdPlain {
 // — the depthwise conv of reference src/modules.py:65-75 fused as the prologue of its pointwise GEMM.
 struct ProdDw {
   static constexpr bool kRaw = false;
+  template <int N> struct Regs {};
   struct Args {
     const void* X;
     int ldx;
@@ -338,6 +345,7 @@ struct ProdDw {
 // TitaNet.forward (reference src/models.py:318-331, prolog conv :370).  K = n_mels * KP.
 struct ProdIm2col {
   static constexpr bool kRaw = false;
+  template <int N> struct Regs {};
   struct Args {
     const float* x;   // [B][n_mels][T] float32, T contiguous (reference layout)
     int n_mels, KP, T;
@@ -382,6 +390,7 @@ struct ProdIm2col {
 // utterance's valid length are already zero in X0.  C must be a multiple of 8.
 struct ProdTaps {
   static constexpr bool kRaw = false;
+  template <int N> struct Regs {};
   struct Args {
     const void* X0;   // [M][C]
     int C, KP, T;
