@@ -64,8 +64,8 @@ struct ProdDy {
     for (int c = tid; c < K; c += NT) bn_bwd_coefs(a.bn, K, c, k0[c], k1[c], k2[c]);
     __syncthreads();
   }
-  // bf16 pipelined loop of gemm_nt_kernel (tn_gemm.h)
-  static constexpr bool kRaw = true;
+  // bf16 pipelined loop of gemm_nt_kernel (tn_gemm.h); two input streams: 128 x 512 workgroup tiles for wide outputs
+  static constexpr bool kRaw = true, kWideCols = true;
   template <int N> struct Regs { uint4 z[N]; uint4 y[N]; };
   template <int ROWS, int NT, int CW, int N>
   __device__ __forceinline__ void load_raw(Regs<N>& rg, const Args& a, int M, int K, int tid, int r0, int kc) {

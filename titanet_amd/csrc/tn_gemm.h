@@ -61,18 +61,23 @@ __device__ __forceinline__ void fill_tile_plain(AT* dst, const AT* __restrict__ 
 // RH = row halves per wave: 1 -> a wave owns a 64 x 64 output tile (2 x 2 MFMA tiles); 2 -> 128 x 64 (rows wm*64 + i*32 of
 // BOTH 128-row halves of a 256-row workgroup tile): 6 fragment reads per 8 MFMAs instead of 4 per 4 — the 64 x 64 wave
 // tile is LDS-read-bound (1 KB of fragments per MFMA), and the epilogues run once per half unchanged
-template <typename AT, int WM, int WN, typename Prod, typename Epi, int RH = 1>
+// CC = column halves per wave (with RH = 1): a wave owns 64 x 128 of a 128-row x 512-column workgroup tile — the A rows are
+// then read once per 512 output columns instead of once per 256 (the pointwise GEMMs of the wide models re-read their
+// row operand N / 256 times: at N = 1024 that re-read, not the MFMA rate, bounded them)
+template <typename AT, int WM, int WN, typename Prod, typename Epi, int RH = 1, int CC = 1>
 __global__ __launch_bounds__(WM* WN * 64, ((sizeof(AT) == 2 && Prod::kRaw) ? 2 : (WM * WN >= 8 ? 4 : 3))) void gemm_nt_kernel(GemmShape g, typename Prod::Args pa,
                                                                typename Epi::Args ea) {
-  constexpr int BM = WM * 64 * RH, BN = WN * 64, BK = Elem<AT>::BK, BKP = BK + Elem<AT>::PAD, NT = WM * WN * 64;
+  constexpr int BM = WM * 64 * RH, BN = WN * 64 * CC, BK = Elem<AT>::BK, BKP = BK + Elem<AT>::PAD, NT = WM * WN * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   AT* As = reinterpret_cast<AT*>(smem);
   AT* Bs = As + BM * BKP;
-  char* scratch = reinterpret_cast<char*>(Bs + BN * BKP);
+  char* scratch = reinterpret_cast<char*>(As + (RH == 2 ? 2 : 1) * (BM + BN) * BKP);   // RH == 2: two tile buffers
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int r0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // RH == 2 (big problems): column tiles are the FAST grid index, so the workgroups that re-read the same A rows (one per
+  // 256-column tile of the output) run at the same time and find them in L2 / Infinity Cache
+  const int r0 = (RH == 2 ? blockIdx.y : blockIdx.x) * BM, n0 = (RH == 2 ? blockIdx.x : blockIdx.y) * BN;
 
   Prod prod;
   constexpr bool RAW = sizeof(AT) == 2 && Prod::kRaw;
@@ -96,9 +101,11 @@ __global__ __launch_bounds__(WM* WN * 64, ((sizeof(AT) == 2 && Prod::kRaw) ? 2 :
   }
   prod.template init<AT, NT, BK>(pa, g.M, g.K, scratch, tid);   // ends with __syncthreads()
 
-  f32x16_t acc[RH][2][2];
+  static_assert(RH == 1 || CC == 1, "one of the two");
+  constexpr int NH = RH * CC;              // 64 x 64 sub-tiles per wave
+  f32x16_t acc[NH][2][2];
 #pragma unroll
-  for (int h = 0; h < RH; ++h)
+  for (int h = 0; h < NH; ++h)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -112,16 +119,30 @@ __global__ __launch_bounds__(WM* WN * 64, ((sizeof(AT) == 2 && Prod::kRaw) ? 2 :
     const int half = lane >> 5;
 #pragma unroll
     for (int ks = 0; ks < BK / Elem<AT>::KM; ++ks) {
-      typename Mma<AT>::Frag b0 = Mma<AT>::load(brow0, ks, half);
-      typename Mma<AT>::Frag b1 = Mma<AT>::load(brow0 + 32 * BKP, ks, half);
+      if constexpr (CC == 2) {
+        typename Mma<AT>::Frag a0 = Mma<AT>::load(arow0, ks, half);
+        typename Mma<AT>::Frag a1 = Mma<AT>::load(arow0 + 32 * BKP, ks, half);
 #pragma unroll
-      for (int h = 0; h < RH; ++h) {
-        typename Mma<AT>::Frag a0 = Mma<AT>::load(arow0 + h * WM * 64 * BKP, ks, half);
-        typename Mma<AT>::Frag a1 = Mma<AT>::load(arow0 + (h * WM * 64 + 32) * BKP, ks, half);
-        acc[h][0][0] = Mma<AT>::mma(a0, b0, acc[h][0][0]);
-        acc[h][0][1] = Mma<AT>::mma(a0, b1, acc[h][0][1]);
-        acc[h][1][0] = Mma<AT>::mma(a1, b0, acc[h][1][0]);
-        acc[h][1][1] = Mma<AT>::mma(a1, b1, acc[h][1][1]);
+        for (int c = 0; c < CC; ++c) {
+          typename Mma<AT>::Frag b0 = Mma<AT>::load(brow0 + c * WN * 64 * BKP, ks, half);
+          typename Mma<AT>::Frag b1 = Mma<AT>::load(brow0 + (c * WN * 64 + 32) * BKP, ks, half);
+          acc[c][0][0] = Mma<AT>::mma(a0, b0, acc[c][0][0]);
+          acc[c][0][1] = Mma<AT>::mma(a0, b1, acc[c][0][1]);
+          acc[c][1][0] = Mma<AT>::mma(a1, b0, acc[c][1][0]);
+          acc[c][1][1] = Mma<AT>::mma(a1, b1, acc[c][1][1]);
+        }
+      } else {
+        typename Mma<AT>::Frag b0 = Mma<AT>::load(brow0, ks, half);
+        typename Mma<AT>::Frag b1 = Mma<AT>::load(brow0 + 32 * BKP, ks, half);
+#pragma unroll
+        for (int h = 0; h < RH; ++h) {
+          typename Mma<AT>::Frag a0 = Mma<AT>::load(arow0 + h * WM * 64 * BKP, ks, half);
+          typename Mma<AT>::Frag a1 = Mma<AT>::load(arow0 + (h * WM * 64 + 32) * BKP, ks, half);
+          acc[h][0][0] = Mma<AT>::mma(a0, b0, acc[h][0][0]);
+          acc[h][0][1] = Mma<AT>::mma(a0, b1, acc[h][0][1]);
+          acc[h][1][0] = Mma<AT>::mma(a1, b0, acc[h][1][0]);
+          acc[h][1][1] = Mma<AT>::mma(a1, b1, acc[h][1][1]);
+        }
       }
     }
   };
@@ -132,6 +153,54 @@ __global__ __launch_bounds__(WM* WN * 64, ((sizeof(AT) == 2 && Prod::kRaw) ? 2 :
     // (TitaNet-L pointwise GEMMs: 354 / 435 us for 161 GFLOP)
     constexpr int VC = RVC, RL = RRL, NW = RNW;
     const int vc = tid % VC, rl = tid / VC;
+    if constexpr (RH == 2) {
+      // big problems: TWO LDS tile buffers, one barrier per K chunk — chunk k + 1 is written into the other buffer while
+      // other waves still multiply chunk k (the launcher sizes the LDS for it)
+      constexpr int TILE = (BM + BN) * BKP;                  // elements of one (A, W) tile pair
+      auto commit = [&](int buf, int kc) {
+        AT* Ab = As + buf * TILE;
+        AT* Bb = Ab + BM * BKP;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) *reinterpret_cast<uint4*>(Bb + (rl + q * RL) * BKP + vc * 8) = wreg[q];
+        prod.template commit_raw<BM, NT, BK, BKP>(reinterpret_cast<bf16_t*>(Ab), areg, pa, g.M, g.K, tid, r0, kc);
+      };
+      commit(0, 0);
+      if (BK < g.K) {
+        load_w(BK);
+        prod.template load_raw<BM, NT, BK>(areg, pa, g.M, g.K, tid, r0, BK);
+      }
+      __syncthreads();
+      int buf = 0;
+      for (int kc = 0; kc < g.K; kc += BK, buf ^= 1) {
+        if (kc + BK < g.K) {
+          commit(buf ^ 1, kc + BK);                          // the other buffer was last read before the previous barrier
+          if (kc + 2 * BK < g.K) {
+            load_w(kc + 2 * BK);
+            prod.template load_raw<BM, NT, BK>(areg, pa, g.M, g.K, tid, r0, kc + 2 * BK);
+          }
+        }
+        {
+          const AT* arow0 = As + buf * TILE + (wm * 64 + (lane & 31)) * BKP;
+          const AT* brow0 = As + buf * TILE + BM * BKP + (wn * 64 + (lane & 31)) * BKP;
+          const int half = lane >> 5;
+#pragma unroll
+          for (int ks = 0; ks < BK / Elem<AT>::KM; ++ks) {
+            typename Mma<AT>::Frag b0 = Mma<AT>::load(brow0, ks, half);
+            typename Mma<AT>::Frag b1 = Mma<AT>::load(brow0 + 32 * BKP, ks, half);
+#pragma unroll
+            for (int h = 0; h < RH; ++h) {
+              typename Mma<AT>::Frag a0 = Mma<AT>::load(arow0 + h * WM * 64 * BKP, ks, half);
+              typename Mma<AT>::Frag a1 = Mma<AT>::load(arow0 + (h * WM * 64 + 32) * BKP, ks, half);
+              acc[h][0][0] = Mma<AT>::mma(a0, b0, acc[h][0][0]);
+              acc[h][0][1] = Mma<AT>::mma(a0, b1, acc[h][0][1]);
+              acc[h][1][0] = Mma<AT>::mma(a1, b0, acc[h][1][0]);
+              acc[h][1][1] = Mma<AT>::mma(a1, b1, acc[h][1][1]);
+            }
+          }
+        }
+        __syncthreads();
+      }
+    } else
     for (int kc = 0; kc < g.K; kc += BK) {
 #pragma unroll
       for (int q = 0; q < NW; ++q) *reinterpret_cast<uint4*>(Bs + (rl + q * RL) * BKP + vc * 8) = wreg[q];
@@ -154,9 +223,9 @@ __global__ __launch_bounds__(WM* WN * 64, ((sizeof(AT) == 2 && Prod::kRaw) ? 2 :
     }
   }
 #pragma unroll
-  for (int h = 0; h < RH; ++h) {
+  for (int h = 0; h < NH; ++h) {
     if (h > 0) __syncthreads();                 // the previous half's staging has been stored
-    Epi::template run<AT, WM, WN>(acc[h], ea, g, smem, tid, r0 + h * WM * 64, n0);
+    Epi::template run<AT, WM, WN>(acc[h], ea, g, smem, tid, r0 + (RH == 2 ? h : 0) * WM * 64, n0 + (CC == 2 ? h : 0) * WN * 64);
   }
 }
 
@@ -191,7 +260,7 @@ struct ProdPlain {
     __syncthreads();
   }
   // bf16 pipelined loop of gemm_nt_kernel: raw vectors of a K chunk (requested early), then tile rows (after the MFMAs)
-  static constexpr bool kRaw = true;
+  static constexpr bool kRaw = true, kWideCols = false;
   template <int N> struct Regs { uint4 x[N]; };
   template <int ROWS, int NT, int CW, int N>
   __device__ __forceinline__ void load_raw(Regs<N>& rg, const Args& a, int M, int K, int tid, int r0, int kc) {
@@ -253,7 +322,7 @@ struct ProdPlain {
 // P_DW: A[r][c] = b_dw[c] + sum_j w_dw[c][j] * act(X)[r + j - pad][c]   (zero outside the utterance)
 // — the depthwise conv of reference src/modules.py:65-75 fused as the prologue of its pointwise GEMM.
 struct ProdDw {
-  static constexpr bool kRaw = false;
+  static constexpr bool kRaw = false, kWideCols = false;
   template <int N> struct Regs {};
   struct Args {
     const void* X;
@@ -344,7 +413,7 @@ struct ProdDw {
 // P_IM2COL (prolog): A[r][ci*KP + j] = x[b][ci][t + j - pad]; x is the float [B, n_mels, T] input of
 // TitaNet.forward (reference src/models.py:318-331, prolog conv :370).  K = n_mels * KP.
 struct ProdIm2col {
-  static constexpr bool kRaw = false;
+  static constexpr bool kRaw = false, kWideCols = false;
   template <int N> struct Regs {};
   struct Args {
     const float* x;   // [B][n_mels][T] float32, T contiguous (reference layout)
@@ -389,7 +458,7 @@ struct ProdIm2col {
 // (the weight is used in the matching [out][tap][ci] order).  Taps outside the utterance read as zero; frames beyond an
 // utterance's valid length are already zero in X0.  C must be a multiple of 8.
 struct ProdTaps {
-  static constexpr bool kRaw = false;
+  static constexpr bool kRaw = false, kWideCols = false;
   template <int N> struct Regs {};
   struct Args {
     const void* X0;   // [M][C]
@@ -535,15 +604,32 @@ inline int launch_gemm(const GemmShape& g, const typename Prod::Args& pa, const 
   if constexpr (sizeof(AT) == 2 && Prod::kRaw && WM * WN == 8) {
     // big problems (>= 4 tiles per CU): 256-row workgroup tiles, 128 x 64 per wave
     const long tiles2 = (long)((g.M + 2 * WM * 64 - 1) / (2 * WM * 64)) * ((g.N + BN - 1) / BN);
-    if (tiles2 >= 1024) {
-      constexpr int BM = WM * 64 * 2;
-      size_t main_bytes = (size_t)(BM + BN) * (Elem<AT>::BK + Elem<AT>::PAD) * sizeof(AT) + Prod::scratch_bytes(g.K, KD, BM, Elem<AT>::BK, sizeof(AT));
+    // wide outputs: 128 x 512 workgroup tiles (64 x 128 per wave), the row operand read once per 512 columns
+    // (measured per producer: with two input streams — BatchNorm backward on load — the saved re-read wins, 343 -> 289 us at
+    //  N = K = 1024; the single-stream producer is better off with the double-buffered 256 x 256 tile below, 241 vs 261 us)
+    if (Prod::kWideCols && g.N >= 512 && (long)((g.M + WM * 64 - 1) / (WM * 64)) * ((g.N + 2 * BN - 1) / (2 * BN)) >= 512) {
+      constexpr int BM = WM * 64, BNC = 2 * BN;
+      size_t main_bytes = (size_t)(BM + BNC) * (Elem<AT>::BK + Elem<AT>::PAD) * sizeof(AT) + Prod::scratch_bytes(g.K, KD, BM, Elem<AT>::BK, sizeof(AT));
+      size_t epi_bytes = Epi::template lds_bytes<AT, WM, WN>();
+      size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+      smem = (smem + 15) & ~(size_t)15;
+      auto kern = gemm_nt_kernel<AT, WM, WN, Prod, Epi, 1, 2>;
+      TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      dim3 grid((g.M + BM - 1) / BM, (g.N + BNC - 1) / BNC);
+      hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, g, pa, ea);
+      return (int)hipGetLastError();
+    }
+    constexpr int BM2 = WM * 64 * 2;
+    const size_t main2 = (size_t)2 * (BM2 + BN) * (Elem<AT>::BK + Elem<AT>::PAD) * sizeof(AT) + Prod::scratch_bytes(g.K, KD, BM2, Elem<AT>::BK, sizeof(AT));
+    if (tiles2 >= 1024 && main2 <= 160 * 1024) {          // two tile buffers + the producer's constants must fit the LDS
+      constexpr int BM = BM2;
+      size_t main_bytes = main2;
       size_t epi_bytes = Epi::template lds_bytes<AT, WM, WN>();
       size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
       smem = (smem + 15) & ~(size_t)15;
       auto kern = gemm_nt_kernel<AT, WM, WN, Prod, Epi, 2>;
       TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN);
+      dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);          // x = column tile (see the kernel)
       hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, g, pa, ea);
       return (int)hipGetLastError();
     }
