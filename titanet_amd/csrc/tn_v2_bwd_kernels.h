@@ -130,11 +130,17 @@ __device__ __forceinline__ void wg2_chunks(const WgradV2Desc& d, const WgSeg& sg
     for (int q = 0; q < 3; ++q) {
       const int i = rq + 16 * q, gr = r0 - PADR + i;
       if (i < WG2_RK + KD - 1) {
-        float v[8];
-        unpack8(px[q], v);
-        if (interior || (gr >= 0 && gr < M)) wg2_act8<FL>(v, cst + 3 * V2_C + c0, cst + 4 * V2_C + c0, d.actX, (uint32_t)gr, c0);
-        if (DW) store8(Xa + i * V2_C + c0, v);
-        else if (i >= PADR && i < PADR + WG2_RK) store8(Qt + (i - PADR) * WG2_PITCH + c0, v);   // plain 1x1: Q row r = input row r
+        if (!DW && FL == 0) {
+          // stored operand used as it is (the kept depthwise outputs, an activated block input): a straight 16-byte copy
+          // (rows outside the tensor were loaded as zeros)
+          if (i >= PADR && i < PADR + WG2_RK) *reinterpret_cast<uint4*>(Qt + (i - PADR) * WG2_PITCH + c0) = px[q];
+        } else {
+          float v[8];
+          unpack8(px[q], v);
+          if (interior || (gr >= 0 && gr < M)) wg2_act8<FL>(v, cst + 3 * V2_C + c0, cst + 4 * V2_C + c0, d.actX, (uint32_t)gr, c0);
+          if (DW) store8(Xa + i * V2_C + c0, v);
+          else if (i >= PADR && i < PADR + WG2_RK) store8(Qt + (i - PADR) * WG2_PITCH + c0, v);   // plain 1x1: Q row r = input row r
+        }
       }
       if (ch + 1 < nchunks) load_x(chunk0 + ch + 1, q);
       __builtin_amdgcn_sched_barrier(0);
