@@ -286,7 +286,10 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       }
     }
     int rc;
-    if (sizeof(AT) == 2 && (use_v2 & 16) && H == 256 && D % 256 == 0) {
+    // the pipelined generic GEMM (BatchNorm backward on load, 128 x 256 tiles) does this K = 1536 product in 183 us; the
+    // weights-in-registers dgrad_wide_v2 re-streams its weight slab per 64 rows and takes 207 us (+ its swizzle): TN_DGRAD_WIDE=1
+    static const bool dgrad_wide_on = getenv("TN_DGRAD_WIDE") && atoi(getenv("TN_DGRAD_WIDE")) == 1;
+    if (sizeof(AT) == 2 && (use_v2 & 16) && H == 256 && D % 256 == 0 && dgrad_wide_on) {
       DgradWideArgs da;
       memset(&da, 0, sizeof(da));
       da.dZ = (const bf16_t*)(ws + p->dEbn); da.Y = (const bf16_t*)(ws + p->E); da.bn = pa.bn;
