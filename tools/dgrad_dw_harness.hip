@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
     for (int it = 0; it < 40; ++it) go(it);
     hipEventRecord(e1, 0); CK(hipEventSynchronize(e1));
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("%s<7>: %.2f us per launch (%.2f TB/s over 4 passes)\n", which ? "dgrad_dw_v7" : "dgrad_dw_v6", ms * 1e3f / 40, 4.0 * M * C * 2 / (ms * 1e-3 / 40) / 1e12);
+    printf("%s<7>: %.2f us per launch (%.2f TB/s over 4 passes)\n", "dgrad_dw_v6", ms * 1e3f / 40, 4.0 * M * C * 2 / (ms * 1e-3 / 40) / 1e12);
   }
   // checksum of the two outputs on the same inputs
   a.dZ = dZ[0]; a.Y = Y[0]; a.X = X[0]; a.OUT = OUT[0]; launch_dgrad_dw_v6(a, 256, 0);
@@ -47,6 +47,6 @@ int main(int argc, char** argv) {
   std::vector<unsigned short> o0((size_t)M * C), o1((size_t)M * C);
   CK(hipMemcpy(o0.data(), OUT[0], o0.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(o1.data(), OUT[1], o1.size() * 2, hipMemcpyDeviceToHost));
   size_t diff = 0; for (size_t i = 0; i < o0.size(); ++i) diff += o0[i] != o1[i];
-  printf("v6 vs v7 outputs: %zu of %zu elements differ\n", diff, o0.size());
+  printf("two launches on the same inputs: %zu of %zu elements differ\n", diff, o0.size());
   return 0;
 }
