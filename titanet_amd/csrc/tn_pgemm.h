@@ -1,0 +1,274 @@
+// titanet_amd — pipelined MFMA GEMMs for the wide models (hidden 512 / 1024: the pointwise 1x1 convs of reference
+// src/modules.py:60-80 are MFMA-bound there) and for every other product whose operands are STORED bf16
+// matrices.
+//
+//   pgemm_nt_kernel   C[M x N] = A[M x K] * W[N x K]^T          (forward / data-gradient form: both operands K-contiguous)
+//
+// Design (MI355X_MICROARCH.md / cdna_hip_programming.md 5): 256 x 256 output tile per 512-thread workgroup, 8 waves as
+// 2 (M) x 4 (N), 128 x 64 per wave = 4 x 2 v_mfma_f32_32x32x16_bf16 tiles (128 accumulator registers).  Operand tiles go
+// HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring of K-step stages
+// (4 x 32 KB, K = 32 each); the DMA instructions of a later K step are issued BETWEEN the MFMAs of the current one (their
+// issue cost hides under the matrix pipe) and waited for with a counted vmcnt.  LDS images are lane-linear (a DMA
+// instruction writes base + lane * 16), so the bank swizzle is applied to the per-lane SOURCE address and undone by the
+// fragment reads: image [256 rows][4 chunks of 16 B], chunk ^= (row >> 2) & 3 (conflict-free ds_read_b128 fragments).
+// (Measured alternatives: 2 stages of K = 64 with one barrier per step, fragments read behind the barrier: 0.73 PFLOP/s on
+// 76800 x 1024 x 1024 against 0.84 for 4 x K = 32 in the same loop shape.)
+// Workgroups are PERSISTENT (one per CU): the K steps of all tiles of a workgroup form one stream, so the first operand
+// tiles of tile t + 1 are in flight while tile t runs its epilogue, and the tile order keeps the column tiles of one row
+// tile on one XCD (they share the A rows through that XCD's L2).
+// Epilogue without LDS and without barriers: the DMA places weight row 2 i + j of a wave's 64 output channels at LDS row
+// 32 j + i, so lane i of the two MFMA column blocks owns the ADJACENT channels 2 i, 2 i + 1 of its rows: bias, BatchNorm
+// statistics (lane-local sums, one shuffle, replicated global atomics) and a packed 4-byte store per row — a wave
+// instruction writes two full 128-byte lines.
+// EVERY vector-memory instruction of the kernel is issued from inline asm: hipcc's waitcnt insertion does not see them, so
+// nothing drains the DMA ring behind our back (a compiler-visible load anywhere in the loop made it put s_waitcnt vmcnt(0)
+// in front of the fragment reads and of every output row), and the vmcnt queue is counted by hand: it retires in order, so
+// the output stores of a tile (buffer stores: rows >= M are dropped by the descriptor's bounds check, 64 per wave whatever
+// the tile) drain under the next tile's K steps while the waits name "at most 63 outstanding".
+#pragma once
+#include "tn_gemm.h"
+
+typedef __attribute__((ext_vector_type(4))) int pg_i32x4_t;
+
+// XCD-contiguous order of the persistent workgroups: block b runs on XCD b % 8 (observed; used for speed only)
+__device__ __forceinline__ int pg_virtual_id(int b, int G) { return (G % 8 == 0) ? (b % 8) * (G / 8) + b / 8 : b; }
+
+template <int N>
+__device__ __forceinline__ void pg_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void pg_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// hidden vector-memory operations (see the header comment)
+__device__ __forceinline__ void pg_store_dword(uint32_t v, unsigned voff, pg_i32x4_t srd, unsigned soff) {
+  asm volatile("buffer_store_dword %0, %1, %2, %3 offen" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void pg_atomic_add(float* p, float v) { asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ pg_i32x4_t pg_make_srd(const void* base, unsigned bytes) {
+  const uint64_t b = (uint64_t)base;
+  pg_i32x4_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xffffu));      // stride 0: raw buffer
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+
+struct PGemmNtArgs {
+  const bf16_t* A;   // [M][lda], K contiguous, used as stored
+  int lda;
+};
+struct PGemmEpiArgs {
+  bf16_t* Y;               // [M][ldy]
+  int ldy;
+  const float* bias;       // [N] or null
+  float* stats;            // [TN_NREP][2][N] column sums / sums of squares of y over the rows < M, or null
+  const float* colscale;   // [N] or null: y = acc * colscale[n] + bias[n]
+};
+
+// DBG (tuning only): 1 no MFMA, 2 no DMA after the prologue, 4 linear DMA source (wrong results), 8 no output stores
+//
+// Loop of one workgroup: K steps of 32 in a ring of 4 stages, ONE barrier per K step; behind it the fragments of the first
+// k-step are read, then per k-step: fragment reads of the next one, one A and one B DMA instruction of the K step three
+// ahead, 8 MFMAs.  Measured on 76800 x 1024 x 1024 (uniform random operands: the matrix pipe alone, fed from registers,
+// sustains 1.65 - 1.9 PFLOP/s on such data and 2.4 on zeros — the chip clocks to its power budget —, tools/mfma_peak.hip):
+//   this loop 0.84 PFLOP/s (191 us; the generic gemm_nt_kernel 0.58 - 0.60); without DMA and stores 1.27, without MFMA
+//   and stores the L2 -> LDS stream alone takes 129 us (1.26 GB at 9.8 TB/s: 256 x 256 tiles at K = 1024 cannot be fed
+//   faster), the output stores cost 20 - 40 us (they queue in front of the next tile's DMA);
+//   2 stages of K = 64: 0.73;  fragments prefetched across the barrier + mid-step barrier: 0.75;  the two wave groups one
+//   phase apart ("ping-pong", a barrier per 8 MFMAs): 0.76 - 0.79, with s_setprio around the MFMAs 0.75.
+template <int DBG = 0>
+__global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtArgs pa, PGemmEpiArgs ea, int tiles_n, int total_tiles) {
+  constexpr int BK = 32, NSTAGE = 4;
+  constexpr int ROWB = BK * 2;               // bytes of a tile row
+  constexpr int CPR = ROWB / 16;             // 16-byte chunks per row
+  constexpr int RPI = 64 / CPR;              // rows per DMA instruction (1 KiB)
+  constexpr int NQ = 256 / (8 * RPI);        // DMA instructions per wave, operand and stage
+  constexpr int TILE_B = 256 * ROWB, STAGE_B = 2 * TILE_B;
+  constexpr int GRP = 2 * NQ;                // DMA instructions per wave and K step
+  constexpr int SWS = 2, SWM = CPR - 1;      // swizzle: chunk ^= (row >> SWS) & SWM
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(tn_lds_char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int G = gridDim.x, v = pg_virtual_id(blockIdx.x, G);
+  const int KT = g.K / BK;
+  const bf16_t* W = reinterpret_cast<const bf16_t*>(g.W);
+
+  // ---- DMA side: instruction q of this wave fills LDS rows (q*8 + wave) * RPI + lane / CPR of both tiles
+  const int dsub = lane / CPR;
+  unsigned offA[NQ], offB[NQ];
+  auto dma_setup = [&](int tile) {
+    const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int p = (q * 8 + wave) * RPI + dsub;                    // LDS row of the tile
+      const int chunk = (DBG & 4) ? (lane % CPR) : ((lane % CPR) ^ ((p >> SWS) & SWM));
+      int ra = mt * 256 + p;
+      int rb = nt * 256 + (p & ~63) + 2 * (p & 31) + ((p >> 5) & 1);    // weight rows: 2 i + j at LDS row 32 j + i
+      ra = ra < g.M ? ra : g.M - 1;            // rows outside the matrix: any valid row (their outputs are never stored)
+      rb = rb < g.N ? rb : g.N - 1;
+      offA[q] = (unsigned)ra * (unsigned)pa.lda + chunk * 8;
+      offB[q] = (unsigned)rb * (unsigned)g.K + chunk * 8;
+    }
+  };
+  auto dma_a = [&](int q, int kt, int stage) {
+    tn_dma16(pa.A + (size_t)offA[q] + kt * BK, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + (q * 8 + wave) * 1024)));
+  };
+  auto dma_b = [&](int q, int kt, int stage) {
+    tn_dma16(W + (size_t)offB[q] + kt * BK, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + TILE_B + (q * 8 + wave) * 1024)));
+  };
+  // ---- MFMA side: fragment byte offsets inside a tile (row i of a 32-row block, k-step ks)
+  const int fi = lane & 31, fh = lane >> 5;
+  int foff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) foff[ks] = fi * ROWB + ((((ks << 1) + fh) ^ ((fi >> SWS) & SWM)) << 4);
+  const int abase = wm * 64 * ROWB, bbase = TILE_B + wn * 64 * ROWB;
+
+  f32x16_t acc[2][2][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
+  };
+  zero_acc();
+
+  // ---- epilogue constants
+  const pg_i32x4_t ysrd = pg_make_srd(ea.Y, (unsigned)((size_t)g.M * ea.ldy * 2));      // stores beyond row M - 1 are dropped
+  const unsigned yvoff = (unsigned)(4 * fh * ea.ldy + 2 * fi) * 2;                        // this lane inside a (32-row, 64-column) block
+  const unsigned row_b = (unsigned)ea.ldy * 2;
+  // bias / column scales of all N columns sit in LDS behind the ring (the only compiler-visible loads of the kernel:
+  // complete before the first DMA)
+  float* cbias = reinterpret_cast<float*>(smem + NSTAGE * STAGE_B);
+  for (int i = tid; i < g.N; i += 512) {
+    cbias[i] = ea.bias ? ea.bias[i] : 0.f;
+    cbias[g.N + i] = ea.colscale ? ea.colscale[i] : 1.f;
+  }
+  __syncthreads();
+
+  int itile = v, ikt = 0;       // next K step to request
+  int ctile = v, ckt = 0;       // K step being multiplied
+  int cstage = 0, istage = 0;
+  int fresh = 3;                // K steps since this wave's last epilogue stores were issued (they sit in the vmcnt queue)
+  // the stream never stops requesting: past the last real K step it re-requests step 0 of the last tile into stages nobody
+  // reads any more (every wait below then has the same count, and no branch splits the MFMA stream)
+  auto advance_issue = [&]() {
+    if (itile < total_tiles && ++ikt == KT) { ikt = 0; itile += G; if (itile < total_tiles) dma_setup(itile); }
+    istage = (istage + 1) & (NSTAGE - 1);
+  };
+  dma_setup(itile < total_tiles ? itile : total_tiles - 1);
+#pragma unroll 1
+  for (int d = 0; d < 3; ++d) {                     // steps 0, 1, 2 in flight
+    const int kt = itile < total_tiles ? ikt : 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { dma_a(q, kt, istage); dma_b(q, kt, istage); }
+    advance_issue();
+  }
+  pg_wait<2 * GRP>();               // step 0 has landed (steps 1 and 2 stay in flight)
+  pg_barrier();
+  while (ctile < total_tiles) {
+    const int kt_req = itile < total_tiles ? ikt : 0;
+    {
+      const char* st = smem + cstage * STAGE_B;
+      bf16x8_t af[2][4], bf[2][2];
+      auto read_frags = [&](int ks, int buf) {
+        const char* ap = st + abase + foff[ks];
+        const char* bp = st + bbase + foff[ks];
+        bf[buf][0] = *reinterpret_cast<const bf16x8_t*>(bp);
+        bf[buf][1] = *reinterpret_cast<const bf16x8_t*>(bp + 32 * ROWB);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[buf][i] = *reinterpret_cast<const bf16x8_t*>(ap + ((i >> 1) * 128 + (i & 1) * 32) * ROWB);
+      };
+      read_frags(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (ks == 0) read_frags(1, 1);
+        if (!(DBG & 2)) { dma_a(ks, kt_req, istage); dma_b(ks, kt_req, istage); }     // of the K step three ahead
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (DBG & 1) {
+            asm volatile("" ::"v"(af[ks][i]), "v"(bf[ks][0]), "v"(bf[ks][1]));
+          } else {
+            acc[i >> 1][i & 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bf[ks][0], acc[i >> 1][i & 1][0], 0, 0, 0);
+            acc[i >> 1][i & 1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bf[ks][1], acc[i >> 1][i & 1][1], 0, 0, 0);
+          }
+        }
+      }
+    }
+    advance_issue();
+    cstage = (cstage + 1) & (NSTAGE - 1);
+    if (++ckt == KT) {
+      // ---- epilogue of this tile, straight from the accumulators
+      const int mt_ = ctile / tiles_n, nt_ = ctile - mt_ * tiles_n;
+      const int ncol = nt_ * 256 + wn * 64 + 2 * fi;               // this lane's channel pair
+      const bool cols_ok = nt_ * 256 + wn * 64 < g.N;                 // wave-uniform (N is a multiple of 64)
+      const bool full_rows = mt_ * 256 + 256 <= g.M;
+      float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+      if (cols_ok) {
+        const f32x2_t bv = *reinterpret_cast<const f32x2_t*>(cbias + ncol), cv = *reinterpret_cast<const f32x2_t*>(cbias + g.N + ncol);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            const int rblk = mt_ * 256 + h * 128 + wm * 64 + mt * 32;     // first row of the 32-row block
+            const unsigned sbase = (unsigned)rblk * row_b + (unsigned)(nt_ * 256 + wn * 64) * 2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int rr = (r & 3) + 8 * (r >> 2);
+              float y0 = fmaf(acc[h][mt][0][r], cv[0], bv[0]), y1 = fmaf(acc[h][mt][1][r], cv[1], bv[1]);
+              if (!(DBG & 8)) pg_store_dword(f2bf_pk(y0, y1), yvoff + (sbase + (unsigned)rr * row_b), ysrd, 0u);   // (the bounds check covers the VGPR offset only)
+              if (!full_rows) {
+                const bool ok = rblk + rr + 4 * fh < g.M;
+                y0 = ok ? y0 : 0.f; y1 = ok ? y1 : 0.f;
+              }
+              s0 += y0; q0 = fmaf(y0, y0, q0);
+              s1 += y1; q1 = fmaf(y1, y1, q1);
+            }
+          }
+        if (ea.stats) {
+          s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64);
+          q0 += __shfl_xor(q0, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+          float* sp = ea.stats + (size_t)((blockIdx.x % TN_NREP) * 2 + fh) * g.N + ncol;     // lower half: sums, upper: squares
+          pg_atomic_add(sp, fh ? q0 : s0);
+          pg_atomic_add(sp + 1, fh ? q1 : s1);
+        }
+      }
+      zero_acc();
+      ckt = 0;
+      ctile += G;
+      fresh = (cols_ok && !(DBG & 8)) ? 0 : 3;
+    }
+    // this wave's part of the next stage has landed.  The vmcnt queue retires in order: the two groups requested after it
+    // may stay in flight, and so may this tile's 64 output stores (+ statistics atomics) while they are YOUNGER than the
+    // group waited for: "at most 63 outstanding" then retires the DMA groups that precede them
+    if (fresh < 3) pg_wait<63>();
+    else pg_wait<2 * GRP>();
+    ++fresh;
+    pg_barrier();           // ... everybody's part; and the stage refilled next is no longer read by anyone
+  }
+  pg_wait<0>();
+}
+
+template <int DBG = 0>
+inline int launch_pgemm_nt_t(const GemmShape& g, const PGemmNtArgs& pa, const PGemmEpiArgs& ea, hipStream_t st, int max_wgs) {
+  if (g.K % 32 || g.K <= 0 || pa.lda % 8 || g.N % 64 || g.N > 3072 || ea.ldy % 2 || g.M <= 0) return TN_E_UNSUPPORTED;
+  if ((long)g.M * pa.lda >= (1L << 32) || (long)g.N * g.K >= (1L << 32) || (long)g.M * ea.ldy * 2 >= (1L << 32)) return TN_E_UNSUPPORTED;
+  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256, total = tiles_m * tiles_n;
+  int grid = total < max_wgs ? total : max_wgs;
+  if (grid >= 8) grid &= ~7;
+  const size_t smem = (size_t)131072 + (size_t)2 * g.N * sizeof(float);
+  auto kern = pgemm_nt_kernel<DBG>;
+  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g, pa, ea, tiles_n, total);
+  return (int)hipGetLastError();
+}
+inline int launch_pgemm_nt(const GemmShape& g, const PGemmNtArgs& pa, const PGemmEpiArgs& ea, hipStream_t st, int max_wgs = 256) {
+  return launch_pgemm_nt_t<0>(g, pa, ea, st, max_wgs);
+}
