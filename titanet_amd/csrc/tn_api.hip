@@ -8,6 +8,7 @@
 #include "tn_fwd_kernels.h"
 #include "tn_gemm.h"
 #include "tn_internal.h"
+#include "tn_pgemm.h"
 #include "tn_v2_kernels.h"
 #include "tn_v2_wide_kernels.h"
 
@@ -610,6 +611,18 @@ int gemm_store(const GemmShape& g, const typename Prod::Args& pa, const EpiStore
   return launch_gemm<AT, 2, 2, Prod, Epi>(g, pa, ea, KD, st);
 }
 
+// plain stored bf16 operand, big problem: the pipelined LDS-DMA GEMM (tn_pgemm.h); -1000 = not applicable
+template <typename AT>
+int gemm_plain_pipe(const tn_plan* p, const GemmShape& g, const void* X, int ldx, const BnAct& act, const EpiStoreArgs& ea, hipStream_t st) {
+  if (sizeof(AT) != 2 || p->masked || ea.rm.len) return -1000;
+  if (act.mode != 0 || act.relu || act.drop_thr || act.rm.len) return -1000;
+  if (g.K % 32 || g.N % 64 || g.N > 3072 || ldx % 8 || ea.ldy % 2) return -1000;
+  if (g.K < 256) return -1000;
+  PGemmNtArgs pa{(const bf16_t*)X, ldx};
+  PGemmEpiArgs pe{(bf16_t*)ea.Y, ea.ldy, ea.bias, ea.stats, ea.colscale};
+  return launch_pgemm_nt(g, pa, pe, st);
+}
+
 template <typename AT>
 const void* wsel(const tn_plan* p, int64_t master_off, const WcRef& r) {
   if (sizeof(AT) == 4) return p->params + master_off;
@@ -680,7 +693,8 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
         GemmShape g{M, H, H, wsel<AT>(p, mb.wskip, bw.wskip)};
         ProdPlain::Args pa{xin, H, actx};
         EpiStoreArgs ea{ws + bw.S, H, params + mb.bskip, statp(mb.bnskip), rm};
-        rc = gemm_store<AT, ProdPlain>(g, pa, ea, 0, st);
+        rc = (H >= 512) ? gemm_plain_pipe<AT>(p, g, xin, H, actx, ea, st) : -1000;
+        if (rc == -1000) rc = gemm_store<AT, ProdPlain>(g, pa, ea, 0, st);
       }
       if (rc) return rc;
     }
@@ -725,7 +739,8 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
             rc = launch_gemm_fp8<EpiStore>(g8, q8, e8, st);
           } else {
             ProdPlain::Args pq{ws + bw.Q[j], H, identity_act()};
-            rc = gemm_store<AT, ProdPlain>(g, pq, ea, 0, st);
+            rc = gemm_plain_pipe<AT>(p, g, ws + bw.Q[j], H, identity_act(), ea, st);
+            if (rc == -1000) rc = gemm_store<AT, ProdPlain>(g, pq, ea, 0, st);
           }
         } else {
           rc = gemm_store<AT, ProdDw>(g, pa, ea, c.kernel, st);
@@ -795,7 +810,8 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       GemmShape g{M, D, H, wsel<AT>(p, m->epi_w, p->wepi)};
       ProdPlain::Args pa{xin, H, actx};
       EpiStoreArgs ea{ws + p->E, D, params + m->epi_b, statp(m->epi_bn), rm};
-      int rc = gemm_store<AT, ProdPlain>(g, pa, ea, 0, st);
+      int rc = (H >= 512) ? gemm_plain_pipe<AT>(p, g, xin, H, actx, ea, st) : -1000;
+      if (rc == -1000) rc = gemm_store<AT, ProdPlain>(g, pa, ea, 0, st);
       if (rc) return rc;
     }
   }
