@@ -6,6 +6,7 @@
 
 #include "tn_bwd_kernels.h"
 #include "tn_internal.h"
+#include "tn_pgemm.h"
 #include "tn_v2_bwd_kernels.h"
 #include "tn_v2_wide_kernels.h"
 
@@ -71,7 +72,30 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   const int use_v2 = p->masked ? 0 : p->use_v2;     // variable-length batches: generic templates (see forward)
   if (p->masked && c.simple_pool) return TN_E_UNSUPPORTED;
   auto identity_rows = [&]() { BnAct a = identity_act(); a.rm = plan_row_mask(p); return a; };
-  const bool batched_wgrad = sizeof(AT) == 2 && ((use_v2 & 4) || (p->wide_wgrad && !p->masked)) && training && p->wg2_layers > 0;
+  // wide models (hidden 512 / 1024, bf16, un-masked, train): every 1x1 conv's backward = one in-place BatchNorm-backward
+  // pass (dS) + the two pipelined LDS-DMA GEMMs of tn_pgemm.h on stored operands (data gradient dS * W, weight gradient
+  // dS^T * Q straight into the gradient buffer), layer by layer
+  const bool pipe = sizeof(AT) == 2 && !use_v2 && p->wide_wgrad && !p->masked && training && H % 256 == 0 && D % 256 == 0;
+  const bool batched_wgrad = sizeof(AT) == 2 && ((use_v2 & 4) || (p->wide_wgrad && !p->masked)) && training && p->wg2_layers > 0 && !pipe;
+  auto pipe_layer = [&](size_t dz, size_t y, const BnRef& bn, int Cout, const WcRef& wc, int Cin, size_t dx_out, const void* q, bool q_plain,
+                        const BnAct& qact, int64_t wgrad_off) -> int {
+    int rc = launch_bn_bwd_apply((bf16_t*)(ws + dz), (const bf16_t*)(ws + y), make_bnbwd(p, bn, M, training), M, Cout, st);
+    if (rc) return rc;
+    GemmShape g{M, Cin, Cout, ws + wc.wt};
+    PGemmNtArgs pa{(const bf16_t*)(ws + dz), Cout};
+    PGemmEpiArgs pe{(bf16_t*)(ws + dx_out), Cin, nullptr, nullptr, nullptr};
+    rc = launch_pgemm_nt(g, pa, pe, st);
+    if (rc) return rc;
+    if (q_plain) {
+      PGemmTnArgs ta{(const bf16_t*)(ws + dz), Cout, Cout, (const bf16_t*)q, Cin, Cin, M, grads + wgrad_off, Cin, 0, 0};
+      ProfScope ps(p, TN_PROF_BWD_WGRAD, st);
+      return launch_pgemm_tn(ta, st);
+    }
+    ProdPlain::Args pp{ws + dz, Cout, identity_act()};
+    ProdPlain::Args qa{q, Cin, qact};
+    return launch_wgrad<AT, ProdPlain, ProdPlain>(M, Cout, Cin, pp, qa, 0, slabs, p->slab_bytes, grads + wgrad_off, st);
+  };
+  auto is_plain = [](const BnAct& a) { return a.mode == 0 && !a.relu && !a.drop_thr && !a.rm.len; };
   const bool v2_bwd = sizeof(AT) == 2 && (use_v2 & 8);
   const int nb = c.n_mega_blocks;
   const int per_blk = nsub + 1;
@@ -276,6 +300,10 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   BnAct act0 = make_act(p, m->prolog_bn, M, training, 1, 0.f, seed, 0);
   BnAct act_last = nb > 0 ? identity_rows() : act0;
   int cur = 0;   // dA[cur] holds the gradient wrt the current block output
+  if (pipe && nb > 0) {
+    int rc = pipe_layer(p->dEbn, p->E, m->epi_bn, D, p->wepi, H, p->dA[cur], x_last, is_plain(act_last), act_last, m->epi_w);
+    if (rc) return rc;
+  } else
   {
     ProdDy::Args pa{ws + p->dEbn, ws + p->E, D, make_bnbwd(p, m->epi_bn, M, training)};
     {
@@ -366,6 +394,10 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       }
     }
     // ---- skip connection: d S = BN-backward(dZ); dXs = dS * W_skip; d W_skip = dS^T X
+    if (pipe) {
+      int rc = pipe_layer(bw.dZk, bw.S, mb.bnskip, H, bw.wskip, H, p->dXs, xin, is_plain(actx), actx, mb.wskip);
+      if (rc) return rc;
+    } else
     {
       ProdDy::Args pa{ws + bw.dZk, ws + bw.S, H, make_bnbwd(p, mb.bnskip, M, training)};
       ProdPlain::Args qa{xin, H, actx};
@@ -393,7 +425,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       const void* sin = j > 0 ? (const void*)(ws + bw.Y[j - 1]) : xin;
       BnAct asin = j > 0 ? make_act(p, mb.sub[j - 1].bn, M, training, 1, pd, seed, i * (nsub + 1) + j - 1) : actx;
       ProdDy::Args pa{ws + bw.dY[j], ws + bw.Y[j], H, make_bnbwd(p, sb.bn, M, training)};
-      if (!batched_wgrad) {
+      if (!batched_wgrad && !pipe) {
         int rc;
         if (p->save_q && training) {
           // the forward kept the depthwise output (the pointwise GEMM's operand): plain operand, no activation / stencil recompute
@@ -460,7 +492,10 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         if (rc) return rc;
         continue;
       }
-      {
+      if (pipe) {
+        int rc = pipe_layer(bw.dY[j], bw.Y[j], sb.bn, H, bw.wpw[j], H, p->dD, ws + bw.Q[j], true, identity_act(), sb.wpw);
+        if (rc) return rc;
+      } else {
         GemmShape g{M, H, H, wt(bw.wpw[j])};
         EpiStoreArgs ea{ws + p->dD, H, nullptr, nullptr};
         int rc;

@@ -1252,3 +1252,30 @@ __global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const float* __restr
                      red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c]);
   }
 }
+
+// ==========================================================================================
+// dS = BatchNorm-backward(dZ, Y) = k0[c] dZ + k1[c] Y + k2[c], written IN PLACE over dZ (bf16): the operand both pipelined
+// GEMMs of a layer's backward read as a stored matrix (data gradient: dS * W, weight gradient: dS^T * Q).  One streaming pass
+// (2 reads + 1 write) instead of the transform inside two GEMM producers.
+// ==========================================================================================
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ dZ, const bf16_t* __restrict__ Y, BnBwd bn, int M, int C) {
+  extern __shared__ __attribute__((aligned(16))) float pg_k[];      // k0, k1, k2 : [3][C]
+  for (int c = threadIdx.x; c < C; c += 256) bn_bwd_coefs(bn, C, c, pg_k[c], pg_k[C + c], pg_k[2 * C + c]);
+  __syncthreads();
+  const int VC = C / 8;
+  const size_t nvec = (size_t)M * VC;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    const int c0 = (int)(i % VC) * 8;
+    float z[8], y[8];
+    load8(dZ + i * 8, z);
+    load8(Y + i * 8, y);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) z[u] = fmaf(pg_k[c0 + u], z[u], fmaf(pg_k[C + c0 + u], y[u], pg_k[2 * C + c0 + u]));
+    store8(dZ + i * 8, z);
+  }
+}
+inline int launch_bn_bwd_apply(bf16_t* dZ, const bf16_t* Y, const BnBwd& bn, int M, int C, hipStream_t st) {
+  if (C % 8 || C > 4096) return TN_E_UNSUPPORTED;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C);
+  return (int)hipGetLastError();
+}

@@ -272,3 +272,154 @@ inline int launch_pgemm_nt_t(const GemmShape& g, const PGemmNtArgs& pa, const PG
 inline int launch_pgemm_nt(const GemmShape& g, const PGemmNtArgs& pa, const PGemmEpiArgs& ea, hipStream_t st, int max_wgs = 256) {
   return launch_pgemm_nt_t<0>(g, pa, ea, st, max_wgs);
 }
+
+// ==========================================================================================
+// pgemm_tn_kernel: weight-gradient form.  OUT[c][k] += sum over rows r of P[r][c] * Q[r][k]   (f32, global atomics)
+//   P [rows][ldp], Q [rows][ldq]: row-major bf16 activations used as stored (the BatchNorm-backward'd gradient dS and the
+//   kept GEMM operand of the layer); the contraction runs over the ROWS, so MFMA fragments are read with the transposing
+//   LDS read (ds_read_b64_tr_b16) from row-major tiles [32 rows][256 channels] (16 KB per operand and K step of 32 rows).
+//   LDS-DMA by BUFFER loads: rows beyond the tensor read as zeros (descriptor bounds check) and add nothing.
+//   Swizzle (source side, undone by the reads): 16-byte chunk ^= (row & 3) << 2 — the 4 rows x 2 segments a transposing
+//   read touches per 32 lanes then cover all 64 banks.
+// One workgroup = one (256 x 256 output slab, row range) unit: units x splits workgroups, the splits of all slabs over the
+// same rows adjacent in the XCD-contiguous order (they share the P / Q slabs through one L2).  Same ring / wait scheme as
+// pgemm_nt_kernel.
+// ==========================================================================================
+typedef __attribute__((ext_vector_type(4))) short pg_s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short pg_s16x8_t;
+__device__ __forceinline__ void pg_dma16_buf(unsigned voff, pg_i32x4_t srd, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ bf16x8_t pg_tr_frag(const char* p) {
+  const pg_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) pg_s16x4_t*)(p));
+  const pg_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) pg_s16x4_t*)(p + 4 * 512));
+  pg_s16x8_t v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+struct PGemmTnArgs {
+  const bf16_t* P; int ldp, np;     // [rows][ldp]; np = channels of P used (multiple of 256): output rows
+  const bf16_t* Q; int ldq, nq;     // [rows][ldq]; nq = channels of Q used (multiple of 256): output columns
+  int rows;
+  float* out; int ldo;              // out[c][k] (+=), c < np, k < nq
+  int splits, steps_per_split;      // row ranges: split s covers K steps [s * steps_per_split, ...)
+};
+
+template <int DUMMY>
+__global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(PGemmTnArgs a) {
+  constexpr int NSTAGE = 4, TILE_B = 16384, STAGE_B = 2 * TILE_B, GRP = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(tn_lds_char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wa = wave >> 2, wb = wave & 3;
+  const int G = gridDim.x, v = pg_virtual_id(blockIdx.x, G);
+  const int tiles_q = a.nq / 256, units = (a.np / 256) * tiles_q;
+  const int unit = v % units, split = v / units;
+  const int tp = unit / tiles_q, tq = unit - tp * tiles_q;
+  const int nsteps_all = (a.rows + 31) / 32;
+  const int s0 = split * a.steps_per_split;
+  int nsteps = nsteps_all - s0;
+  nsteps = nsteps < a.steps_per_split ? nsteps : a.steps_per_split;
+  if (nsteps <= 0) return;                                         // workgroup-uniform
+
+  const pg_i32x4_t psrd = pg_make_srd(a.P, (unsigned)((size_t)a.rows * a.ldp * 2));
+  const pg_i32x4_t qsrd = pg_make_srd(a.Q, (unsigned)((size_t)a.rows * a.ldq * 2));
+  // DMA: instruction q of this wave fills tile rows (q*8 + wave)*2 + (lane >> 5), 16-byte chunk lane & 31 of that row
+  unsigned voffP[2], voffQ[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int r = (q * 8 + wave) * 2 + (lane >> 5);
+    const int chunk = (lane & 31) ^ ((r & 3) << 2);
+    voffP[q] = (unsigned)(((size_t)(s0 * 32 + r) * a.ldp + tp * 256 + chunk * 8) * 2);
+    voffQ[q] = (unsigned)(((size_t)(s0 * 32 + r) * a.ldq + tq * 256 + chunk * 8) * 2);
+  }
+  const unsigned stepP = 32u * (unsigned)a.ldp * 2u, stepQ = 32u * (unsigned)a.ldq * 2u;
+  int istage = 0;
+  auto dma_p = [&](int q) { pg_dma16_buf(voffP[q], psrd, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + istage * STAGE_B + (q * 8 + wave) * 1024))); };
+  auto dma_q = [&](int q) { pg_dma16_buf(voffQ[q], qsrd, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + istage * STAGE_B + TILE_B + (q * 8 + wave) * 1024))); };
+  auto advance_issue = [&]() {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { voffP[q] += stepP; voffQ[q] += stepQ; }      // past the last row: zeros (bounds check)
+    istage = (istage + 1) & (NSTAGE - 1);
+  };
+  // fragments
+  const int i16 = lane & 15, g1 = (lane >> 4) & 1, half = lane >> 5, rw = (i16 >> 2) & 3;
+  const int lbase = half * 4096 + (i16 >> 2) * 512 + (2 * g1 + ((i16 & 3) >> 1)) * 16 + (i16 & 1) * 8;
+  int aoff[4], boff[2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) aoff[mi] = lbase + wa * 256 + ((mi ^ rw) << 6);
+#pragma unroll
+  for (int nj = 0; nj < 2; ++nj) boff[nj] = TILE_B + lbase + (wb >> 1) * 256 + (((((wb & 1) << 1) | nj) ^ rw) << 6);
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll 1
+  for (int d = 0; d < 3; ++d) {
+    dma_p(0); dma_q(0); dma_p(1); dma_q(1);
+    advance_issue();
+  }
+  pg_wait<2 * GRP>();
+  pg_barrier();
+  int cstage = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    const char* st = smem + cstage * STAGE_B;
+    bf16x8_t af[2][4], bf[2][2];
+    auto read_frags = [&](int ks, int buf) {
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) bf[buf][nj] = pg_tr_frag(st + boff[nj] + ks * 8192);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) af[buf][mi] = pg_tr_frag(st + aoff[mi] + ks * 8192);
+    };
+    read_frags(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks == 0) read_frags(1, 1);
+      dma_p(ks); dma_q(ks);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][0], acc[mi][0], 0, 0, 0);
+        acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][1], acc[mi][1], 0, 0, 0);
+      }
+    }
+    advance_issue();
+    cstage = (cstage + 1) & (NSTAGE - 1);
+    pg_wait<2 * GRP>();
+    pg_barrier();
+  }
+  pg_wait<0>();
+  float* out = a.out + (size_t)(tp * 256 + wa * 128) * a.ldo + tq * 256 + wb * 64 + (lane & 31);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        atomic_add_f32(out + (size_t)(mi * 32 + cd_row(r, lane)) * a.ldo + nj * 32, acc[mi][nj][r]);
+}
+
+inline int launch_pgemm_tn(PGemmTnArgs a, hipStream_t st, int max_wgs = 256) {
+  if (a.np % 256 || a.nq % 256 || a.np <= 0 || a.nq <= 0 || a.ldp % 8 || a.ldq % 8 || a.rows <= 0) return TN_E_UNSUPPORTED;
+  if ((long)a.rows * a.ldp * 2 >= (1L << 32) || (long)a.rows * a.ldq * 2 >= (1L << 32)) return TN_E_UNSUPPORTED;
+  const int units = (a.np / 256) * (a.nq / 256);
+  if (units > max_wgs) return TN_E_UNSUPPORTED;
+  const int nsteps = (a.rows + 31) / 32;
+  int splits = max_wgs / units;
+  if (splits > nsteps) splits = nsteps;
+  a.steps_per_split = (nsteps + splits - 1) / splits;
+  a.splits = splits;
+  const int grid = units * splits;
+  auto kern = pgemm_tn_kernel<0>;
+  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 131072, st, a);
+  return (int)hipGetLastError();
+}
+
