@@ -38,7 +38,7 @@ extern "C" {
 #define TN_PREC_BF16 1 /* bf16 activations/weights, v_mfma_f32_32x32x16_bf16, f32 accumulate/statistics */
 #define TN_PREC_FP8 2  /* BASELINE.json configs[4] (TitaNet-L): the pointwise (1x1) convs of the mega-block sub-blocks —
                           reference src/modules.py:76-78, 91 % of the model's FLOPs — run their FORWARD GEMM on the fp8 matrix
-                          cores (v_mfma_f32_32x32x16_fp8_fp8, OCP e4m3 operands: the depthwise output as produced, the
+                          cores (v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales), OCP e4m3 operands: the depthwise output as produced, the
                           weights with one scale per output channel), f32 accumulation; everything else (storage, statistics,
                           the whole backward pass, skip / epilog / attention GEMMs) is the bf16 plan */
 

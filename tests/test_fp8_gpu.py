@@ -1,5 +1,5 @@
 """TN_PREC_FP8 (BASELINE.json configs[4]: "TitaNet-L, fp8 MFMA pointwise-conv path"): the forward pointwise GEMMs of the
-mega-block sub-blocks on v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3 operands, per-output-channel weight scales, f32
+mega-block sub-blocks on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales) (OCP e4m3 operands, per-output-channel weight scales, f32
 accumulation), everything else the bf16 plan.  Stated tolerance of the mode, against the float64 oracle of the reference
 path: embeddings within 0.12 relative, loss within 5 %, whole-gradient cosine > 0.9 at the TitaNet-L width (e4m3 carries 3
 mantissa bits: 6 % per operand element, averaged down by the K = 1024 contraction); and the SHARP statement: against the

@@ -65,16 +65,19 @@ def test_eval_forward_sizes():
 
 
 @pytest.mark.parametrize("size", ["m", "l"])
-def test_wide_slab_kernels_agree_with_generic_depthwise_path(size):
-    """dw_fwd_slab / dw_bwd_slab (LDS-DMA tiles, rolling register windows; the default for the wide bf16 models) against the
-    generic depthwise kernels (TN_WIDE_DW_BWD=0 at plan creation) on the same bf16 step, at a shape with interior strips
-    (T = 300) and utterance boundaries inside tiles, dropout on: outputs and every depthwise / pointwise gradient tensor."""
+def test_wide_kernels_agree_with_generic_path(size):
+    """The kernels of the wide bf16 models — dw_fwd_slab / dw_bwd_slab (LDS-DMA tiles, rolling register windows) and the
+    pipelined GEMMs of tn_pgemm.h (forward, data gradient on the in-place BatchNorm-backward'd dS, transposed weight
+    gradient) — against the generic kernel templates (TN_GENERIC=1 at plan creation) on the same bf16 step, at a shape with
+    interior strips (T = 300) and utterance boundaries inside tiles, dropout on: outputs and every depthwise / pointwise
+    gradient tensor."""
     import os
     case = _case(size, 1, 5, 300, 31)
     x, y = case_inputs(case, torch.float32)
     res = {}
     for flag in ("0", "1"):
-        os.environ["TN_WIDE_DW_BWD"] = flag
+        if flag == "0":
+            os.environ["TN_GENERIC"] = "1"
         try:
             m = build(case, "ce", precision="bf16", dropout=0.1).train()
             m._seed_base, m._step = 2024, 0
@@ -83,7 +86,7 @@ def test_wide_slab_kernels_agree_with_generic_depthwise_path(size):
             torch.cuda.synchronize()
             res[flag] = (emb.detach().cpu().numpy(), {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters()})
         finally:
-            os.environ.pop("TN_WIDE_DW_BWD", None)
+            os.environ.pop("TN_GENERIC", None)
         del m
     # reference: the float64 oracle with the same dropout masks
     from tests.util import mask_fn_for

@@ -174,20 +174,18 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   p->prec = precision;
   p->esz = precision == TN_PREC_BF16 ? 2 : 4;
   {
-    const char* e = getenv("TN_V2");
-    // TN_V2 = bit mask (debug / A-B): 1 forward sub-block, 2 forward skip conv, 4 batched weight gradients, 8 fused data-gradient kernel; default all
-    const int mask = e ? atoi(e) : 127;   // 16: wide (1536-channel) decoder-side kernels; 64: fused dgrad + depthwise backward
-    p->use_v2 = (precision == TN_PREC_BF16 && !p->fp8 && m->cfg.hidden == 256 && m->cfg.kernel == 3) ? mask : 0;
-    // 32: keep the depthwise outputs for the batched weight gradients (needs 1 and 4)
-    p->save_q = (p->use_v2 & 1) && (p->use_v2 & 4) && (p->use_v2 & 32);
-    // generic template path (fp32 parity plans, TitaNet-M / -L): same idea, the forward GEMM's depthwise producer stores its tile
-    const char* sq = getenv("TN_SAVEQ");
-    if (!p->use_v2 && !(sq && atoi(sq) == 0)) p->save_q = true;
-    // hidden >= TN_DW_SPLIT (default 512): stand-alone depthwise producer + plain pointwise GEMM (tn_fwd_kernels.h: dw_fwd_kernel)
-    const char* ds = getenv("TN_DW_SPLIT");
-    p->split_dw = !p->use_v2 && (p->fp8 || m->cfg.hidden >= (ds ? atoi(ds) : 512)) && m->cfg.hidden % 8 == 0;
-    const char* pe = getenv("TN_PARTS");
-    if (pe && atoi(pe) > 0) p->combine_parts = atoi(pe);
+    // TN_GENERIC=1 (the one debug switch of the library, read at plan creation): every layer runs the generic kernel
+    // templates — what the fp32 parity plans, masked batches and unusual shapes use anyway.  Tests cross-check the
+    // specialised kernels against it (tests/test_v2_shapes_gpu.py, tests/test_model_sizes_gpu.py).
+    const char* e = getenv("TN_GENERIC");
+    const bool generic = e && atoi(e) != 0;
+    p->generic = generic;
+    // specialised kernels of the headline shape (hidden 256, 3 taps, bf16): tn_v2_kernels.h
+    p->use_v2 = (precision == TN_PREC_BF16 && !p->fp8 && m->cfg.hidden == 256 && m->cfg.kernel == 3 && !generic) ? 1 : 0;
+    // the forward keeps every depthwise output (the pointwise GEMM's operand) for the weight gradients
+    p->save_q = true;
+    // hidden >= 512: stand-alone depthwise producer + plain pointwise GEMM (tn_fwd_kernels.h)
+    p->split_dw = !p->use_v2 && (p->fp8 || m->cfg.hidden >= 512) && m->cfg.hidden % 8 == 0;
   }
   const tn_config& c = m->cfg;
   const size_t M = p->M, H = c.hidden, D = c.enc_out, A = c.attn_hidden, Hr = c.hidden / c.se_reduction;
@@ -230,10 +228,8 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   // ---- activations
   p->Y0 = b.take(M * H * e);
   {
-    const char* wdb = getenv("TN_WIDE_DW_BWD");
-    p->wide_dw_bwd = !(wdb && atoi(wdb) == 0);
-    const char* pt = getenv("TN_PROLOG_TAPS");
-    p->prolog_taps = precision == TN_PREC_BF16 && c.n_mels % 8 == 0 && !(pt && atoi(pt) == 0);
+    p->wide_dw_bwd = !p->generic;
+    p->prolog_taps = precision == TN_PREC_BF16 && c.n_mels % 8 == 0;
     if (p->prolog_taps) {
       p->x0 = b.take(M * (size_t)c.n_mels * e + 64);
       p->wprolog_taps = b.take(H * (size_t)c.n_mels * c.prolog_kernel * e);
@@ -289,7 +285,6 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   p->dEbn = b.take(M * D * e);
   p->dHP = b.take(M * A * e + 512);
   p->dpooled = b.take((size_t)batch * 2 * D * 4);
-  p->wepi_swz = b.take(D * H * 2);
   p->mu = b.take((size_t)batch * D * 4);
   p->dmu = b.take((size_t)batch * D * 4);
   p->dlin = b.take((size_t)batch * c.emb * 4);
@@ -300,21 +295,18 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     p->slab_bytes = biggest * sizeof(float) * 48;   // ~48 K-splits of the largest weight, more for smaller ones
     p->slabs = b.take(p->slab_bytes);
   }
-  {
-    const char* ww = getenv("TN_WIDE_WGRAD");
-    p->wide_wgrad = !p->use_v2 && precision == TN_PREC_BF16 && (H == 512 || H == 1024) && D % 256 == 0 && p->save_q &&
-                    c.n_mega_blocks > 0 && !(ww && atoi(ww) == 0);
-  }
-  if (p->use_v2 || p->wide_wgrad) {
+  // hidden 512 / 1024 (TitaNet-M / -L), bf16: slab kernels for the depthwise convs, pipelined GEMMs (tn_pgemm.h)
+  p->wide_wgrad = !p->use_v2 && !p->generic && precision == TN_PREC_BF16 && (H == 512 || H == 1024) && D % 256 == 0 && c.n_mega_blocks > 0;
+  if (p->use_v2) {
     const int hs = (int)(H / 256);
     p->wg2_upl = hs * hs;
     p->wg2_layers = c.n_mega_blocks * (c.n_sub_blocks + 1) * p->wg2_upl;
     // the epilog conv's weight gradient rides along as (D / 256) x (H / 256) slabs of 256 x 256
-    p->wg2_epi_slabs = (c.n_mega_blocks > 0 && D % 256 == 0 && ((p->use_v2 & 16) || p->wide_wgrad)) ? (int)(D / 256) * hs : 0;
+    p->wg2_epi_slabs = (c.n_mega_blocks > 0 && D % 256 == 0 && p->use_v2) ? (int)(D / 256) * hs : 0;
     p->wg2_layers += p->wg2_epi_slabs;
     // ... and the two weight gradients of the attentive pooling (D x 128 and 128 x D): one unit per 256-channel slab of D,
     // the 128-wide operand read as 256 (half of the unit's output is dropped by the reduction)
-    p->wg2_asp_units = (p->wg2_epi_slabs > 0 && (p->use_v2 & 16) && H == 256 && A == 128 && !c.simple_pool) ? 2 * (int)(D / 256) : 0;
+    p->wg2_asp_units = (p->wg2_epi_slabs > 0 && p->use_v2 && H == 256 && A == 128 && !c.simple_pool) ? 2 * (int)(D / 256) : 0;
     p->wg2_layers += p->wg2_asp_units;
     p->wg2_grid = 256;
     p->wg2_desc = b.take((size_t)p->wg2_layers * 256);   // >= sizeof(WgradV2Desc) each (checked at upload)
@@ -367,7 +359,7 @@ void plan_layout_tail(tn_plan* p) {
   }
   Bump b;
   b.off = p->ws_fixed_bytes;
-  if ((p->use_v2 || p->wide_wgrad) && p->wg2_layers > 0) {
+  if (p->use_v2 && p->wg2_layers > 0) {
     // every group's launch cuts its (layer, 32-row chunk) units into one contiguous range per workgroup: the number of
     // partial slabs a layer can receive is bounded by the smallest group
     const int chunks = (p->M + 31) / 32;
@@ -424,8 +416,6 @@ extern "C" void tn_plan_destroy(tn_plan* p) {
   if (!p) return;
   for (auto e : p->prof_events) (void)hipEventDestroy(e);
   for (auto e : p->bucket_events) (void)hipEventDestroy(e);
-  for (auto e : p->fork_events) (void)hipEventDestroy(e);
-  if (p->side_stream) (void)hipStreamDestroy(p->side_stream);
   delete p;
 }
 
@@ -543,15 +533,6 @@ extern "C" int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbu
     TN_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     p->bucket_events.push_back(e);
   }
-  {
-    const char* ss = getenv("TN_WGRAD_STREAM");
-    if (!p->side_stream && ss && atoi(ss) != 0) TN_CHECK_HIP(hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking));
-    while (p->fork_events.size() < 64) {
-      hipEvent_t e;
-      TN_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      p->fork_events.push_back(e);
-    }
-  }
   p->bound = true;
   return 0;
 }
@@ -614,7 +595,7 @@ int gemm_store(const GemmShape& g, const typename Prod::Args& pa, const EpiStore
 // plain stored bf16 operand, big problem: the pipelined LDS-DMA GEMM (tn_pgemm.h); -1000 = not applicable
 template <typename AT>
 int gemm_plain_pipe(const tn_plan* p, const GemmShape& g, const void* X, int ldx, const BnAct& act, const EpiStoreArgs& ea, hipStream_t st) {
-  if (sizeof(AT) != 2 || p->masked || ea.rm.len) return -1000;
+  if (sizeof(AT) != 2 || p->masked || p->generic || ea.rm.len) return -1000;
   if (act.mode != 0 || act.relu || act.drop_thr || act.rm.len) return -1000;
   if (g.K % 32 || g.N % 64 || g.N > 3072 || ldx % 8 || ea.ldy % 2) return -1000;
   if (g.K < 256) return -1000;
@@ -683,13 +664,14 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
     BlockWs& bw = p->blk[i];
     // skip connection: 1x1 conv (reference src/models.py:452-455)
     {
-      int rc;
-      if (use_v2 & 2) {
+      int rc = -1000;
+      if (use_v2) {
         SubFwdV2Args va{(const bf16_t*)xin, actx, nullptr, nullptr, (const bf16_t*)(ws + bw.wskip.w), params + mb.bskip,
                         (bf16_t*)(ws + bw.S), statp(mb.bnskip), M, T, 0,
                         bw.wskip.sw ? (const uint4*)(ws + bw.wskip.sw) : nullptr, nullptr};
         rc = launch_sub_fwd_v4<1, false>(va, 256, st);
-      } else {
+      }
+      if (rc == -1000) {
         GemmShape g{M, H, H, wsel<AT>(p, mb.wskip, bw.wskip)};
         ProdPlain::Args pa{xin, H, actx};
         EpiStoreArgs ea{ws + bw.S, H, params + mb.bskip, statp(mb.bnskip), rm};
@@ -709,12 +691,13 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       int rc;
       {
         ProfScope ps(p, TN_PROF_FWD_SUBBLOCK, st);
-        if (use_v2 & 1) {
+        if (use_v2) {
           SubFwdV2Args va{(const bf16_t*)cur, acur, params + sb.wdw, params + sb.bdw, (const bf16_t*)(ws + bw.wpw[j].w),
                           params + sb.bpw, (bf16_t*)(ws + bw.Y[j]), statp(sb.bn), M, T, 0,
                           bw.wpw[j].sw ? (const uint4*)(ws + bw.wpw[j].sw) : nullptr,
                           (p->save_q && training) ? (bf16_t*)(ws + bw.Q[j]) : nullptr};
           rc = launch_sub_fwd_v5<3, true>(va, 256, st);
+          if (rc == -1000) rc = gemm_store<AT, ProdDw>(g, pa, ea, c.kernel, st);
         } else if (p->split_dw && p->save_q) {
           // wide models: the depthwise output is produced once by a streaming kernel (it is kept for the weight gradients
           // anyway) and the pointwise GEMM reads it as a plain operand
@@ -755,7 +738,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       const int CV = H / 8, TG = 512 / CV;
       size_t smem = (size_t)(3 * H + ((Hr + 3) & ~3) + TG * H) * sizeof(float);
       int rc1 = -1000;
-      if (sizeof(AT) == 2 && H == V2_C && Hr == 16 && (use_v2 & 1)) {
+      if (sizeof(AT) == 2 && H == V2_C && Hr == 16 && use_v2) {
         SeSqueezeV2Args sa;
         memset(&sa, 0, sizeof(sa));
         sa.Y = (const bf16_t*)cur; sa.act = acur; sa.W1 = params + mb.se_w1; sa.W2 = params + mb.se_w2;
@@ -775,11 +758,11 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
         ik = 1.f / (1.f - pd);
       }
       int rc2 = -1000;
-      if (sizeof(AT) == 2 && H == V2_C && (use_v2 & 1)) {
+      if (sizeof(AT) == 2 && H == V2_C && use_v2) {
         CombineFwdV2Args ca;
         memset(&ca, 0, sizeof(ca));
         ca.S = (const bf16_t*)(ws + bw.S); ca.actS = acts; ca.Y3 = (const bf16_t*)cur; ca.act3 = acur;
-        ca.gate = (const float*)(ws + bw.g); ca.OUT = (bf16_t*)(ws + bw.OUT); ca.T = T; ca.parts = p->combine_parts;
+        ca.gate = (const float*)(ws + bw.g); ca.OUT = (bf16_t*)(ws + bw.OUT); ca.T = T; ca.parts = 4;
         ca.drop_thr = thr; ca.drop_key = key; ca.inv_keep = ik;
         ca.key_add = (const uint32_t*)(ws + p->step_state) + 2;
         rc2 = launch_combine_fwd_v2(ca, B, st);
@@ -797,7 +780,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   }
   // ---- epilog 1x1 conv (reference src/models.py:384, :404)
   {
-    const bool wide = sizeof(AT) == 2 && (use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128;
+    const bool wide = sizeof(AT) == 2 && use_v2 && H == 256 && D % 256 == 0 && A == 128;
     if (wide && actx.mode == 0 && !actx.relu && !actx.drop_thr) {
       WideOutArgs wa;
       memset(&wa, 0, sizeof(wa));
@@ -829,7 +812,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   // ---- attentive statistics pooling (reference src/models.py:553-584)
   {
     int rc;
-    if (sizeof(AT) == 2 && (use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128) {
+    if (sizeof(AT) == 2 && use_v2 && H == 256 && D % 256 == 0 && A == 128) {
       WideInArgs wa;
       memset(&wa, 0, sizeof(wa));
       wa.A = (const bf16_t*)(ws + p->E); wa.act = acte; wa.W = (const bf16_t*)wsel<AT>(p, m->asp_win, p->wwin);
@@ -842,7 +825,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       rc = gemm_store<AT, ProdPlain, EpiStoreTanh>(g1, pa1, ea1, 0, st);
     }
     if (rc) return rc;
-    if (sizeof(AT) == 2 && (use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128) {
+    if (sizeof(AT) == 2 && use_v2 && H == 256 && D % 256 == 0 && A == 128) {
       WideOutArgs wa;
       memset(&wa, 0, sizeof(wa));
       wa.X = (const bf16_t*)(ws + p->HID); wa.W = (const bf16_t*)wsel<AT>(p, m->asp_wout, p->wwout); wa.bias = params + m->asp_bout;

@@ -76,7 +76,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   // pass (dS) + the two pipelined LDS-DMA GEMMs of tn_pgemm.h on stored operands (data gradient dS * W, weight gradient
   // dS^T * Q straight into the gradient buffer), layer by layer
   const bool pipe = sizeof(AT) == 2 && !use_v2 && p->wide_wgrad && !p->masked && training && H % 256 == 0 && D % 256 == 0;
-  const bool batched_wgrad = sizeof(AT) == 2 && ((use_v2 & 4) || (p->wide_wgrad && !p->masked)) && training && p->wg2_layers > 0 && !pipe;
+  const bool batched_wgrad = sizeof(AT) == 2 && use_v2 && training && p->wg2_layers > 0;
   auto pipe_layer = [&](size_t dz, size_t y, const BnRef& bn, int Cout, const WcRef& wc, int Cin, size_t dx_out, const void* q, bool q_plain,
                         const BnAct& qact, int64_t wgrad_off) -> int {
     int rc = launch_bn_bwd_apply((bf16_t*)(ws + dz), (const bf16_t*)(ws + y), make_bnbwd(p, bn, M, training), M, Cout, st);
@@ -96,24 +96,15 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     return launch_wgrad<AT, ProdPlain, ProdPlain>(M, Cout, Cin, pp, qa, 0, slabs, p->slab_bytes, grads + wgrad_off, st);
   };
   auto is_plain = [](const BnAct& a) { return a.mode == 0 && !a.relu && !a.drop_thr && !a.rm.len; };
-  const bool v2_bwd = sizeof(AT) == 2 && (use_v2 & 8);
+  const bool v2_bwd = sizeof(AT) == 2 && use_v2;
   const int nb = c.n_mega_blocks;
   const int per_blk = nsub + 1;
   int rc_fin = 0;
   // ---- everything that turns accumulated sums / kept tensors into the final gradients of ONE bucket, then the bucket's
   // event: with grad_groups > 1 the data-parallel trainer all-reduces bucket k while the backward of earlier blocks runs
-  const hipStream_t main_st = st;
   auto finalize_bucket = [&](int k) {
     const tn_plan::GradBucket& bk = p->buckets[k];
     const bool has_blocks = bk.blk_hi >= bk.blk_lo;
-    // every bucket but the last runs on the side stream (fork here, joined at the end of backward): nothing it reads is
-    // written again by the rest of backward (per-layer kept gradients, per-layer sums, per-block SE scratch)
-    hipStream_t st = main_st;
-    if (p->side_stream && k + 1 < (int)p->buckets.size() && k < (int)p->fork_events.size()) {
-      (void)hipEventRecord(p->fork_events[k], main_st);
-      (void)hipStreamWaitEvent(p->side_stream, p->fork_events[k], 0);
-      st = p->side_stream;
-    }
     if (bk.prolog) {
       const int cur_ = p->prolog_cur;
       ProdDy::Args pa{ws + p->dA[cur_], ws + p->Y0, H, make_bnbwd(p, m->prolog_bn, M, training)};
@@ -144,7 +135,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         const long total = (long)count * chunks;
         const int upw = (int)((total + p->wg2_grid - 1) / p->wg2_grid);
         const size_t smem = (size_t)(2 * WG2_RK * WG2_PITCH + (WG2_RK + 2) * V2_C) * sizeof(bf16_t) + (size_t)(6 + 3) * V2_C * sizeof(float);
-        auto kern = p->save_q ? wgrad_batched_v2_kernel<3, false> : wgrad_batched_v2_kernel<3, true>;
+        auto kern = wgrad_batched_v2_kernel<3, false>;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
           rc_fin = TN_E_STATE; return;
         }
@@ -255,7 +246,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     // d hid_pre = (dEN * W_out) .* (1 - hid^2)
     {
       int rc;
-      if (sizeof(AT) == 2 && (use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128) {
+      if (sizeof(AT) == 2 && use_v2 && H == 256 && D % 256 == 0 && A == 128) {
         WideInArgs wa;
         memset(&wa, 0, sizeof(wa));
         wa.A = (const bf16_t*)(ws + p->dE); wa.W = (const bf16_t*)wt(p->wwout); wa.H = (const bf16_t*)(ws + p->HID);
@@ -279,7 +270,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     // d x = dHP * W_in + direct term; through the epilog relu -> dEbn (+ BN backward sums)
     {
       int rc;
-      if (sizeof(AT) == 2 && (use_v2 & 16) && H == 256 && D % 256 == 0 && A == 128) {
+      if (sizeof(AT) == 2 && use_v2 && H == 256 && D % 256 == 0 && A == 128) {
         WideOutArgs wa;
         memset(&wa, 0, sizeof(wa));
         wa.X = (const bf16_t*)(ws + p->dHP); wa.W = (const bf16_t*)wt(p->wwin); wa.Y = (bf16_t*)(ws + p->dEbn);
@@ -314,16 +305,9 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       }
     }
     int rc;
-    // the pipelined generic GEMM (BatchNorm backward on load, 128 x 256 tiles) does this K = 1536 product in 183 us; the
-    // weights-in-registers dgrad_wide_v2 re-streams its weight slab per 64 rows and takes 207 us (+ its swizzle): TN_DGRAD_WIDE=1
-    static const bool dgrad_wide_on = getenv("TN_DGRAD_WIDE") && atoi(getenv("TN_DGRAD_WIDE")) == 1;
-    if (sizeof(AT) == 2 && (use_v2 & 16) && H == 256 && D % 256 == 0 && dgrad_wide_on) {
-      DgradWideArgs da;
-      memset(&da, 0, sizeof(da));
-      da.dZ = (const bf16_t*)(ws + p->dEbn); da.Y = (const bf16_t*)(ws + p->E); da.bn = pa.bn;
-      da.Wt = (const bf16_t*)wt(p->wepi); da.Wswz = (const uint4*)(ws + p->wepi_swz); da.OUT = (bf16_t*)(ws + p->dA[cur]); da.M = M; da.KW = D;
-      rc = launch_dgrad_wide_v2(da, 256, st);
-    } else {
+    // (the pipelined generic GEMM, BatchNorm backward on load, does this K = 1536 product in 183 us; a weights-in-registers
+    //  kernel that re-streamed its weight slab per 64 rows took 207 us and was removed)
+    {
       GemmShape g{M, H, D, wt(p->wepi)};
       EpiStoreArgs ea{ws + p->dA[cur], H, nullptr, nullptr};
       rc = gemm_any<AT, ProdDy, EpiStore>(g, pa, ea, st);
@@ -378,7 +362,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         ca.gate = (const float*)(ws + bw.g); ca.hid = (const float*)(ws + bw.h); ca.dgate = (const float*)(ws + bw.dgate);
         ca.dpre2 = (float*)(ws + bw.dpre2); ca.dpre1 = (float*)(ws + bw.dpre1);
         ca.W1 = params + mb.se_w1; ca.W2 = params + mb.se_w2; ca.dYbn = (bf16_t*)(ws + bw.dY[nsub - 1]);
-        ca.bsums3 = bsum(mb.sub[nsub - 1].bn); ca.T = T; ca.parts = p->combine_parts >= 2 ? 2 : 1;
+        ca.bsums3 = bsum(mb.sub[nsub - 1].bn); ca.T = T; ca.parts = 2;
         rc2 = launch_combine_bwd2_v2(ca, B, st);
         if (rc2 > 0) return rc2;
       }
@@ -438,7 +422,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         }
         if (rc) return rc;
       }
-      if (v2_bwd && (use_v2 & 64)) {
+      if (v2_bwd) {
         // (A + B) in one pass: dD never leaves the CU (dgrad_dw_v6)
         DgradDwArgs fa;
         memset(&fa, 0, sizeof(fa));
@@ -457,39 +441,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
           ProfScope ps(p, TN_PROF_BWD_DW, st);
           rc = launch_dgrad_dw_v6(fa, 256, st);
         }
-        if (rc > 0) return rc;
-        if (rc == 0) continue;
-      }
-      if (v2_bwd) {
-        // (A) pointwise data gradient dD = BN-backward(dZ, Y) * W   (persistent MFMA kernel, W^T in registers)
-        DgradV2Args va;
-        memset(&va, 0, sizeof(va));
-        va.dZ = (const bf16_t*)(ws + bw.dY[j]); va.Y = (const bf16_t*)(ws + bw.Y[j]); va.bn = pa.bn;
-        va.Wt = (const bf16_t*)(ws + bw.wpw[j].wt); va.OUT = (bf16_t*)(ws + p->dD); va.M = M;
-        va.Wswz = bw.wpw[j].swt ? (const uint4*)(ws + bw.wpw[j].swt) : nullptr;
-        int rc;
-        {
-          ProfScope ps(p, TN_PROF_BWD_DGRAD, st);
-          rc = launch_dgrad_v2<64>(va, 256, st);
-        }
-        if (rc) return rc;
-        // (B) depthwise backward + activation backward + BN sums (streaming kernel)
-        DwBwdV3Args da;
-        memset(&da, 0, sizeof(da));
-        da.dD = (const bf16_t*)(ws + p->dD); da.X = (const bf16_t*)sin; da.actX = asin;
-        da.wdw = params + sb.wdw; da.M = M; da.T = T;
-        da.gacc = (float*)(ws + p->dw_gacc) + (size_t)(i * nsub + j) * TN_NREP * (c.kernel + 1) * H;
-        if (j > 0) {
-          da.ADD = nullptr; da.OUT = (bf16_t*)(ws + bw.dY[j - 1]); da.bsumsX = bsum(mb.sub[j - 1].bn);
-        } else {
-          da.ADD = (const bf16_t*)(ws + p->dXs); da.OUT = (bf16_t*)(ws + p->dA[cur ^ 1]);
-          da.bsumsX = (i == 0) ? bsum(m->prolog_bn) : nullptr;
-        }
-        {
-          ProfScope ps(p, TN_PROF_BWD_DW, st);
-          rc = launch_dw_bwd_v4<3>(da, 256, st);
-        }
-        if (rc) return rc;
+        if (rc) return rc == -1000 ? TN_E_UNSUPPORTED : rc;
         continue;
       }
       if (pipe) {
@@ -565,9 +517,6 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   // weight gradients (v2: all of the bucket's layers in one balanced launch), sums -> BatchNorm / bias / SE gradients
   finalize_bucket((int)p->buckets.size() - 1);
   if (rc_fin) return rc_fin;
-  if (p->side_stream)      // join: the caller's stream owns every gradient when tn_backward's work is done
-    for (int k = 0; k + 1 < (int)p->buckets.size() && k < (int)p->bucket_events.size(); ++k)
-      (void)hipStreamWaitEvent(main_st, p->bucket_events[k], 0);
   return (int)hipGetLastError();
 }
 
@@ -612,7 +561,7 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
   }
   if (!sd.empty())
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->se_table, sd.data(), sd.size() * sizeof(SeGradDesc), hipMemcpyHostToDevice, st));
-  if ((p->use_v2 || p->wide_wgrad) && p->wg2_layers > 0) {
+  if (p->use_v2 && p->wg2_layers > 0) {
     const tn_config& c = m->cfg;
     const int nsub = c.n_sub_blocks, M = p->M, H = c.hidden, hs = H / 256;
     std::vector<WgradV2Desc> wd;

@@ -80,6 +80,7 @@ struct tn_plan {
   const tn_model* model;
   int B, T, M, prec;
   int use_v2 = 0;           // specialised hidden=256 bf16 kernels (tn_v2_kernels.h)
+  bool generic = false;     // TN_GENERIC=1: generic kernel templates everywhere (debug / cross-check switch)
   size_t esz;               // activation element size
   size_t ws_bytes = 0;
   size_t bound_bytes = 0;       // size of the workspace handed to tn_plan_bind
@@ -98,7 +99,6 @@ struct tn_plan {
   int n_fp8 = 0;
   bool split_dw = false;                // wide models: depthwise producer as its own streaming kernel (forward)
   bool save_q = false;                  // forward stores the depthwise outputs (bf16 v2 path with batched weight gradients)
-  int combine_parts = 4;                // row parts per utterance of the v2 element-wise kernels (env TN_PARTS)
   size_t bzero_begin, bzero_bytes;      // region cleared at the start of every backward
   size_t step_state = 0;                // {uint64 step; uint32 word}: device-resident step counter / dropout word (hipGraph replay)
   std::vector<size_t> stats;            // per BN id: forward sums  float[NREP][2][C]
@@ -108,7 +108,7 @@ struct tn_plan {
   std::vector<BlockWs> blk;
   size_t E, HID, EN, pooled, smax, sinv, qv, lin, emb, emb_norm, dlogits, dscale, logits, preds;
   WcRef wprolog, wepi, wwin, wwout;
-  bool wide_dw_bwd = true;         // TN_WIDE_DW_BWD=0: generic depthwise backward for the wide models (A/B)
+  bool wide_dw_bwd = true;         // slab depthwise kernels of the wide models (off under TN_GENERIC)
   bool prolog_taps = false;        // bf16 plans: prolog GEMMs read a packed rows x n_mels copy of the input (ProdTaps)
   size_t x0 = 0, wprolog_taps = 0, prolog_gtmp = 0;
   size_t cast_table, bn_table, stats_ptr_table;
@@ -124,7 +124,6 @@ struct tn_plan {
   size_t dHP;          // rows x attn AT
   size_t dpooled, dlin, demb;   // float
   size_t swz_table = 0; int n_swz = 0;   // (src, dst) pairs of the fragment-order copies, refreshed after every parameter cast
-  size_t wepi_swz;              // epilog weight in MFMA-fragment order (dgrad_wide_v2)
   size_t mu, dmu;               // float [B][D]: mean over time of the encoder output and its gradient (simple_pool)
   size_t slabs;        // split-K partial weight gradients
   size_t slab_bytes = 0;
@@ -133,8 +132,7 @@ struct tn_plan {
   size_t dw_gacc, dw_table;                         // depthwise gradient accumulators [layer][NREP][KD+1][256] + finalize table
   int wg2_layers = 0, wg2_maxparts = 0, wg2_units_per_wg = 0, wg2_grid = 0, wg2_epi_slabs = 0, wg2_asp_units = 0;
   int wg2_upl = 1;              // units per pointwise layer: (hidden / 256)^2 output slabs of 256 x 256
-  bool wide_wgrad = false;      // hidden = 512 / 1024 (TitaNet-M / -L), bf16: generic forward / data-gradient kernels, but the
-                                // pointwise weight gradients run as slab units of the batched launch
+  bool wide_wgrad = false;      // hidden = 512 / 1024 (TitaNet-M / -L), bf16: slab depthwise kernels + the pipelined GEMMs of tn_pgemm.h
   size_t bwd_table_bytes = 0;
   // gradient buckets in COMPLETION order (data-parallel overlap: bucket i's all-reduce starts when its event fires)
   struct GradBucket {
@@ -147,10 +145,6 @@ struct tn_plan {
   int grad_groups = 1;            // 1: one bucket, every deferred weight gradient in one launch at the end of backward
   std::vector<GradBucket> buckets;
   std::vector<hipEvent_t> bucket_events;
-  // optional: all but the last bucket are finalised on a plan-owned side stream (fork / join by events), so that their
-  // bandwidth-bound weight-gradient launches fill the launch gaps and tails of the dependent backward chain
-  hipStream_t side_stream = nullptr;
-  std::vector<hipEvent_t> fork_events;
   // per-kernel event timing (tn_profile_*)
   int prof_class = 0;
   int prof_stride = 1;            // tn_profile_sample: bracket every n-th launch of the class

@@ -318,202 +318,13 @@ __global__ void wgrad_v2_reduce_kernel(const WgradV2Out* __restrict__ outs, cons
   }
 }
 
-// ==========================================================================================
-// Depthwise backward, streaming version (no MFMA in this kernel, so no resident weight fragments:
-// the registers go to the per-channel constants, a 3-row sliding window and the accumulators).
-//   dA[r]  = sum_k w[c][k] dD[r - k + pad]  (+ ADD[r])
-//   OUT[r] = dA[r] * d act/d bn (X[r])             mask = [A > 0] * inv_keep  (A = act(X), so no
-//                                                    second dropout-hash evaluation is needed)
-//   d w_dw[c][k] += dD[r] A[r + k - pad],  d b_dw[c] += dD[r],  BN sums of the layer that made X.
-// A 64-row tile (+ halo) of dD and X is staged raw in LDS (all its loads in flight at once), then
-// every thread walks a strip of 8 consecutive rows for its 8 channels with a sliding window, so
-// act() is evaluated 10 times per 8 outputs instead of 3 times per output.
-// ==========================================================================================
-struct DwBwdV3Args {
-  const bf16_t* dD;
-  const bf16_t* X;
-  BnAct actX;
-  const bf16_t* ADD;   // or null
-  bf16_t* OUT;
-  const float* wdw;
-  float* gacc;         // [TN_NREP][KD + 1][256] replicated accumulators of d w_dw (k-major) and d b_dw (pre-zeroed)
-  float* bsumsX;       // or null
-  int M, T, ntiles;
-};
-
-// 4 channels per thread, one wave per 8-row strip (all lanes of a wave share the row, so the utterance
-// boundary tests are wave-uniform scalar branches), 512 threads per 64-row tile, <= 128 VGPRs so that two
-// workgroups (16 waves) share a CU and hide each other's LDS / VALU latency.
+// 8-byte vector <-> 4 floats (4 channels per lane: the stencil layout of the fused data-gradient kernel)
 __device__ __forceinline__ void unpack4(const uint2& a, float v[4]) {
   v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
   v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
 }
-__device__ __forceinline__ void act4_reg(float v[4], const float sc[4], const float sh[4], const BnAct& a, uint32_t row, int c0) {
-  if (a.mode != 0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = v[i] * sc[i] + sh[i];
-  }
-  if (a.relu) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-  }
-  if (a.drop_thr) tn_drop4(v, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, (uint32_t)(c0 >> 2) & 1u, tn_act_key(a), a.drop_thr);
-}
 
-template <int KD>
-__global__ __launch_bounds__(512, 4) void dw_bwd_v3_kernel(DwBwdV3Args a) {
-  constexpr int PADR = (KD - 1) / 2, ROWS = 64 + KD - 1, NT = 512;
-  static_assert(KD == 3, "sliding window below is written for K = 3");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* Ds = reinterpret_cast<bf16_t*>(smem);     // [ROWS][256] raw dD
-  bf16_t* Xs = Ds + ROWS * V2_C;                     // [ROWS][256] raw X
-  float* cst = reinterpret_cast<float*>(Xs + ROWS * V2_C);   // sc, sh, mean, rstd, wd[KD] : [4 + KD][256]; later the reduction scratch
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, strip = tid >> 6, c0 = lane * 4;
-  const bool has_bn = a.actX.mode != 0;
-  const bool has_mask = has_bn || a.actX.relu || a.actX.drop_thr;
-  const float mscale = a.actX.drop_thr ? a.actX.inv_keep : 1.f;
-
-  if (tid < V2_C) {
-    float s = 1.f, h = 0.f, mean = 0.f, rstd = 1.f;
-    if (has_bn && !(V2_DBG_SKIP & 64)) {
-      bn_scale_shift(a.actX, V2_C, tid, s, h);
-      bn_mean_rstd(a.actX, V2_C, tid, mean, rstd);
-    }
-    cst[tid] = s; cst[V2_C + tid] = h; cst[2 * V2_C + tid] = mean; cst[3 * V2_C + tid] = rstd;
-#pragma unroll
-    for (int k = 0; k < KD; ++k) cst[(4 + k) * V2_C + tid] = a.wdw[(size_t)tid * KD + k];
-  }
-  __syncthreads();
-  float sc[4], sh[4], mean[4], rstd[4], wd[KD][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    sc[i] = cst[c0 + i]; sh[i] = cst[V2_C + c0 + i]; mean[i] = cst[2 * V2_C + c0 + i]; rstd[i] = cst[3 * V2_C + c0 + i];
-#pragma unroll
-    for (int k = 0; k < KD; ++k) wd[k][i] = cst[(4 + k) * V2_C + c0 + i];
-  }
-  float gw[KD][4], gb[4], s1[4], s2[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    gb[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f;
-#pragma unroll
-    for (int k = 0; k < KD; ++k) gw[k][i] = 0.f;
-  }
-
-  for (int tile = blockIdx.x; tile < ((V2_DBG_SKIP & 16) ? 0 : a.ntiles); tile += gridDim.x) {
-    const int out0 = tile * 64, raw0 = out0 - PADR;
-    __syncthreads();
-    // ---- stage the raw tiles: all loads of the tile are issued before any is consumed
-    constexpr int NV = (ROWS * 32 + NT - 1) / NT;   // 16-byte vectors per thread per stream
-    uint4 bd[NV], bx[NV];
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      const int v = tid + q * NT, r = v >> 5, gr = raw0 + r;
-      const bool ok = r < ROWS && gr >= 0 && gr < a.M;
-      bd[q] = ok ? *reinterpret_cast<const uint4*>(a.dD + (size_t)gr * V2_C + (v & 31) * 8) : make_uint4(0, 0, 0, 0);
-      bx[q] = ok ? *reinterpret_cast<const uint4*>(a.X + (size_t)gr * V2_C + (v & 31) * 8) : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      const int v = tid + q * NT, r = v >> 5;
-      if (r < ROWS) {
-        *reinterpret_cast<uint4*>(Ds + r * V2_C + (v & 31) * 8) = bd[q];
-        *reinterpret_cast<uint4*>(Xs + r * V2_C + (v & 31) * 8) = bx[q];
-      }
-    }
-    __syncthreads();
-    // ---- sliding window over this wave's 8 output rows
-    const int l0 = strip * 8;            // LDS row of (first output row - PADR)
-    float Dp[4], Dc[4], Dn[4], Ap[4], Ac[4], An[4];
-    auto load_row = [&](int l, float* D, float* A) {
-      unpack4(*reinterpret_cast<const uint2*>(Ds + l * V2_C + c0), D);
-      unpack4(*reinterpret_cast<const uint2*>(Xs + l * V2_C + c0), A);
-      const int gr = raw0 + l;
-      if (gr >= 0 && gr < a.M) act4_reg(A, sc, sh, a.actX, (uint32_t)gr, c0);
-      else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) A[i] = 0.f;
-      }
-    };
-    load_row(l0, Dp, Ap);
-    load_row(l0 + 1, Dc, Ac);
-    uint2 addn = make_uint2(0, 0);
-    if (a.ADD && out0 + l0 < a.M) addn = *reinterpret_cast<const uint2*>(a.ADD + (size_t)(out0 + l0) * V2_C + c0);
-#pragma unroll
-    for (int o = 0; o < 8; ++o) {
-      const int gr = out0 + l0 + o;       // global output row (wave-uniform)
-      load_row(l0 + o + 2, Dn, An);
-      const uint2 addc = addn;
-      if (a.ADD && o + 1 < 8 && gr + 1 < a.M) addn = *reinterpret_cast<const uint2*>(a.ADD + (size_t)(gr + 1) * V2_C + c0);
-      if (gr < a.M) {
-        const int t = gr % a.T;
-        float dA[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          gb[i] += Dc[i];
-          dA[i] = wd[1][i] * Dc[i];
-          gw[1][i] = fmaf(Dc[i], Ac[i], gw[1][i]);
-        }
-        if (t + 1 < a.T) {    // wave-uniform: next row belongs to the same utterance
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { dA[i] = fmaf(wd[0][i], Dn[i], dA[i]); gw[2][i] = fmaf(Dc[i], An[i], gw[2][i]); }
-        }
-        if (t > 0) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { dA[i] = fmaf(wd[2][i], Dp[i], dA[i]); gw[0][i] = fmaf(Dc[i], Ap[i], gw[0][i]); }
-        }
-        if (a.ADD) {
-          float ad[4];
-          unpack4(addc, ad);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) dA[i] += ad[i];
-        }
-        if (has_mask) {
-          float y[4];
-          unpack4(*reinterpret_cast<const uint2*>(Xs + (l0 + o + 1) * V2_C + c0), y);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float m = a.actX.relu ? ((Ac[i] > 0.f) ? mscale : 0.f) : mscale;
-            dA[i] *= m;
-            s1[i] += dA[i];
-            s2[i] += dA[i] * (y[i] - mean[i]) * rstd[i];
-          }
-        }
-        uint2 ov;
-        ov.x = f2bf_pk(dA[0], dA[1]);
-        ov.y = f2bf_pk(dA[2], dA[3]);
-        *reinterpret_cast<uint2*>(a.OUT + (size_t)gr * V2_C + c0) = ov;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { Dp[i] = Dc[i]; Dc[i] = Dn[i]; Ap[i] = Ac[i]; Ac[i] = An[i]; }
-    }
-  }
-  // ---- reductions: the 8 waves (row strips) hold the same channels -> plain LDS stores + a short sum,
-  // then COALESCED, 8-way replicated global atomics (LDS atomics with same-address traffic and strided,
-  // unreplicated global atomics made this epilogue cost more than the tiles themselves).
-  __syncthreads();
-  float* red = reinterpret_cast<float*>(smem);       // [8 waves][KD + 3][256]
-  {
-    float* mine = red + (size_t)strip * (KD + 3) * V2_C + c0;
-#pragma unroll
-    for (int k = 0; k < KD; ++k) *reinterpret_cast<float4*>(mine + k * V2_C) = make_float4(gw[k][0], gw[k][1], gw[k][2], gw[k][3]);
-    *reinterpret_cast<float4*>(mine + KD * V2_C) = make_float4(gb[0], gb[1], gb[2], gb[3]);
-    *reinterpret_cast<float4*>(mine + (KD + 1) * V2_C) = make_float4(s1[0], s1[1], s1[2], s1[3]);
-    *reinterpret_cast<float4*>(mine + (KD + 2) * V2_C) = make_float4(s2[0], s2[1], s2[2], s2[3]);
-  }
-  __syncthreads();
-  const int rep = blockIdx.x % TN_NREP;
-  for (int i = tid; i < ((V2_DBG_SKIP & 32) ? 0 : (KD + 3) * V2_C); i += NT) {
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) v += red[(size_t)w * (KD + 3) * V2_C + i];
-    const int k = i / V2_C, c = i % V2_C;
-    if (k <= KD) atomic_add_f32(&a.gacc[(size_t)(rep * (KD + 1) + k) * V2_C + c], v);
-    else if (a.bsumsX && has_mask) atomic_add_f32(&a.bsumsX[(size_t)(rep * 2 + (k - KD - 1)) * V2_C + c], v);
-  }
-}
-
-// d w_dw[c][k] / d b_dw[c] of every depthwise layer from the replicated accumulators (one launch)
+// depthwise gradient accumulators [TN_NREP][KD + 1][256] of the fused data-gradient kernels -> the gradient buffer
 struct DwGradOut {
   const float* gacc;   // [TN_NREP][KD + 1][256]
   float* g_wdw;        // [256][KD]
@@ -530,25 +341,6 @@ __global__ void dw_grad_finalize_kernel(const DwGradOut* __restrict__ outs, int 
   }
 }
 
-template <int KD>
-inline int launch_dw_bwd_v3(DwBwdV3Args a, int max_wgs, hipStream_t st) {
-  a.ntiles = (a.M + 63) / 64;
-  const int grid = a.ntiles < max_wgs ? a.ntiles : max_wgs;
-  constexpr int ROWS = 64 + KD - 1;
-  const size_t smem = (size_t)2 * ROWS * V2_C * sizeof(bf16_t) + (size_t)(4 + KD) * V2_C * sizeof(float);
-  auto kern = dw_bwd_v3_kernel<KD>;
-  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a);
-  return (int)hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
-// dw_bwd_v4: the same streaming kernel with (a) the activation flags as template parameters and (b) a
-// wave-uniform FAST PATH per 8-row strip: when the strip's 10 window rows lie inside one utterance (97 % of
-// the strips at T = 300) the row loop is straight-line code — no boundary tests, no scalar branches between
-// the LDS reads and the FMAs (v3 executed ~130 wave-uniform branches and ~2000 instructions per tile).
-// FL bits: 1 = BatchNorm on load, 2 = ReLU, 4 = dropout, 8 = skip-path addend.
-// ------------------------------------------------------------------------------------------
 template <int FL>
 __device__ __forceinline__ void act4_t(float v[4], const float sc[4], const float sh[4], uint32_t key, uint32_t thr, uint32_t row, int c0) {
   if (FL & 1) {
@@ -562,270 +354,6 @@ __device__ __forceinline__ void act4_t(float v[4], const float sc[4], const floa
   if (FL & 4) tn_drop4(v, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, (uint32_t)(c0 >> 2) & 1u, key, thr);
 }
 
-template <int KD, int FL>
-__global__ __launch_bounds__(512, 2) void dw_bwd_v4_kernel(DwBwdV3Args a) {
-  constexpr int PADR = (KD - 1) / 2, ROWS = 64 + KD - 1, NT = 512;
-  constexpr bool HAS_MASK = (FL & 7) != 0, HAS_ADD = (FL & 8) != 0;
-  static_assert(KD == 3, "sliding window below is written for K = 3");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* Ds = reinterpret_cast<bf16_t*>(smem);     // [ROWS][256] raw dD
-  bf16_t* Xs = Ds + ROWS * V2_C;                     // [ROWS][256] raw X
-  float* cst = reinterpret_cast<float*>(Xs + ROWS * V2_C);   // sc, sh, mean*rstd, rstd, wd[KD] : [4 + KD][256]
-  bf16_t* Ad = reinterpret_cast<bf16_t*>(cst + (4 + KD) * V2_C);   // [64][256] skip-path addend (HAS_ADD)
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, strip = tid >> 6, c0 = lane * 4;
-  const float mscale = (FL & 4) ? a.actX.inv_keep : 1.f;
-  const uint32_t dkey = tn_act_key(a.actX), dthr = a.actX.drop_thr;
-
-  if (tid < V2_C) {
-    float s = 1.f, h = 0.f, mean = 0.f, rstd = 1.f;
-    if (FL & 1) {
-      bn_scale_shift(a.actX, V2_C, tid, s, h);
-      bn_mean_rstd(a.actX, V2_C, tid, mean, rstd);
-    }
-    cst[tid] = s; cst[V2_C + tid] = h; cst[2 * V2_C + tid] = mean * rstd; cst[3 * V2_C + tid] = rstd;
-#pragma unroll
-    for (int k = 0; k < KD; ++k) cst[(4 + k) * V2_C + tid] = a.wdw[(size_t)tid * KD + k];
-  }
-  __syncthreads();
-  float sc[4], sh[4], wd[KD][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    sc[i] = cst[c0 + i]; sh[i] = cst[V2_C + c0 + i];
-#pragma unroll
-    for (int k = 0; k < KD; ++k) wd[k][i] = cst[(4 + k) * V2_C + c0 + i];
-  }
-  float gw[KD][4], gb[4], s1[4], s2[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    gb[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f;
-#pragma unroll
-    for (int k = 0; k < KD; ++k) gw[k][i] = 0.f;
-  }
-
-  constexpr int NV = (ROWS * 32 + NT - 1) / NT;   // 16-byte vectors per thread per stream
-  uint4 bd[NV], bx[NV], ba[HAS_ADD ? 4 : 1];
-  auto prefetch = [&](int tile) {                  // next tile's raw rows fly while this one is processed
-    const int raw0 = tile * 64 - PADR;
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      const int v = tid + q * NT, r = v >> 5, gr = raw0 + r;
-      const bool ok = r < ROWS && gr >= 0 && gr < a.M;
-      bd[q] = ok ? *reinterpret_cast<const uint4*>(a.dD + (size_t)gr * V2_C + (v & 31) * 8) : make_uint4(0, 0, 0, 0);
-      bx[q] = ok ? *reinterpret_cast<const uint4*>(a.X + (size_t)gr * V2_C + (v & 31) * 8) : make_uint4(0, 0, 0, 0);
-    }
-    if (HAS_ADD) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int v = tid + q * NT, gr = tile * 64 + (v >> 5);
-        ba[q] = gr < a.M ? *reinterpret_cast<const uint4*>(a.ADD + (size_t)gr * V2_C + (v & 31) * 8) : make_uint4(0, 0, 0, 0);
-      }
-    }
-  };
-  if ((int)blockIdx.x < a.ntiles) prefetch(blockIdx.x);
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    const int out0 = tile * 64, raw0 = out0 - PADR;
-    __syncthreads();
-    const int l0 = strip * 8;            // LDS row of (first output row - PADR)
-    const int g_first = raw0 + l0, g_last = g_first + 9;
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      const int v = tid + q * NT, r = v >> 5;
-      if (r < ROWS) {
-        *reinterpret_cast<uint4*>(Ds + r * V2_C + (v & 31) * 8) = bd[q];
-        *reinterpret_cast<uint4*>(Xs + r * V2_C + (v & 31) * 8) = bx[q];
-      }
-    }
-    if (HAS_ADD) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int v = tid + q * NT;
-        *reinterpret_cast<uint4*>(Ad + (v >> 5) * V2_C + (v & 31) * 8) = ba[q];
-      }
-    }
-    if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
-    __syncthreads();
-    const bool fast = g_first >= 0 && g_last < a.M && (g_first % a.T) + 9 < a.T;   // wave-uniform
-    if (fast) {
-      // ---- straight-line: every window row is a valid row of the same utterance
-      float D[3][4], A[3][4], Y[3][4];
-      uint2 rd, rx;                // raw LDS words of the row after next (loaded one row ahead)
-      auto fetch = [&](int j) {
-        rd = *reinterpret_cast<const uint2*>(Ds + (l0 + j) * V2_C + c0);
-        rx = *reinterpret_cast<const uint2*>(Xs + (l0 + j) * V2_C + c0);
-      };
-#define TN_DW4_PLACE(j, S)                                                                       \
-      {                                                                                          \
-        unpack4(rd, D[S]);                                                                       \
-        unpack4(rx, Y[S]);                                                                       \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) A[S][i] = Y[S][i];                          \
-        act4_t<FL>(A[S], sc, sh, dkey, dthr, (uint32_t)(g_first + (j)), c0);                     \
-      }
-      // one output row: window slots P (previous), C (current), N (next) are compile-time constants
-#define TN_DW4_ROW(o, P, C_, N)                                                                  \
-      {                                                                                          \
-        TN_DW4_PLACE((o) + 2, N)                                                                 \
-        fetch((o) + 3);   /* row l0+o+3 <= l0+10 < ROWS+... : in bounds of the staged tile */    \
-        float dA[4];                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
-          gb[i] += D[C_][i];                                                                     \
-          dA[i] = wd[1][i] * D[C_][i];                                                           \
-          dA[i] = fmaf(wd[0][i], D[N][i], dA[i]);                                                \
-          dA[i] = fmaf(wd[2][i], D[P][i], dA[i]);                                                \
-          gw[0][i] = fmaf(D[C_][i], A[P][i], gw[0][i]);                                          \
-          gw[1][i] = fmaf(D[C_][i], A[C_][i], gw[1][i]);                                         \
-          gw[2][i] = fmaf(D[C_][i], A[N][i], gw[2][i]);                                          \
-        }                                                                                        \
-        if (HAS_ADD) {                                                                           \
-          float ad[4];                                                                           \
-          unpack4(*reinterpret_cast<const uint2*>(Ad + (l0 + (o)) * V2_C + c0), ad);             \
-          _Pragma("unroll") for (int i = 0; i < 4; ++i) dA[i] += ad[i];                          \
-        }                                                                                        \
-        if (HAS_MASK) {                                                                          \
-          _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
-            const float m = (FL & 2) ? ((A[C_][i] > 0.f) ? mscale : 0.f) : mscale;               \
-            dA[i] *= m;                                                                          \
-            s1[i] += dA[i];                                                                      \
-            s2[i] = fmaf(dA[i], Y[C_][i], s2[i]);                                                \
-          }                                                                                      \
-        }                                                                                        \
-        uint2 ov;                                                                                \
-        ov.x = f2bf_pk(dA[0], dA[1]);                                                            \
-        ov.y = f2bf_pk(dA[2], dA[3]);                                                            \
-        *reinterpret_cast<uint2*>(a.OUT + (size_t)(out0 + l0 + (o)) * V2_C + c0) = ov;           \
-      }
-      fetch(0); TN_DW4_PLACE(0, 0)
-      fetch(1); TN_DW4_PLACE(1, 1)
-      fetch(2);
-#pragma unroll 1
-      for (int ob = 0; ob < 6; ob += 3) {     // a real loop (3 rows per trip) bounds the scheduler's appetite for registers
-        TN_DW4_ROW(ob, 0, 1, 2)
-        TN_DW4_ROW(ob + 1, 1, 2, 0)
-        TN_DW4_ROW(ob + 2, 2, 0, 1)
-      }
-      TN_DW4_ROW(6, 0, 1, 2)
-      TN_DW4_ROW(7, 1, 2, 0)
-#undef TN_DW4_ROW
-#undef TN_DW4_PLACE
-    } else {
-      // ---- boundary strips (utterance edges, first / last rows of the batch): per-row wave-uniform tests
-      float Dp[4], Dc[4], Dn[4], Ap[4], Ac[4], An[4];
-      auto load_row = [&](int l, float* Dv, float* Av) {
-        unpack4(*reinterpret_cast<const uint2*>(Ds + l * V2_C + c0), Dv);
-        unpack4(*reinterpret_cast<const uint2*>(Xs + l * V2_C + c0), Av);
-        const int gr = raw0 + l;
-        if (gr >= 0 && gr < a.M) act4_t<FL>(Av, sc, sh, dkey, dthr, (uint32_t)gr, c0);
-        else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) Av[i] = 0.f;
-        }
-      };
-      load_row(l0, Dp, Ap);
-      load_row(l0 + 1, Dc, Ac);
-#pragma unroll 1
-      for (int o = 0; o < 8; ++o) {
-        const int gr = out0 + l0 + o;
-        load_row(l0 + o + 2, Dn, An);
-        if (gr < a.M) {
-          const int t = gr % a.T;
-          float dA[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            gb[i] += Dc[i];
-            dA[i] = wd[1][i] * Dc[i];
-            gw[1][i] = fmaf(Dc[i], Ac[i], gw[1][i]);
-          }
-          if (t + 1 < a.T) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { dA[i] = fmaf(wd[0][i], Dn[i], dA[i]); gw[2][i] = fmaf(Dc[i], An[i], gw[2][i]); }
-          }
-          if (t > 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { dA[i] = fmaf(wd[2][i], Dp[i], dA[i]); gw[0][i] = fmaf(Dc[i], Ap[i], gw[0][i]); }
-          }
-          if (HAS_ADD) {
-            float ad[4];
-            unpack4(*reinterpret_cast<const uint2*>(Ad + (l0 + o) * V2_C + c0), ad);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dA[i] += ad[i];
-          }
-          if (HAS_MASK) {
-            float y[4];
-            unpack4(*reinterpret_cast<const uint2*>(Xs + (l0 + o + 1) * V2_C + c0), y);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float m = (FL & 2) ? ((Ac[i] > 0.f) ? mscale : 0.f) : mscale;
-              dA[i] *= m;
-              s1[i] += dA[i];
-              s2[i] = fmaf(dA[i], y[i], s2[i]);
-            }
-          }
-          uint2 ov;
-          ov.x = f2bf_pk(dA[0], dA[1]);
-          ov.y = f2bf_pk(dA[2], dA[3]);
-          *reinterpret_cast<uint2*>(a.OUT + (size_t)gr * V2_C + c0) = ov;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { Dp[i] = Dc[i]; Dc[i] = Dn[i]; Ap[i] = Ac[i]; Ac[i] = An[i]; }
-      }
-    }
-  }
-  // s2 was accumulated against the RAW y:  sum dA * xhat = rstd * sum dA*y - mean*rstd * sum dA   (per thread, linear)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) s2[i] = cst[3 * V2_C + c0 + i] * s2[i] - cst[2 * V2_C + c0 + i] * s1[i];
-  __syncthreads();
-  float* red = reinterpret_cast<float*>(smem);       // [8 waves][KD + 3][256]  (inside the Ds/Xs tiles; cst stays intact)
-  {
-    float* mine = red + (size_t)strip * (KD + 3) * V2_C + c0;
-#pragma unroll
-    for (int k = 0; k < KD; ++k) *reinterpret_cast<float4*>(mine + k * V2_C) = make_float4(gw[k][0], gw[k][1], gw[k][2], gw[k][3]);
-    *reinterpret_cast<float4*>(mine + KD * V2_C) = make_float4(gb[0], gb[1], gb[2], gb[3]);
-    *reinterpret_cast<float4*>(mine + (KD + 1) * V2_C) = make_float4(s1[0], s1[1], s1[2], s1[3]);
-    *reinterpret_cast<float4*>(mine + (KD + 2) * V2_C) = make_float4(s2[0], s2[1], s2[2], s2[3]);
-  }
-  __syncthreads();
-  const int rep = blockIdx.x % TN_NREP;
-  for (int i = tid; i < (KD + 3) * V2_C; i += NT) {
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) v += red[(size_t)w * (KD + 3) * V2_C + i];
-    const int k = i / V2_C, c = i % V2_C;
-    if (k <= KD) atomic_add_f32(&a.gacc[(size_t)(rep * (KD + 1) + k) * V2_C + c], v);
-    else if (a.bsumsX && HAS_MASK) atomic_add_f32(&a.bsumsX[(size_t)(rep * 2 + (k - KD - 1)) * V2_C + c], v);
-  }
-}
-
-template <int KD, int FL>
-inline int launch_dw_bwd_v4_t(DwBwdV3Args a, int grid, size_t smem, hipStream_t st) {
-  auto kern = dw_bwd_v4_kernel<KD, FL>;
-  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a);
-  return (int)hipGetLastError();
-}
-// picks the specialisation for the flag combinations the model produces; anything else runs v3
-template <int KD>
-inline int launch_dw_bwd_v4(DwBwdV3Args a, int max_wgs, hipStream_t st) {
-  a.ntiles = (a.M + 63) / 64;
-  const int grid = a.ntiles < max_wgs ? a.ntiles : max_wgs;
-  constexpr int ROWS = 64 + KD - 1;
-  const size_t smem = (size_t)2 * ROWS * V2_C * sizeof(bf16_t) + (size_t)(4 + KD) * V2_C * sizeof(float) +
-                      (a.ADD ? (size_t)64 * V2_C * sizeof(bf16_t) : 0);
-  const int fl = (a.actX.mode != 0 ? 1 : 0) | (a.actX.relu ? 2 : 0) | (a.actX.drop_thr ? 4 : 0) | (a.ADD ? 8 : 0);
-  switch (fl) {
-    case 7: return launch_dw_bwd_v4_t<KD, 7>(a, grid, smem, st);    // sub-blocks 2, 3 in training with dropout
-    case 3: return launch_dw_bwd_v4_t<KD, 3>(a, grid, smem, st);    // ... without dropout
-    case 8: return launch_dw_bwd_v4_t<KD, 8>(a, grid, smem, st);    // first sub-block: block input is stored activated; + skip gradient
-    case 11: return launch_dw_bwd_v4_t<KD, 11>(a, grid, smem, st);  // first sub-block of block 0: prolog BN + ReLU on load; + skip gradient
-    default: return launch_dw_bwd_v3<KD>(a, 2 * max_wgs, st);   // v3 runs two workgroups per CU
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// combine_bwd1_v2: pass 1 of the mega-block tail backward (combine_bwd1_kernel, tn_bwd_kernels.h) for hidden = 256, bf16:
-//   dZ = dOUT * [block output > 0] / (1 - p);  dgate[b][c] = sum_t dZ * act3(Y3);  skip-BN backward sums.
-// The mask is recomputed from Y3, S, the SE gate and the block output's dropout hash (the block output is not read back).
-// `parts` workgroups per utterance, a thread owns 8 fixed channels (constants in registers), 3 x 4 rows in flight.
-// ------------------------------------------------------------------------------------------
 struct CombineBwd1V2Args {
   const bf16_t* dOUT; const float* gate;
   const bf16_t* Y3; BnAct act3;
@@ -1480,9 +1008,9 @@ inline int launch_dgrad_v2(DgradV2Args a, int max_wgs, hipStream_t st) {
 //   dD   = BatchNorm-backward-on-load(dZ, Y) * W                    (MFMA, W^T resident in registers)
 //   dA   = sum_k w_dw[c][k] dD[r - k + pad]  (+ ADD)                  (transposed stencil over time, through LDS)
 //   OUT  = dA * d act / d bn (X)  -> stored;  BN-backward sums of the layer that made X;  d w_dw, d b_dw
-// dgrad_v2 + dw_bwd_v4 wrote dD (one rows x 256 tensor) to HBM and read it back: 6 passes per sub-block; this kernel
-// moves 4 (dZ, Y, X in, OUT out).  Both predecessors run at the rate of a plain streaming kernel, so the passes are the
-// time.  Tiles are 32 GEMM rows that yield 30 output rows (the stencil needs dD[r-1] and dD[r+1]: consecutive tiles
+// A separate data-gradient kernel + depthwise-backward kernel (round 1) wrote dD (one rows x 256 tensor) to HBM and read it
+// back: 6 passes per sub-block; this kernel moves 4 (dZ, Y, X in, OUT out).  Both predecessors ran at the rate of a plain
+// streaming kernel, so the passes are the time.  Tiles are 32 GEMM rows that yield 30 output rows (the stencil needs dD[r-1] and dD[r+1]: consecutive tiles
 // overlap by two rows, re-read from L2), small enough that the three input streams of the NEXT tile (48 KB per CU) stay in
 // flight in registers (6 x 16 bytes per thread) without spilling next to the 64 weight VGPRs.
 // FL bits: 1 = BatchNorm on load of X, 2 = ReLU, 4 = dropout, 8 = skip-path addend.
@@ -1754,7 +1282,7 @@ inline int launch_dgrad_dw_v6_t(DgradDwArgs a, int grid, size_t smem, hipStream_
   hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
   return (int)hipGetLastError();
 }
-// -1000: no specialisation for this flag combination (caller runs dgrad_v2 + dw_bwd_v4)
+// -1000: no specialisation for this flag combination
 inline int launch_dgrad_dw_v6(DgradDwArgs a, int max_wgs, hipStream_t st) {
   if (!a.Wswz) return -1000;
   a.ntiles = (a.M + V6_OUT - 1) / V6_OUT;
@@ -1770,125 +1298,4 @@ inline int launch_dgrad_dw_v6(DgradDwArgs a, int max_wgs, hipStream_t st) {
     case 11: return launch_dgrad_dw_v6_t<11>(a, grid, smem, st);
     default: return -1000;
   }
-}
-
-// ------------------------------------------------------------------------------------------
-// dgrad_wide_v2: data gradient of a 1x1 conv whose OUTPUT side is the 1536-wide tensor (the epilog conv):
-//   dX[M][256] = BatchNorm-backward-on-load(dZ, Y)[M][KW] * W^T        (K = KW = 1536 = 6 slabs of 256)
-// dgrad_v2's skeleton with a slab loop inside every 64-row tile: the accumulators live across the slabs, the
-// 256 x 256 weight slab of the NEXT step is prefetched into registers beside the current one (they stream from L2),
-// the BN-backward coefficients of all KW channels sit in LDS.  dZ / Y rows are read exactly once.
-// ------------------------------------------------------------------------------------------
-struct DgradWideArgs {
-  const bf16_t* dZ; const bf16_t* Y; BnBwd bn;     // [M][KW]
-  const bf16_t* Wt;      // [256][KW] bf16: row = input channel of the conv (output of this product), K contiguous
-  const uint4* Wswz;     // the same weights in MFMA-fragment order [KW/256 slabs][8 waves][16 k-steps][64 lanes] x 16 bytes
-  bf16_t* OUT;           // [M][256]
-  int M, KW, ntiles;
-};
-__global__ void dgrad_wide_swizzle_kernel(const bf16_t* __restrict__ Wt, int KW, uint4* __restrict__ out) {
-  const int n = (KW / V2_C) * 8 * 16 * 64;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int lane = i & 63, ks = (i >> 6) & 15, wave = (i >> 10) & 7, slab = i >> 13;
-    out[i] = *reinterpret_cast<const uint4*>(Wt + (size_t)(wave * 32 + (lane & 31)) * KW + slab * V2_C + ks * 16 + (lane >> 5) * 8);
-  }
-}
-__global__ __launch_bounds__(V2_NT, 2) void dgrad_wide_v2_kernel(DgradWideArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* Pt = reinterpret_cast<bf16_t*>(smem);      // [64][264] dY slab rows (MFMA B operand)
-  bf16_t* Dt = Pt + V2_R * V2_AP;                     // [64][264] output staging
-  float* cst = reinterpret_cast<float*>(Dt + V2_R * V2_AP);   // k0, k1, k2 : [3][KW]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-  const int vc = tid & 31, rq = tid >> 5, c0 = vc * 8;
-  const int ns = a.KW / V2_C;
-  for (int c = tid; c < a.KW; c += V2_NT) {
-    float k0, k1, k2;
-    bn_bwd_coefs(a.bn, a.KW, c, k0, k1, k2);
-    cst[c] = k0; cst[a.KW + c] = k1; cst[2 * a.KW + c] = k2;
-  }
-  const int first = blockIdx.x, stride = gridDim.x;
-  if (first >= a.ntiles) return;
-  const int nsteps = ((a.ntiles - first + stride - 1) / stride) * ns;     // (tile, slab) steps of this workgroup
-  bf16x8_t wf[16], wfn[16];
-  uint4 pz[4], py[4];
-  auto fetch = [&](int step) {            // weights of the step's slab + dZ / Y rows of its (tile, slab)
-    if (step >= nsteps) return;
-    const int tile = first + (step / ns) * stride, slab = step % ns;
-    // fragment-ordered weights (dgrad_wide_swizzle_kernel): one fully coalesced 1 KB read per wave and k-step.  Reading the
-    // fragments straight from the [256][KW] matrix touches 32 rows x 32 B per instruction and thrashes L1 (4x the L2 traffic).
-    const uint4* wsrc = a.Wswz + ((size_t)(slab * 8 + wave) * 16) * 64 + lane;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) wfn[ks] = __builtin_bit_cast(bf16x8_t, wsrc[ks * 64]);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int gr = tile * V2_R + rq + 16 * q;
-      const bool ok = gr < a.M;
-      const size_t o = (size_t)gr * a.KW + slab * V2_C + c0;
-      pz[q] = ok ? *reinterpret_cast<const uint4*>(a.dZ + o) : make_uint4(0, 0, 0, 0);
-      py[q] = ok ? *reinterpret_cast<const uint4*>(a.Y + o) : make_uint4(0, 0, 0, 0);
-    }
-  };
-  fetch(0);
-  __syncthreads();                        // constants visible
-  f32x16_t acc0, acc1;
-  for (int step = 0; step < nsteps; ++step) {
-    const int tile = first + (step / ns) * stride, slab = step % ns;
-    const int out0 = tile * V2_R;
-    __syncthreads();                      // previous step's MFMA is done with Pt (and the previous tile's Dt rows are stored)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = rq + 16 * q;
-      float z[8], y[8];
-      unpack8(pz[q], z);
-      unpack8(py[q], y);
-      if (out0 + r < a.M) {
-        const float* kk = cst + slab * V2_C + c0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) z[i] = kk[i] * z[i] + kk[a.KW + i] * y[i] + kk[2 * a.KW + i];
-      }
-      store8(Pt + r * V2_AP + c0, z);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) wf[ks] = wfn[ks];
-    fetch(step + 1);
-    __syncthreads();
-    if (slab == 0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    }
-    const bf16_t* brow = Pt + (lane & 31) * V2_AP + half * 8;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(brow + ks * 16);
-      const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(brow + 32 * V2_AP + ks * 16);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b1, acc1, 0, 0, 0);
-    }
-    if (slab == ns - 1) {                 // workgroup-uniform
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int ci = wave * 32 + 8 * g + 4 * half;
-        uint2 w0, w1;
-        w0.x = f2bf_pk(acc0[4 * g], acc0[4 * g + 1]); w0.y = f2bf_pk(acc0[4 * g + 2], acc0[4 * g + 3]);
-        w1.x = f2bf_pk(acc1[4 * g], acc1[4 * g + 1]); w1.y = f2bf_pk(acc1[4 * g + 2], acc1[4 * g + 3]);
-        *reinterpret_cast<uint2*>(Dt + (lane & 31) * V2_AP + ci) = w0;
-        *reinterpret_cast<uint2*>(Dt + (32 + (lane & 31)) * V2_AP + ci) = w1;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int o = rq + 16 * q, gr = out0 + o;
-        if (gr < a.M) *reinterpret_cast<uint4*>(a.OUT + (size_t)gr * V2_C + c0) = *reinterpret_cast<const uint4*>(Dt + o * V2_AP + c0);
-      }
-    }
-  }
-}
-inline int launch_dgrad_wide_v2(DgradWideArgs a, int max_wgs, hipStream_t st) {
-  a.ntiles = (a.M + V2_R - 1) / V2_R;
-  const int grid = a.ntiles < max_wgs ? a.ntiles : max_wgs;
-  const size_t smem = (size_t)2 * V2_R * V2_AP * sizeof(bf16_t) + (size_t)3 * a.KW * sizeof(float);
-  hipLaunchKernelGGL(dgrad_wide_swizzle_kernel, dim3(192), dim3(256), 0, st, a.Wt, a.KW, const_cast<uint4*>(a.Wswz));
-  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(dgrad_wide_v2_kernel, dim3(grid), dim3(V2_NT), smem, st, a);
-  return (int)hipGetLastError();
 }

@@ -72,205 +72,6 @@ struct SubFwdV2Args {
                         // batched weight-gradient launch reads it instead of recomputing activation + stencil (sub_fwd_v5 only)
 };
 
-template <int KD, bool DW>
-__global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v2_kernel(SubFwdV2Args a) {
-  constexpr int PADR = DW ? (KD - 1) / 2 : 0;
-  constexpr int OUTR = DW ? V2_R - (KD - 1) : V2_R;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);     // [64][264] output staging tile; its first 32 KB double as
-  bf16_t* Xa = Cs;                                  // [64][256] the activated input rows (dead once the stencil ran)
-  bf16_t* As = Cs + V2_R * V2_AP;                   // [64][264] MFMA B operand (depthwise output)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int vc = tid & 31, rq = tid >> 5;          // this thread's channel vector and row phase (rows rq + 16 q)
-  const int c0 = vc * 8;
-
-  // ---- per-thread constants: BN scale/shift and depthwise taps of the thread's 8 channels.
-  // Computed cooperatively (one channel per thread, 18 loads) and redistributed through LDS: having
-  // every thread reduce the 8 statistic replicas of its own 8 channels costs 144 gather loads per
-  // thread and dominated the kernel.
-  float sc[8], sh[8];
-  float wd[DW ? KD : 1][8], bd[8];
-  {
-    float* tmp = reinterpret_cast<float*>(As);      // scratch before the first tile: [2 + KD + 1][256]
-    if (tid < V2_C) {
-      float s, h;
-      bn_scale_shift(a.act, V2_C, tid, s, h);
-      tmp[tid] = s;
-      tmp[V2_C + tid] = h;
-      if (DW) {
-        tmp[2 * V2_C + tid] = a.bdw[tid];
-#pragma unroll
-        for (int k = 0; k < KD; ++k) tmp[(3 + k) * V2_C + tid] = a.wdw[(size_t)tid * KD + k];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      sc[i] = tmp[c0 + i];
-      sh[i] = tmp[V2_C + c0 + i];
-      if (DW) {
-        bd[i] = tmp[2 * V2_C + c0 + i];
-#pragma unroll
-        for (int k = 0; k < KD; ++k) wd[k][i] = tmp[(3 + k) * V2_C + c0 + i];
-      }
-    }
-    __syncthreads();
-  }
-  // ---- this wave's 32 output channels of W as MFMA A fragments, resident for the whole kernel.  The
-  // activation rows are the B operand, so a lane ends up with 4 CONSECUTIVE channels of one row per
-  // accumulator quad: the output tile is staged with 8-byte LDS writes (2-byte writes cost 4x more).
-  const int half = lane >> 5;
-  bf16x8_t wf[16];
-  {
-    const int co = wave * 32 + (lane & 31);
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
-      wf[ks] = *reinterpret_cast<const bf16x8_t*>(a.W + (size_t)co * V2_C + ks * 16 + half * 8);
-  }
-  float biasr[16];   // bias of this lane's 16 output channels: 32*wave + 8g + 4*half + j
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) biasr[4 * g + j] = a.bias[wave * 32 + 8 * g + 4 * half + j];
-  float st_s[8], st_q[8];   // BN statistics of this thread's 8 channels (from the staged bf16 tile)
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
-
-  uint4 pf[4];
-  auto prefetch = [&](int tile) {
-    const int raw0 = tile * OUTR - PADR;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int gr = raw0 + rq + 16 * q;
-      if (gr >= 0 && gr < a.M) pf[q] = *reinterpret_cast<const uint4*>(a.X + (size_t)gr * V2_C + c0);
-      else pf[q] = make_uint4(0, 0, 0, 0);
-    }
-  };
-  int tile = blockIdx.x;
-  if (tile < a.ntiles) prefetch(tile);
-  for (; tile < a.ntiles; tile += gridDim.x) {
-    const int out0 = tile * OUTR, raw0 = out0 - PADR;
-    __syncthreads();   // (1) previous tile's output staging (aliases Xa) has been stored
-    // ---- registers -> LDS with the activation applied once per element
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = rq + 16 * q, gr = raw0 + r;
-      float v[8];
-      unpack8(pf[q], v);
-      if (!(V2_DBG_SKIP & 8) && gr >= 0 && gr < a.M) act8_reg(v, sc, sh, a.act, (uint32_t)gr, c0);
-      if (DW) store8(Xa + r * V2_C + c0, v);
-      else store8(As + r * V2_AP + c0, v);
-    }
-    if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);   // next tile's loads fly during the rest
-    __syncthreads();   // (2)
-    if (DW) {
-      // ---- depthwise stencil over time -> MFMA operand tile.  Each thread owns 4 CONSECUTIVE output rows
-      // (a sliding window over KD + 3 activated rows: every LDS row is read and unpacked once, not KD times).
-      {
-        const int o0 = rq * 4;
-        float win[KD + 3][8];
-#pragma unroll
-        for (int j = 0; j < KD + 3; ++j) {
-          if (o0 + j < V2_R) load8(Xa + (o0 + j) * V2_C + c0, win[j]);
-          else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) win[j][i] = 0.f;
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int o = o0 + q;
-          float acc[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) acc[i] = bd[i];
-          if (!(V2_DBG_SKIP & 2) && o < OUTR) {
-            const int t = (out0 + o) % a.T;
-#pragma unroll
-            for (int k = 0; k < KD; ++k) {
-              const int tt = t + k - PADR;
-              if (tt >= 0 && tt < a.T) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = fmaf(wd[k][i], win[q + k][i], acc[i]);
-              }
-            }
-          }
-          store8(As + o * V2_AP + c0, acc);
-        }
-      }
-      __syncthreads();   // (3)
-    }
-    // ---- pointwise GEMM: [64 x 256] x W^T, weights from registers
-    f32x16_t acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const bf16_t* brow = As + (lane & 31) * V2_AP + half * 8;
-#pragma unroll
-    for (int ks = 0; ks < ((V2_DBG_SKIP & 1) ? 1 : 16); ++ks) {
-      const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(brow + ks * 16);
-      const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(brow + 32 * V2_AP + ks * 16);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b1, acc1, 0, 0, 0);
-    }
-    // ---- epilogue: lane = row (lane&31 [+32]), regs 4g..4g+3 = channels 32*wave + 8g + 4*half + 0..3
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int co = wave * 32 + 8 * g + 4 * half;
-      uint2 w0, w1;
-      w0.x = f2bf_pk(acc0[4 * g] + biasr[4 * g], acc0[4 * g + 1] + biasr[4 * g + 1]);
-      w0.y = f2bf_pk(acc0[4 * g + 2] + biasr[4 * g + 2], acc0[4 * g + 3] + biasr[4 * g + 3]);
-      w1.x = f2bf_pk(acc1[4 * g] + biasr[4 * g], acc1[4 * g + 1] + biasr[4 * g + 1]);
-      w1.y = f2bf_pk(acc1[4 * g + 2] + biasr[4 * g + 2], acc1[4 * g + 3] + biasr[4 * g + 3]);
-      *reinterpret_cast<uint2*>(Cs + (lane & 31) * V2_AP + co) = w0;
-      *reinterpret_cast<uint2*>(Cs + (32 + (lane & 31)) * V2_AP + co) = w1;
-    }
-    __syncthreads();   // (4)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int o = rq + 16 * q, gr = out0 + o;
-      if (!(V2_DBG_SKIP & 4) && o < OUTR && gr < a.M) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(Cs + o * V2_AP + c0);
-        *reinterpret_cast<uint4*>(a.Y + (size_t)gr * V2_C + c0) = raw;
-        float y[8];
-        unpack8(raw, y);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { st_s[i] += y[i]; st_q[i] = fmaf(y[i], y[i], st_q[i]); }
-      }
-    }
-  }
-  if (a.stats) {
-    // the 16 row phases hold the same channels: plain LDS stores + a short sum, then coalesced replicated atomics
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);      // [16][2][256]
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      red[(rq * 2 + 0) * V2_C + c0 + i] = st_s[i];
-      red[(rq * 2 + 1) * V2_C + c0 + i] = st_q[i];
-    }
-    __syncthreads();
-    const int rep = blockIdx.x % TN_NREP;
-    {
-      const int which = tid >> 8, c = tid & 255;
-      float v = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v += red[(r * 2 + which) * V2_C + c];
-      atomic_add_f32(&a.stats[(size_t)(rep * 2 + which) * V2_C + c], v);
-    }
-  }
-}
-
-template <int KD, bool DW>
-inline int launch_sub_fwd_v2(SubFwdV2Args a, int resident_wgs, hipStream_t st) {
-  constexpr int OUTR = DW ? V2_R - (KD - 1) : V2_R;
-  a.ntiles = (a.M + OUTR - 1) / OUTR;
-  const int grid = a.ntiles < resident_wgs ? a.ntiles : resident_wgs;
-  const size_t smem = (size_t)(2 * V2_R * V2_AP) * sizeof(bf16_t);
-  auto kern = sub_fwd_v2_kernel<KD, DW>;
-  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
-  return (int)hipGetLastError();
-}
-
-
 // activation with compile-time flags (FL bits: 1 = BatchNorm, 2 = ReLU, 4 = dropout): no uniform branches in the row loops
 template <int FL>
 __device__ __forceinline__ void act8_t(float v[8], const float sc[8], const float sh[8], uint32_t key, uint32_t thr, uint32_t row, int c0) {
@@ -285,7 +86,7 @@ __device__ __forceinline__ void act8_t(float v[8], const float sc[8], const floa
   if (FL & 4) tn_drop8(v, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, key, thr);
 }
 
-// sub_fwd_v4: sub_fwd_v2 with the activation flags as template parameters, workgroup-uniform fast paths for
+// sub_fwd_v4: persistent MFMA kernel (W resident in registers) with the activation flags as template parameters, workgroup-uniform fast paths for
 // interior tiles (no row-range tests) and single-utterance tiles (no tap-boundary tests: 79 % of the tiles at
 // T = 300), and accumulators that start from the bias.
 template <int KD, bool DW, int FL>
@@ -525,7 +326,7 @@ inline int launch_sub_fwd_v4(SubFwdV2Args a, int resident_wgs, hipStream_t st) {
     case 0: return launch_sub_fwd_v4_t<KD, DW, 0>(a, grid, smem, st);   // block input (stored activated)
     case 3: return launch_sub_fwd_v4_t<KD, DW, 3>(a, grid, smem, st);   // BN + ReLU (eval, p = 0, prolog output)
     case 7: return launch_sub_fwd_v4_t<KD, DW, 7>(a, grid, smem, st);   // BN + ReLU + dropout
-    default: return launch_sub_fwd_v2<KD, DW>(a, resident_wgs, st);
+    default: return -1000;      // no specialisation for this activation (the caller runs the generic GEMM)
   }
 }
 
@@ -985,7 +786,7 @@ inline int launch_sub_fwd_v5(SubFwdV2Args a, int resident_wgs, hipStream_t st) {
     case 0: return launch_sub_fwd_v5_t<KD, DW, 0>(a, grid, smem, st);
     case 3: return launch_sub_fwd_v5_t<KD, DW, 3>(a, grid, smem, st);
     case 7: return launch_sub_fwd_v5_t<KD, DW, 7>(a, grid, smem, st);
-    default: return launch_sub_fwd_v2<KD, DW>(a, resident_wgs, st);
+    default: return -1000;      // no specialisation for this activation (the caller runs the generic GEMM)
   }
 }
 

@@ -22,7 +22,8 @@ int main(int argc, char** argv) {
   { std::vector<float> hs(8 * 2 * C, 0.f); for (int c = 0; c < C; ++c) { hs[c] = 0.1f * M; hs[C + c] = 1.5f * M; } CK(hipMemcpy(stats, hs.data(), hs.size() * 4, hipMemcpyHostToDevice)); }
   CK(hipMemset(bs, 0, 8 * 2 * C * 4)); CK(hipMemset(gacc, 0, 8 * 4 * C * 4)); CK(hipMemset(bsx, 0, 8 * 2 * C * 4));
   uint4* swz; CK(hipMalloc(&swz, C * C * 2));
-  hipLaunchKernelGGL(dgrad_wide_swizzle_kernel, dim3(32), dim3(256), 0, 0, W, C, swz);
+  { SwzDesc hd{W, swz, C, C}; SwzDesc* dd; CK(hipMalloc(&dd, sizeof(hd))); CK(hipMemcpy(dd, &hd, sizeof(hd), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(swizzle256_kernel<0>, dim3(16, 1), dim3(256), 0, 0, dd); }
   DgradDwArgs a; memset(&a, 0, sizeof(a));
   a.bn.fstats = stats; a.bn.bsums = bs; a.bn.gamma = gamma; a.bn.inv_n = 1.f / M; a.bn.eps = 1e-5f; a.bn.batch = 1.f;
   a.Wswz = swz; a.wdw = wdw; a.gacc = gacc; a.bsumsX = bsx; a.M = M; a.T = T;

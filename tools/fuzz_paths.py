@@ -1,4 +1,4 @@
-"""Differential fuzz: the specialised bf16 kernels (TN_V2 default) vs the generic templates (TN_V2=0) on random shapes,
+"""Differential fuzz: the specialised bf16 kernels (default) vs the generic templates (TN_GENERIC=1) on random shapes,
 dropout rates, heads and modes.  Both paths share the same counter-based dropout masks, so embeddings / loss / the whole
 gradient must agree to bf16 noise.  Usage: python tools/fuzz_paths.py [n_cases] [seed]"""
 import os, sys
@@ -10,9 +10,9 @@ from titanet_amd import LOSSES, TitaNet
 
 def run(mask, cfg):
     if mask is None:
-        os.environ.pop("TN_V2", None)
+        os.environ.pop("TN_GENERIC", None)
     else:
-        os.environ["TN_V2"] = mask
+        os.environ["TN_GENERIC"] = "1"
     torch.manual_seed(cfg["wseed"])
     if cfg["head"] == "ce":
         lf = LOSSES["ce"](192, cfg["ncls"], device="cuda")

@@ -1,4 +1,4 @@
-// Timing harness for the 1536-wide decoder-side kernels (tuning tool): wide_in_v2<0/1>, wide_out_v2<256,0>, <128,0>, <128,2>, dgrad_wide_v2.
+// Timing harness for the 1536-wide decoder-side kernels (tuning tool): wide_in_v2<0/1>, wide_out_v2<256,0>, <128,0>, <128,2>.
 #include "../titanet_amd/csrc/tn_v2_wide_kernels.h"
 #include "../titanet_amd/csrc/tn_v2_bwd_kernels.h"
 #include <string.h>
@@ -54,15 +54,6 @@ int main(int argc, char** argv) {
     a.RAW = E2[0]; a.actR = act; a.bsums = bs; a.bias = nullptr;
     us = timeit([&](int i) { a.X = HID[i % NSET]; a.Y = E[i % NSET]; a.RAW = E2[i % NSET]; launch_wide_out_v2<128, 2>(a, 256, 0); });
     printf("wide_out_v2<128,2> : %7.2f us  (18.5t = %.0f MB -> %.2f TB/s)\n", us, 18.5 * t / 1e6, 18.5 * t / us / 1e6);
-  }
-  {
-    uint4* swz; CK(hipMalloc(&swz, (size_t)D * H * 2));
-    hipLaunchKernelGGL(dgrad_wide_swizzle_kernel, dim3(64), dim3(256), 0, 0, W, D, swz);
-    DgradWideArgs a; memset(&a, 0, sizeof(a));
-    a.bn.fstats = stats; a.bn.bsums = bs; a.bn.gamma = gamma; a.bn.inv_n = 1.f / M; a.bn.eps = 1e-5f; a.bn.batch = 1.f;
-    a.Wt = W; a.Wswz = swz; a.M = M; a.KW = D;
-    float us = timeit([&](int i) { a.dZ = E[i % NSET]; a.Y = E2[i % NSET]; a.OUT = O[i % NSET]; launch_dgrad_wide_v2(a, 256, 0); });
-    printf("dgrad_wide_v2      : %7.2f us  (13t = %.0f MB -> %.2f TB/s)\n", us, 13 * t / 1e6, 13 * t / us / 1e6);
   }
   return 0;
 }
