@@ -177,6 +177,113 @@ def cpu_baseline(budget_s=24.0):
             "legs": legs}
 
 
+# algorithmic FLOPs (fwd + bwd) and bf16 bytes per utterance at T = 300
+FLOPS_PER_UTT = {"s": 9.62e9, "m": 21.4e9, "l": 42.0e9}
+ELEMS_PER_FRAME = {"m": (1 + 10 * 5) * 512 + 1536, "l": (1 + 5 * 5) * 1024 + 1536}     # inter-kernel tensor elements per frame
+MFMA_PEAK_BF16 = 2.5e15        # dense (MI355X_MICROARCH.md)
+
+
+def _timed_steps(fn, warm, steps):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def other_configs(dev):
+    """BASELINE.json configs[2..4] as bounded legs OUTSIDE the headline's timed region (rank 0, one GPU): ms per step,
+    utterances/s, the governing roofline of SURVEY.md 8(d) and the MFMA utilisation FLOPs x utt/s / 2.5 PFLOP/s (bf16 dense)."""
+    import random
+    from titanet_amd import LOSSES, TitaNet
+    from titanet_amd.trainer import Trainer
+    from titanet_amd.transforms import MelSpectrogram
+    out = {}
+    n_classes = 251
+
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:      # a leg must never take the headline line down with it
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        torch.cuda.empty_cache()
+
+    def fixed(size, nb, prec, head, B=256, T=300, steps=8):
+        loss = LOSSES["ce"](192, n_classes, device=dev) if head == "ce" else LOSSES["arc"](192, n_classes, device=dev, scale=30, margin=0.2)
+        m = TitaNet.get_titanet(n_mega_blocks=nb, model_size=size, loss_function=loss, dropout=0.1, device=dev, precision=prec).train()
+        tr = Trainer(m)
+        g = torch.Generator().manual_seed(7)
+        x = (torch.randn(B, 80, T, generator=g) * 0.11 - 0.10).to(dev)
+        y = torch.randint(0, n_classes, (B,), generator=g).to(dev)
+        dt = _timed_steps(lambda: tr.step(x, y), 3, steps)
+        ups = B / dt
+        r = {"workload": f"TitaNet-{size.upper()}/{nb} fwd+bwd+Adam, {head} head, batch {B}, 80x{T}, {prec}", "ms_per_step": round(dt * 1e3, 3),
+             "utt_per_s": round(ups, 1), "mfma_util": round(FLOPS_PER_UTT[size] * ups / MFMA_PEAK_BF16, 4)}
+        if size == "l":
+            r.update({"bound": "mfma", "frac": r["mfma_util"], "peak_TFLOPs": MFMA_PEAK_BF16 / 1e12,
+                      "note": "8(d): L is MFMA-bound in bf16; the fp8 plan runs the forward pointwise GEMMs on the f8f6f4 MFMA, the rest in bf16"})
+        else:
+            nbytes = {"s": ALG_BYTES_PER_UTT_BF16, "m": ELEMS_PER_FRAME["m"] * 300 * 10.0}[size]
+            r.update({"bound": "hbm", "frac": round(nbytes * ups / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_MB_per_utt": round(nbytes / 1e6, 2)})
+        return r
+
+    def ragged_m():
+        # configs[3]: TitaNet-M, waveforms of U(2, 20) s at 16 kHz -> on-GPU mel + SpecAugment (time stretch, 1 freq + 1 time
+        # mask, parameters.yml:79-107) -> zero-padded batch + lengths -> masked train step
+        B, sr, hop = 32, 16000, 160
+        rnd = random.Random(3)
+        g = torch.Generator().manual_seed(3)
+        nsamp = [int(rnd.uniform(2.0, 20.0) * sr) for _ in range(B)]
+        A = max(nsamp)
+        wav = torch.zeros(B, A)
+        for b, n in enumerate(nsamp):
+            wav[b, :n] = torch.randn(n, generator=g) * 0.05
+        wav = wav.to(dev)
+        mel = MelSpectrogram(sr, n_fft=512, win_length=400, hop_length=hop, n_mels=80, device=dev)
+        rates = [rnd.uniform(0.95, 1.05) for _ in range(B)]
+        frames = [mel.n_frames(n, r) for n, r in zip(nsamp, rates)]
+        T = max(frames)
+        fm = torch.zeros(B, 80, dtype=torch.bool)
+        tm = torch.zeros(B, T, dtype=torch.bool)
+        for b in range(B):
+            f0 = rnd.randrange(0, 80 - 20); fm[b, f0:f0 + rnd.randrange(1, 28)] = True
+            t0 = rnd.randrange(0, max(1, frames[b] - 10)); tm[b, t0:t0 + rnd.randrange(1, max(2, int(0.15 * frames[b])))] = True
+        loss = LOSSES["ce"](192, n_classes, device=dev)
+        m = TitaNet.get_titanet(n_mega_blocks=10, model_size="m", loss_function=loss, dropout=0.1, device=dev, precision="bf16").train()
+        tr = Trainer(m)
+        y = torch.randint(0, n_classes, (B,), generator=g).to(dev)
+        ln = torch.tensor(frames, dtype=torch.int64)
+
+        def step():
+            x = mel.batch(wav, lengths=nsamp, rates=rates, freq_masks=fm, time_masks=tm)
+            tr.step(x, y, lengths=ln)
+        dt = _timed_steps(step, 2, 5)
+        valid = sum(frames)
+        nbytes = ELEMS_PER_FRAME["m"] * valid * 10.0
+        flops = FLOPS_PER_UTT["m"] * valid / 300.0
+        return {"workload": f"TitaNet-M/10, {B} waveforms of U(2,20) s -> GPU mel + SpecAugment -> padded [B,80,{T}] + lengths -> masked fwd+bwd+Adam, bf16",
+                "ms_per_step": round(dt * 1e3, 3), "utt_per_s": round(B / dt, 1), "audio_s_per_s": round(sum(nsamp) / sr / dt, 1),
+                "valid_frames": valid, "padded_frames": B * T, "bound": "hbm", "frac": round(nbytes / dt / 1e9 / HBM_PEAK_GBS, 4),
+                "mfma_util": round(flops / dt / MFMA_PEAK_BF16, 4), "includes": "mel front end + SpecAugment inside the step"}
+
+    leg("s17_arcface_b256", lambda: fixed("s", 17, "bf16", "arc"))
+    leg("m10_ragged_mel_specaug_masked", ragged_m)
+    leg("m10_b256", lambda: fixed("m", 10, "bf16", "ce", steps=6))
+    leg("l5_fp8_b256", lambda: fixed("l", 5, "fp8", "ce", steps=5))
+    leg("l5_bf16_b256", lambda: fixed("l", 5, "bf16", "ce", steps=5))
+    return out
+
+
+def _spawn_entry(local_rank, argv, world, port):
+    os.environ.update({"RANK": str(local_rank), "LOCAL_RANK": str(local_rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    sys.argv = argv
+    main()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,28 +293,50 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--loss", default="ce", choices=["ce", "arc"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the bounded legs of BASELINE configs[2..4]")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the streaming-ceiling microbenchmark (PMC passes: keeps foreign kernels out of the counters)")
     ap.add_argument("--prof-class", type=int, default=0, help="kernel class timed with HIP events in the timed region (0 = the dominant one)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo for single-GPU smoke tests)")
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--grad-groups", type=int, default=2, help="gradient buckets of mega blocks for the overlapped all-reduce (N > 1)")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU execution path for the product)")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # launched as a plain `python bench.py --gpus N`: start the N ranks here (one process per GPU, RCCL)
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and not args.same_device:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} device(s) visible — refusing to report a {args.gpus}-GPU line")
+        import socket
+        import torch.multiprocessing as mp
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        mp.spawn(_spawn_entry, args=(sys.argv, args.gpus, port), nprocs=args.gpus, join=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU execution path for the product)")
+    if world != args.gpus:
+        raise SystemExit(f"launched with WORLD_SIZE={world} but --gpus {args.gpus}")
     if args.same_device:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} device(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=args.backend)
-    assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+        probe = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(probe)                    # a real collective before anything is timed
+        rccl_ranks = int(round(float(probe.item())))
+        assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, dist.get_world_size(), world)
 
     from titanet_amd import LOSSES, TitaNet
     from titanet_amd.trainer import Trainer
@@ -220,7 +349,7 @@ def main():
         loss = LOSSES["arc"](192, n_classes, device=dev, scale=30, margin=0.2)      # parameters.yml:42-44
     model = TitaNet.get_titanet(embedding_size=192, n_mels=80, n_mega_blocks=17, model_size="s", attention_hidden_size=128,
                                 loss_function=loss, dropout=0.1, device=dev, precision=args.precision).train()
-    trainer = Trainer(model, lr=1e-3)
+    trainer = Trainer(model, lr=1e-3, n_buckets=args.grad_groups)
     g = torch.Generator(device="cpu").manual_seed(42 + rank)       # per-rank shard of the synthetic global batch
     x = (torch.randn(args.batch, 80, T, generator=g) * 0.11 - 0.10).to(dev)
     y = torch.randint(0, n_classes, (args.batch,), generator=g).to(dev)
@@ -256,16 +385,24 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         emb, preds, lv = trainer.step(x, y)
+    torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0            # this rank's own clock (spread across ranks reported below)
     barrier()
     dt = time.perf_counter() - t0
     ms, cnt = C.c_double(), C.c_int64()
     lib.tn_profile_read(plan.handle, C.byref(ms), C.byref(cnt))
     lib.tn_profile_begin(plan.handle, 0)
     lib.tn_profile_sample(plan.handle, 1)
+    rank_ms = [dt_rank / args.steps * 1e3]
     if world > 1:
-        tt = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        cdev = dev if args.backend == "nccl" else "cpu"
+        tt = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        mine = torch.tensor([dt_rank / args.steps * 1e3], device=cdev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_ms = [float(t.item()) for t in allr]
     loss_value = float(lv.item())
 
     if rank == 0:
@@ -286,7 +423,8 @@ def main():
         step_alg = ALG_BYTES_PER_UTT_BF16 * (esz / 2) * args.batch          # per GPU
         achieved = step_alg / step_s / 1e9
         k_traffic, s_traffic, src = pmc_traffic(dom) if headline else (None, None, None)
-        ceil = {"cold": float("nan"), "hot": float("nan")} if args.no_ceiling else stream_ceiling(dev)
+        ceil = {"cold": None, "hot": None} if args.no_ceiling else stream_ceiling(dev)
+        rnd = lambda v, n=1: None if v is None else round(v, n)
         out = {
             "metric": "utterances/sec TitaNet-S fwd+bwd (80-mel x 300f)",
             "value": round(value, 1),
@@ -302,16 +440,19 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"TitaNet-S/17 fwd+bwd+Adam, {args.loss.upper()}-251 head, batch {args.batch}/GPU, 80x300 (BASELINE configs[1])",
                        "global_batch": args.batch * world, "frames": T, "parallelism": f"dp{world}", "dropout": 0.1,
-                       "loss": loss_value},
+                       "loss": loss_value, "rccl_ranks": rccl_ranks, "backend": args.backend if world > 1 else None,
+                       "grad_groups": args.grad_groups if world > 1 else 1,
+                       "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)}},
             "roofline": {
                 "bound": "hbm", "scope": "whole step: SURVEY.md 8(d) algorithmic bytes / step time (per GPU)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_step": int(step_alg),
+                "mfma_util": round(FLOPS_PER_UTT["s"] * (args.batch / step_s) / MFMA_PEAK_BF16, 4),
                 "traffic": s_traffic, "traffic_source": src,
                 "traffic_ratio": round(s_traffic / step_alg, 3) if s_traffic else None,
-                "stream_ceiling": {"cold_GBps": round(ceil["cold"], 1), "hot_GBps": round(ceil["hot"], 1),
+                "stream_ceiling": {"cold_GBps": rnd(ceil["cold"]), "hot_GBps": rnd(ceil["hot"]),
                                    "what": "2 reads + 1 write over 39.3 MB bf16 tensors, plain element-wise kernel, this run"},
-                "frac_of_cold_stream_ceiling": round(achieved / ceil["cold"], 4),
+                "frac_of_cold_stream_ceiling": rnd(achieved / ceil["cold"], 4) if ceil["cold"] else None,
                 "moved_GBps": round(s_traffic / step_s / 1e9, 1) if s_traffic else None,
                 "dominant_kernel": {
                     "class": PROF_CLASSES[dom], "name": PROF_KERNELS[dom], "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt.value,
@@ -321,10 +462,15 @@ def main():
                     "traffic_per_launch": k_traffic},
                 "class_ms_per_step": {PROF_CLASSES[k]: round(v[0], 3) for k, v in cls_ms.items()}},
         }
+        del trainer, model
+        torch.cuda.empty_cache()
+        if world == 1 and not args.no_other_configs:
+            out["other_configs"] = other_configs(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

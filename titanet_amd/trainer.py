@@ -118,10 +118,11 @@ class Trainer:
                 model.grad_groups = n_buckets
                 model._drop_plans()
 
-    def forward_backward(self, spectrograms, speakers):
-        """forward + backward into the flat gradient buffer; returns (embeddings, preds, loss)."""
+    def forward_backward(self, spectrograms, speakers, lengths=None):
+        """forward + backward into the flat gradient buffer; returns (embeddings, preds, loss).  ``lengths``: valid frames
+        per utterance of a zero-padded batch (collate_fn's second output): the padding mask of ``TitaNet.forward``."""
         m = self.model
-        emb, preds, loss, plan = m._native_forward(spectrograms, speakers)
+        emb, preds, loss, plan = m._native_forward(spectrograms, speakers, lengths=lengths)
         dev = emb.device
         stream = torch.cuda.current_stream(dev).cuda_stream
         vp = C.c_void_p
@@ -140,10 +141,10 @@ class Trainer:
                                   self.eps, self.weight_decay, self.step_count, 1.0 / self.reducer.world, vp(stream)),
               "tn_adam_step")
 
-    def step(self, spectrograms, speakers):
-        if self.use_graph:
+    def step(self, spectrograms, speakers, lengths=None):
+        if self.use_graph and lengths is None:
             return self._graph_step(spectrograms, speakers)
-        out = self.forward_backward(spectrograms, speakers)
+        out = self.forward_backward(spectrograms, speakers, lengths=lengths)
         grads = self.model.flat_gradients()
         if grads.is_cuda and len(self._last_plan.buckets) > 1:
             self.reducer.all_reduce_overlapped_(grads, self._last_plan, self.model._lib)
