@@ -48,6 +48,27 @@ def test_layout_is_reference_state_dict(loss):
         assert p.untyped_storage().data_ptr() == base.untyped_storage().data_ptr(), n
 
 
+@pytest.mark.parametrize("name,kw,loss", [
+    ("s2_none", dict(n_mega_blocks=2, model_size="s"), None),
+    ("s2_ce251", dict(n_mega_blocks=2, model_size="s"), "ce"),
+    ("s2_arc251", dict(n_mega_blocks=2, model_size="s"), "arc"),
+    ("m1_none", dict(n_mega_blocks=1, model_size="m"), None),
+    ("l1_none", dict(n_mega_blocks=1, model_size="l"), None),
+    ("s1_simple_pool", dict(n_mega_blocks=1, model_size="s", simple_pool=True), None)])
+def test_state_dict_keys_match_the_reference_listing(name, kw, loss):
+    """key ORDER, shapes and dtypes against tests/golden/state_dict_keys.json, listed from the reference's own
+    ``TitaNet.get_titanet(...).state_dict()`` by tests/golden/make_state_dict_keys.py (a checkpoint written by the reference
+    loads key for key; torch.save keeps the order)"""
+    import json
+    import os
+    from titanet_amd import LOSSES, TitaNet
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "state_dict_keys.json")))[name]
+    lf = None if loss is None else (LOSSES["ce"](192, 251) if loss == "ce" else LOSSES["arc"](192, 251, scale=30, margin=0.2))
+    sd = TitaNet.get_titanet(loss_function=lf, **kw).state_dict()
+    got = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]
+    assert got == want
+
+
 def test_simple_pool_layout_is_reference_state_dict():
     """Decoder(simple_pool=True), reference src/models.py:497-502: keys decoder.pool.2.{weight,bias}, no pool BatchNorm"""
     from titanet_amd import TitaNet

@@ -2,6 +2,7 @@
 HIP path and the loss goes down (the reference's own 'can it overfit' smoke idea, src/train.py:59-60)."""
 import os
 
+import numpy as np
 import pytest
 import torch
 import yaml
@@ -36,8 +37,8 @@ def test_yaml_driven_training_reduces_loss(tmp_path):
     assert hist[-1][1] < hist[0][1] * 0.7, hist            # overfits a fixed batch
     ck = tmp_path / "ck" / "epoch_1.pth"
     train.save_checkpoint(model, trainer, 1, str(ck))
-    d = torch.load(ck)
-    assert set(d) == {"model", "optimizer", "lr_scheduler", "epoch"}
+    d = torch.load(ck, weights_only=True)            # tensors, numbers and plain containers only
+    assert set(d) == {"model", "optimizer", "lr_scheduler", "epoch", "dropout_stream"}      # the reference's four keys + the dropout stream position
     assert "encoder.prolog.conv_block.0.weight" in d["model"] and "loss_function.fc.weight" in d["model"]
 
 
@@ -274,3 +275,53 @@ def test_margin_head_at_the_cos_clamp_vs_reference_golden(name):
     den = torch.exp(num) + expo.sum(1) - expo.gather(1, yt)[:, 0]
     (-(num - torch.log(den + kw["eps"])).mean()).backward()
     assert rel_err(gx, xo.grad.numpy()) < 1e-4 and rel_err(gw, wn.grad.numpy()) < 1e-4
+
+
+def test_resume_from_a_checkpoint_written_by_the_reference():
+    """tests/golden/ref_checkpoint_tiny.pth was written by the REFERENCE's model + torch.optim.Adam in the reference's
+    layout (src/learn.py:188-195) after two of its own train steps; ref_checkpoint_next.npz holds its parameters after the
+    third step on the same deterministic batch (tests/golden/make_reference_checkpoint.py).  Loading it here (weights_only)
+    and running ONE fused step must land on the reference's third-step parameters: key-for-key state_dict compatibility,
+    Adam moments / step count taken over, same arithmetic."""
+    import os
+    from tests.golden.cases import CASES
+    from tests.test_forward_gpu import build
+    from tests.util import case_inputs
+    from titanet_amd import train
+    from titanet_amd.trainer import Trainer
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    case = CASES["tiny_k3"]
+    m = build(case, "ce").train()
+    tr = Trainer(m, lr=123.0)                  # overwritten by the checkpoint's param group
+    epoch, sched = train.load_checkpoint(m, tr, os.path.join(gold, "ref_checkpoint_tiny.pth"))
+    assert epoch == 2 and sched == {} and tr.step_count == 2 and abs(tr.lr - 1e-3) < 1e-12
+    ck = torch.load(os.path.join(gold, "ref_checkpoint_tiny.pth"), weights_only=True)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ck["model"].keys())
+    for k, v in ck["model"].items():
+        assert torch.equal(sd[k].cpu(), v), k
+    x, y = case_inputs(case, torch.float32)
+    _, _, loss = tr.step(x.cuda(), y.cuda())
+    torch.cuda.synchronize()
+    nxt = np.load(os.path.join(gold, "ref_checkpoint_next.npz"))
+    assert abs(float(loss) - float(nxt["loss"])) < 2e-4 * abs(float(nxt["loss"])) + 1e-5
+    sd = m.state_dict()
+    # a bias in front of a BatchNorm has a TRUE gradient of zero: both implementations hand Adam rounding noise there, and
+    # Adam turns noise into steps of +-lr whatever its size — those tensors may differ by up to 2 lr; everything else
+    # must agree to float32 rounding amplified by 1/sqrt(v)
+    zero_grad = (".conv_block.0.bias", ".conv.0.bias", ".conv.1.bias", "skip_connection.0.bias", "decoder.linear.0.bias",
+                 "decoder.pool.0.out_linear.bias")      # (the last: a per-channel constant cancels in the softmax over time)
+    worst, worst_k = 0.0, None
+    for k in sd:
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(nxt[k]) == 3, k
+            continue
+        a, b = sd[k].float().cpu().numpy(), nxt[k]
+        if k.endswith(zero_grad):
+            assert float(np.abs(a - b).max()) <= 2.1e-3, k
+            continue
+        e = float(np.abs(a - b).max() / (np.abs(b).max() + 1e-6))
+        if e > worst:
+            worst, worst_k = e, k
+    print("worst relative parameter / buffer difference after the resumed step", worst, worst_k)
+    assert worst < 2e-3, (worst, worst_k)

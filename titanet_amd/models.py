@@ -119,7 +119,7 @@ class TitaNet(nn.Module):
         self._seed_base = int(torch.initial_seed()) & 0xFFFFFFFFFFFF
         self._opt_state = None
         import os
-        self.grad_groups = int(os.environ.get("TN_GRAD_GROUPS", "1"))   # > 1: tn_backward finalises the gradient in 1 + grad_groups buckets (data-parallel overlap)
+        self.grad_groups = 1   # > 1 (set by the data-parallel Trainer): tn_backward finalises the gradient in 1 + grad_groups buckets (data-parallel overlap)
 
         # ---- flat storage + mirrored module tree
         dev = torch.device(device)
