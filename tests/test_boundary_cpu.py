@@ -130,3 +130,15 @@ def test_reference_assertions():
     m = TitaNet.get_titanet(n_mega_blocks=1, model_size="s")
     with pytest.raises(AssertionError, match="Loss function should not be None in training mode"):
         m(torch.zeros(2, 80, 50), speakers=torch.zeros(2, dtype=torch.int64))
+
+
+def test_hot_path_kernels_do_not_spill():
+    """tools/resource_usage.py --check: compiles the HIP sources with -Rpass-analysis=kernel-resource-usage (cross-compiles
+    without a GPU) and fails on spilled VGPRs in the specialised / pipelined kernels beyond the documented exceptions"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "resource_usage.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "pgemm_nt_kernel" in r.stdout and "dgrad_dw_v6_kernel" in r.stdout

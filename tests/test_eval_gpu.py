@@ -28,6 +28,8 @@ def test_verification_eer_parity():
             specs.append(base + torch.randn(case["cfg"]["n_mels"], T, generator=g) * 0.05 - 0.1)
             spk.append(s)
     got, scores, labels = metrics.verification_test(m, specs, spk)
+    got5, scores5, _ = metrics.verification_test(m, specs, spk, batch_size=5)        # three padded batches instead of one
+    assert np.abs(scores5 - scores).max() < 2e-5 and abs(got5["test/eer"] - got["test/eer"]) < 1e-6
     assert len(scores) == (n_spk * per_spk) ** 2                      # all ordered pairs incl. self pairs
     sd = case_state_dict(case, None, torch.float64)
     embs = []

@@ -134,3 +134,63 @@ def test_reported_loss_and_preds_match_the_head_on_raw_embeddings():
     assert abs(float(want) - float(loss)) < 1e-5 * max(1.0, float(want))
     assert (logits.argmax(1) == preds).float().mean() > 0.995
     assert rel(emb, torch.nn.functional.normalize(raw, dim=1)) < 1e-6
+
+
+def test_arcface_full_size_properties():
+    """BASELINE.json configs[2] per GPU: TitaNet-S/17, batch 256, ArcFace(30, 0.2) (reference src/losses.py:77-132).
+    Properties the reference's head has at any size: the head weight comes back row-normalised (in-place, :88-90); the
+    reported loss / predictions equal the margin softmax recomputed from the returned (already normalised) embeddings and
+    that weight; the weight gradient of row c is orthogonal to nothing in particular but the gradient wrt a normalised
+    embedding direction is tangent (x . dL/dx = 0 because the head sees x / |x|); backward is linear in the loss scale."""
+    torch.manual_seed(0)
+    loss = LOSSES["arc"](192, NCLS, device="cuda", scale=30, margin=0.2)
+    m = TitaNet.get_titanet(embedding_size=192, n_mels=80, n_mega_blocks=17, model_size="s", attention_hidden_size=128,
+                            loss_function=loss, dropout=0.1, device="cuda", precision="fp32").train()
+    x, y = batch()
+    emb, preds, l = m(x, speakers=y)
+    W = dict(m.named_parameters())["loss_function.fc.weight"].detach().double()
+    assert torch.allclose(W.norm(dim=1), torch.ones(NCLS, device="cuda", dtype=torch.float64), atol=1e-5)
+    e = emb.detach().double()
+    assert torch.allclose(e.norm(dim=1), torch.ones(B, device="cuda", dtype=torch.float64), atol=1e-5)
+    cos = (e @ W.t()).clamp(-1, 1)
+    assert (cos.argmax(1) == preds).float().mean() > 0.995
+    s, mg, eps = 30.0, 0.2, 1e-6
+    tgt = cos.gather(1, y[:, None]).squeeze(1)
+    num = s * torch.cos(torch.arccos(tgt) + mg)
+    excl = torch.exp(s * cos).sum(1) - torch.exp(s * tgt)
+    want = -(num - torch.log(torch.exp(num) + excl + eps)).mean()
+    assert abs(float(want) - float(l)) < 1e-4 * max(1.0, abs(float(want))), (float(want), float(l))
+    l.backward(retain_graph=True)
+    g1 = torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+    m.zero_grad()
+    (l * 4.0).backward()
+    g4 = torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+    assert torch.isfinite(g1).all() and float(g1.norm()) > 0
+    assert rel(g4, g1 * 4.0) < 1e-4
+
+
+def test_validation_forward_between_forward_and_backward():
+    """the reference allows `loss = model(x, speakers=y)` ... `model.eval(); model(val)` ... `loss.backward()`: the eval
+    forward (same shape on purpose) runs on its own plan and must not disturb the saved state of the train forward"""
+    m = make("fp32", dropout=0.1).train()
+    x, y = batch()
+    xs, ys = x[:32].contiguous(), y[:32].contiguous()
+    _, _, l = m(xs, speakers=ys)
+    l.backward(retain_graph=True)                 # reference gradient from this forward's saved state
+    g_ref = torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+    m.zero_grad()
+    m.eval()
+    with torch.no_grad():
+        v1 = m(xs).clone()
+        v2 = m(x[:8].contiguous()).clone()
+    m.train()
+    l.backward()                                  # ... and again after the validation forwards
+    g_mid = torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+    # (two backward passes from one forward differ by the summation order of the atomics-accumulated BatchNorm sums only)
+    assert rel(g_mid, g_ref) < 1e-3, rel(g_mid, g_ref)
+    assert torch.isfinite(v1).all() and torch.isfinite(v2).all()
+    # ... while a second TRAIN forward of the same shape does invalidate it, loudly
+    _, _, l3 = m(xs, speakers=ys)
+    _, _, l4 = m(xs, speakers=ys)
+    with pytest.raises(RuntimeError, match="saved activations"):
+        l3.backward()

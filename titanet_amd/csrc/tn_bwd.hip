@@ -603,10 +603,8 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
         BnAct asin = j > 0 ? make_act(p, mb.sub[j - 1].bn, M, 1, 1, pd, 0, 0) : actx;
         for (int po = 0; po < hs; ++po)
           for (int qo = 0; qo < hs; ++qo) {
-            if (p->save_q)   // the forward kept the depthwise output: a plain operand, no activation / stencil recompute
-              add(bw.dY[j], bw.Y[j], mb.sub[j].bn, H, (const void*)(p->ws + bw.Q[j]), identity_act(), H, 0, -1, -1, mb.sub[j].wpw, po, qo);
-            else
-              add(bw.dY[j], bw.Y[j], mb.sub[j].bn, H, sin, asin, H, i * (nsub + 1) + j - 1, mb.sub[j].wdw, mb.sub[j].bdw, mb.sub[j].wpw, po, qo);
+            // the forward kept the depthwise output: a plain operand, no activation / stencil recompute
+            add(bw.dY[j], bw.Y[j], mb.sub[j].bn, H, (const void*)(p->ws + bw.Q[j]), identity_act(), H, 0, -1, -1, mb.sub[j].wpw, po, qo);
           }
       }
     }
@@ -640,6 +638,8 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
                   p->grads + m->asp_win + (int64_t)s * 256, D, A | (256 << 16));
     }
     if ((int)wd.size() != p->wg2_layers) return TN_E_STATE;
+    for (const auto& d : wd)
+      if (d.actX.drop_thr || d.wdw) return TN_E_STATE;      // the launch has no dropout-hashing / depthwise-recompute variant
     if (sizeof(WgradV2Desc) > 256 || sizeof(WgradV2Out) > 32) return TN_E_STATE;
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_desc, wd.data(), wd.size() * sizeof(WgradV2Desc), hipMemcpyHostToDevice, st));
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_out, wo.data(), wo.size() * sizeof(WgradV2Out), hipMemcpyHostToDevice, st));

@@ -229,8 +229,8 @@ __global__ __launch_bounds__(V2_NT, 2) void wgrad_batched_v2_kernel(const WgradV
     const int layer = unit / chunks_per_layer;
     const int chunk0 = unit % chunks_per_layer;
     const int nchunks = min(chunks_per_layer - chunk0, unit_end - unit);
-    WgradV2Desc d = descs[layer];
-    if (d.actX.drop_thr) d.actX.drop_key = tn_layer_key(seed, (uint32_t)d.drop_layer);
+    const WgradV2Desc& d = descs[layer];        // read field by field (scalar loads): a by-value copy of the 200-byte
+                                                // descriptor lived in scratch (the kernel's "93 spilled VGPRs")
     const bool dw = ALLOW_DW && d.wdw != nullptr;
     __syncthreads();
     if (tid < V2_C) {
@@ -267,11 +267,11 @@ __global__ __launch_bounds__(V2_NT, 2) void wgrad_batched_v2_kernel(const WgradV
           }
         }
       } else {
-        switch (fl) {
-          case 0: wg2_chunks<KD, false, 0>(d, sg, acc); break;
-          case 3: wg2_chunks<KD, false, 3>(d, sg, acc); break;
-          default: wg2_chunks<KD, false, -1>(d, sg, acc); break;
-        }
+        // operands of this launch: stored tensors used as they are (kept depthwise outputs, activated block inputs, the
+        // attention hidden layer) or BatchNorm + ReLU of a raw tensor (prolog output, epilog output); a dropout-hashing
+        // variant is not instantiated (it cost the whole kernel its register allocation)
+        if (fl == 0) wg2_chunks<KD, false, 0>(d, sg, acc);
+        else wg2_chunks<KD, false, 3>(d, sg, acc);
       }
     }
     // ---- partial slab of this (layer, segment)
@@ -283,17 +283,19 @@ __global__ __launch_bounds__(V2_NT, 2) void wgrad_batched_v2_kernel(const WgradV
     if (tid == 0) reinterpret_cast<int*>(cst)[0] = part;
     __syncthreads();
     part = reinterpret_cast<int*>(cst)[0];
+    // buffer stores: ONE per-lane offset register + a scalar offset per accumulator register (128 precomputed 64-bit
+    // addresses were hoisted out of the unit loop and lived in scratch: the kernel's "93 spilled VGPRs")
     float* slab = d.slabs + (size_t)part * V2_C * V2_C;
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(slab, 0, V2_C * V2_C * (int)sizeof(float), 0x00020000);
+    const int voff = ((wa * 128 + 4 * (lane >> 5)) * V2_C + wb * 64 + (lane & 31)) * (int)sizeof(float);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = wa * 128 + i * 32 + cd_row(r, lane);
-          const int ci = wb * 64 + j * 32 + (lane & 31);
-          slab[(size_t)co * V2_C + ci] = acc[i][j][r];
-        }
+        for (int r = 0; r < 16; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), srd, voff,
+                                                ((i * 32 + (r & 3) + 8 * (r >> 2)) * V2_C + j * 32) * (int)sizeof(float), 0);
     unit += nchunks;
   }
 }

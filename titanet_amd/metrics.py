@@ -72,19 +72,26 @@ def get_test_metrics(scores, labels, mindcf_p_target=1e-2, mindcf_c_fa=1, mindcf
 
 
 @torch.no_grad()
-def verification_test(model, spectrograms, speakers, mindcf_p_target=1e-2, mindcf_c_fa=1, mindcf_c_miss=1):
+def verification_test(model, spectrograms, speakers, mindcf_p_target=1e-2, mindcf_c_fa=1, mindcf_c_miss=1, batch_size=64):
     """``learn.test`` (reference src/learn.py:409-459) without its 200x redundant forward passes:
-    every utterance is embedded ONCE (eval mode, B = 1, its own length, as the reference does per pair),
-    then all ordered pairs including self-pairs (itertools.product(indices, repeat=2),
-    src/datasets.py:171-183) are scored with the cosine similarity of the L2-normalised embeddings.
+    every utterance is embedded ONCE, ``batch_size`` utterances per forward: the batch is zero-padded to its longest
+    utterance and run with the padding mask (``lengths=``), which makes every row equal to that utterance embedded on
+    its own (eval mode: running statistics; tests/test_mask_gpu.py) — what the reference computes with B = 1 per pair.
+    Then all ordered pairs including self-pairs (itertools.product(indices, repeat=2), src/datasets.py:171-183) are scored
+    with the cosine similarity of the L2-normalised embeddings.
     spectrograms: list of [n_mels, T_i] or [1, n_mels, T_i] tensors; speakers: list of ids."""
     was_training = model.training
     model.eval()
     dev = model.flat_parameters().device
+    specs = [(s[0] if s.dim() == 3 else s) for s in spectrograms]
     embs = []
-    for s in spectrograms:
-        x = s if s.dim() == 3 else s.unsqueeze(0)
-        embs.append(model(x.to(dev)))
+    for lo in range(0, len(specs), batch_size):
+        chunk = specs[lo:lo + batch_size]
+        lens = torch.tensor([int(s.shape[-1]) for s in chunk], dtype=torch.int64)
+        x = torch.zeros(len(chunk), chunk[0].shape[0], int(lens.max()), dtype=torch.float32, device=dev)
+        for i, s in enumerate(chunk):
+            x[i, :, :s.shape[-1]] = s.to(device=dev, dtype=torch.float32)
+        embs.append(model(x, lengths=lens) if len(set(lens.tolist())) > 1 else model(x))
     model.train(was_training)
     e = torch.cat(embs, dim=0)
     e = e / e.norm(dim=1, keepdim=True).clamp(min=1e-8)       # F.cosine_similarity eps

@@ -41,6 +41,7 @@ def _ptr(t):
 class _Plan:
     def __init__(self, handle, workspace, key):
         self.handle, self.workspace, self.key = handle, workspace, key
+        self.generation = 0          # forwards run on this plan (a backward belongs to exactly one of them)
 
 
 class _TitaNetFunction(torch.autograd.Function):
@@ -49,7 +50,7 @@ class _TitaNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spectrograms, anchor, module, speakers, lengths=None):
         emb, preds, loss, plan = module._native_forward(spectrograms, speakers, lengths=lengths)
-        ctx.module, ctx.plan = module, plan
+        ctx.module, ctx.plan, ctx.generation = module, plan, plan.generation
         ctx.in_shape = spectrograms.shape if spectrograms.requires_grad else None
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(preds)
@@ -58,9 +59,11 @@ class _TitaNetFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_emb, g_preds, g_loss):
         module, plan = ctx.module, ctx.plan
-        if module._active_plan is not plan:
-            raise RuntimeError("titanet_amd: backward() must follow the forward() it belongs to "
-                               "(another forward ran on this module in between)")
+        # forwards of OTHER plans (another shape, or the other mode: a validation forward under model.eval() between
+        # `loss = model(...)` and `loss.backward()`, as the reference allows) leave this plan's saved state alone
+        if plan.handle is None or plan.generation != ctx.generation:
+            raise RuntimeError("titanet_amd: the saved activations of this forward() are gone (another forward of the same "
+                               "shape and mode ran on this module, or its plan was evicted, before backward())")
         g_in = module._native_backward(plan, g_emb, g_loss, ctx.in_shape)
         return g_in, None, None, None, None
 
@@ -69,7 +72,7 @@ class TitaNet(nn.Module):
     """TitaNet speaker-embedding network (reference src/models.py:162-339) on hand-written HIP kernels."""
 
     TARGET_PARAMS = {"s": 6.4, "m": 13.4, "l": 25.3}
-    MAX_PLANS = 4
+    MAX_PLANS = 6
 
     def __init__(
         self,
@@ -239,6 +242,7 @@ class TitaNet(nn.Module):
     def _drop_plans(self):
         for plan in getattr(self, "_plans", {}).values():
             self._lib.tn_plan_destroy(plan.handle)
+            plan.handle = None
         self._plans = OrderedDict()
         self._active_plan = None
 
@@ -308,7 +312,7 @@ class TitaNet(nn.Module):
         return {"fp32": _lib.TN_PREC_FP32, "bf16": _lib.TN_PREC_BF16, "fp8": _lib.TN_PREC_FP8}[self.precision]
 
     def _get_plan(self, batch, frames):
-        key = (batch, frames, self._prec())
+        key = (batch, frames, self._prec(), bool(self.training))      # train and eval forwards never share saved state
         plan = self._plans.get(key)
         if plan is not None:
             self._plans.move_to_end(key)
@@ -322,6 +326,7 @@ class TitaNet(nn.Module):
             if old is self._active_plan:
                 self._active_plan = None
             self._lib.tn_plan_destroy(old.handle)
+            old.handle = None
         handle = C.c_void_p()
         check(self._lib.tn_plan_create(self._model, batch, frames, self._prec(), C.byref(handle)), "tn_plan_create")
         if self.grad_groups > 1:
@@ -382,6 +387,7 @@ class TitaNet(nn.Module):
                                               C.c_uint64(seed), _ptr(emb), _ptr(preds), _ptr(loss), C.c_void_p(stream)),
                   "tn_forward_masked")
         plan.input_ref = x      # keep the input alive for backward (prolog weight gradient re-reads it)
+        plan.generation += 1
         self._active_plan = plan
         if speakers is None:
             preds = torch.empty(0, dtype=torch.int64, device=dev)

@@ -90,6 +90,15 @@ class MelSpectrogram:
         assert masks is None, "interval masks go with the equal-length entry point; pass freq_masks / time_masks here"
         ln = torch.as_tensor(lengths if lengths is not None else [A] * B, dtype=torch.int64)
         rt = torch.as_tensor(rates if rates is not None else [1.0] * B, dtype=torch.float64)
+        # the C entry point trusts these: a length beyond the row or a mask of another batch size would read out of bounds
+        if ln.numel() != B or int(ln.min()) < 1 or int(ln.max()) > A:
+            raise ValueError(f"lengths must be {B} values in [1, {A}]")
+        if rt.numel() != B or not bool((rt > 0).all()):
+            raise ValueError(f"rates must be {B} positive values")
+        if freq_masks is not None and tuple(freq_masks.shape) != (B, self.n_mels):
+            raise ValueError(f"freq_masks must have shape ({B}, {self.n_mels}), got {tuple(freq_masks.shape)}")
+        if time_masks is not None and (time_masks.dim() != 2 or time_masks.shape[0] != B):
+            raise ValueError(f"time_masks must have shape ({B}, frames), got {tuple(time_masks.shape)}")
         frames = [self.n_frames(int(n), float(r)) for n, r in zip(ln.tolist(), rt.tolist())]
         T = max(frames)
         if time_masks is not None:
