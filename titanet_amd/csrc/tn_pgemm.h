@@ -77,7 +77,9 @@ struct PGemmEpiArgs {
 //   and stores the L2 -> LDS stream alone takes 129 us (1.26 GB at 9.8 TB/s: 256 x 256 tiles at K = 1024 cannot be fed
 //   faster), the output stores cost 20 - 40 us (they queue in front of the next tile's DMA);
 //   2 stages of K = 64: 0.73;  fragments prefetched across the barrier + mid-step barrier: 0.75;  the two wave groups one
-//   phase apart ("ping-pong", a barrier per 8 MFMAs): 0.76 - 0.79, with s_setprio around the MFMAs 0.75.
+//   phase apart ("ping-pong", a barrier per 8 MFMAs): 0.76 - 0.79, with s_setprio around the MFMAs 0.75;  16-byte output
+//   stores (quad transpose of the packed pairs, 16 instead of 64 store instructions per wave and tile): 4 % slower —
+//   the store cost is the burst itself (every workgroup reaches its epilogue at the same time), not the instruction count.
 template <int DBG = 0>
 __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtArgs pa, PGemmEpiArgs ea, int tiles_n, int total_tiles) {
   constexpr int BK = 32, NSTAGE = 4;
@@ -261,8 +263,14 @@ inline int launch_pgemm_nt_t(const GemmShape& g, const PGemmNtArgs& pa, const PG
   if (g.K % 32 || g.K <= 0 || pa.lda % 8 || g.N % 64 || g.N > 3072 || ea.ldy % 2 || g.M <= 0) return TN_E_UNSUPPORTED;
   if ((long)g.M * pa.lda >= (1L << 32) || (long)g.N * g.K >= (1L << 32) || (long)g.M * ea.ldy * 2 >= (1L << 32)) return TN_E_UNSUPPORTED;
   const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256, total = tiles_m * tiles_n;
+  // persistent workgroups with the same number of tiles each (1200 tiles: 240 x 5 beats 256 x 4.7, the last round of which
+  // runs at 69 % occupancy: 201 vs 209 us), a multiple of 8 for the XCD-contiguous order
   int grid = total < max_wgs ? total : max_wgs;
-  if (grid >= 8) grid &= ~7;
+  if (grid >= 8) {
+    const int rounds = (total + grid - 1) / grid;
+    grid = (((total + rounds - 1) / rounds) + 7) & ~7;
+    if (grid > max_wgs) grid = max_wgs & ~7;
+  }
   const size_t smem = (size_t)131072 + (size_t)2 * g.N * sizeof(float);
   auto kern = pgemm_nt_kernel<DBG>;
   TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
