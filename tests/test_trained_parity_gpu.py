@@ -1,0 +1,74 @@
+"""Gradient parity at TRAINED weights (the per-tensor bf16 tolerances at a random initialisation are 0.2-0.35
+because ~0.5 % of the ReLU / dropout-survivor decisions of a randomly initialised network flip under bf16 rounding; a
+mis-scaled slab could hide in that).  Here a 2-block S-width model is first trained for 250 fused-Adam steps in fp32 on a
+small deterministic task (separable class means, so the activations settle away from the decision boundaries), then the
+bf16 / fp8 plans' gradients AT THOSE WEIGHTS are compared tensor by tensor with the float64 oracle (same dropout masks)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import titanet_oracle as O
+from tests.test_forward_gpu import build
+from tests.util import mask_fn_for, oracle_cfg, rel_err
+
+pytestmark = pytest.mark.gpu
+
+P, SEED, NCLS = 0.1, 777, 16
+
+
+def _task(B, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    means = torch.randn(NCLS, 80, 1, generator=torch.Generator().manual_seed(5)) * 0.08          # the classes: fixed spectral shapes
+    y = torch.randint(0, NCLS, (B,), generator=g)
+    x = means[y] + torch.randn(B, 80, T, generator=g) * 0.05 - 0.10
+    return x, y
+
+
+@pytest.mark.parametrize("hidden,kernel,precision", [(256, 3, "bf16"), (512, 7, "bf16"), (512, 7, "fp8")])
+def test_gradients_at_trained_weights_vs_float64_oracle(hidden, kernel, precision):
+    from titanet_amd.trainer import Trainer
+    case = dict(cfg=dict(n_mels=80, n_mega_blocks=2, hidden=hidden, enc_out=1536, emb=192, kernel=kernel, attn_hidden=128),
+                batch=64, frames=120, n_classes=NCLS, seed=31)
+    m32 = build(case, "ce", precision="fp32", dropout=P).train()
+    tr = Trainer(m32, lr=1e-3)
+    first = last = None
+    for step in range(250):
+        x, y = _task(64, 120, 1000 + step % 8)
+        lv = tr.step(x.cuda(), y.cuda())[2]
+        if step == 0:
+            first = float(lv)
+    last = float(lv)
+    assert last < 0.5 * first, (first, last)                       # it did train
+    sd_trained = {k: v.detach().cpu().clone() for k, v in m32.state_dict().items()}
+    del tr, m32
+    torch.cuda.empty_cache()
+    # ---- the plan under test at the trained weights
+    x, y = _task(64, 120, 4242)
+    m = build(case, "ce", precision=precision, dropout=P).train()
+    m.load_state_dict(sd_trained)
+    m._seed_base, m._step = SEED, 0
+    emb, _, lv = m(x.cuda(), speakers=y.cuda())
+    lv.backward()
+    torch.cuda.synchronize()
+    named = dict(m.named_parameters())
+    got = {k: named[k].grad.detach().cpu().numpy() for k in named}
+    # ---- float64 oracle at the same weights, same masks
+    sd = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in sd_trained.items()}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running_" not in k:
+            v.requires_grad_(True)
+    out = O.titanet_forward(sd, x.double(), oracle_cfg(case, dropout=P), training=True, speakers=y, loss="ce", mask_fn=mask_fn_for(SEED, P))
+    out.loss.backward()
+    want = {k: sd[k].grad.numpy() for k in got}
+    big = [k for k in got if got[k].size >= 4096 and float(np.abs(want[k]).max()) > 1e-9]
+    per = {k: rel_err(got[k], want[k]) for k in big}
+    a = np.concatenate([got[k].ravel() for k in got]); b = np.concatenate([want[k].ravel() for k in got])
+    cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+    worst = sorted(per.items(), key=lambda kv: -kv[1])[:4]
+    e_emb = rel_err(emb.detach().cpu().numpy(), out.normalized.detach().numpy())
+    print(f"H={hidden} {precision}: loss {float(lv):.4f} / {float(out.loss):.4f} (trained from {first:.3f} to {last:.3f}), emb {e_emb:.2e}, "
+          f"gradient cosine {cos:.5f}, worst large tensors {[(k, round(v, 4)) for k, v in worst]}")
+    lim = 5e-2 if precision == "bf16" else 1.5e-1                  # fp8: e4m3 forward operands (3 mantissa bits)
+    assert cos > (0.999 if precision == "bf16" else 0.99), cos
+    for k, v in per.items():
+        assert v < lim, (k, v)
