@@ -258,7 +258,8 @@ def other_configs(dev):
         ln = torch.tensor(frames, dtype=torch.int64)
 
         def step():
-            x = mel.batch(wav, lengths=nsamp, rates=rates, freq_masks=fm, time_masks=tm)
+            # the front end writes the prolog conv's packed bf16 operand itself (no float32 [B, 80, T] tensor, no pack pass)
+            x = mel.batch(wav, lengths=nsamp, rates=rates, freq_masks=fm, time_masks=tm, into=m)
             tr.step(x, y, lengths=ln)
         dt = _timed_steps(step, 2, 5)
         valid = sum(frames)

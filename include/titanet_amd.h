@@ -119,6 +119,14 @@ int tn_forward(tn_plan* p, const float* spectrograms, const int64_t* speakers, i
  * lengths.  Not for stream capture (host lengths). */
 int tn_forward_masked(tn_plan* p, const float* spectrograms, const int64_t* lengths_host, const int64_t* speakers,
                       int32_t training, uint64_t seed, float* embeddings, int64_t* preds, float* loss, void* stream);
+/* The bf16 plans read the input as a packed bf16 [batch * frames][n_mels] operand in their workspace (device pointer, NULL
+ * for fp32 plans / unbound plans).  A producer on the same stream (tn_mel_forward_batch_packed) may fill it directly;
+ * tn_forward_prepacked == tn_forward / tn_forward_masked (lengths_host NULL / given) on that operand, without a spectrogram
+ * argument (frames beyond an utterance's length must be zero there, as the mel front end writes them; d loss / d
+ * spectrograms is not available on this path). */
+void* tn_plan_prolog_input(tn_plan* p);
+int tn_forward_prepacked(tn_plan* p, const int64_t* lengths_host, const int64_t* speakers, int32_t training, uint64_t seed,
+                         float* embeddings, int64_t* preds, float* loss, void* stream);
 
 /* ---- loss.backward() through the module (reference src/learn.py:117) -------------------------
  * Must follow a tn_forward(training or eval) on the same plan.  Writes d loss / d params into
@@ -213,6 +221,15 @@ int tn_mel_forward(tn_mel* m, const float* waves, int32_t batch, int64_t n_sampl
 int tn_mel_forward_batch(tn_mel* m, const float* waves, int32_t batch, int64_t n_samples_max, const int64_t* lengths,
                          const double* rates, const uint8_t* freq_mask, const uint8_t* time_mask, int32_t frames_out, float* out,
                          void* stream);
+/* The front end FUSED into the prolog's producer (BASELINE.json configs[3]; replaces reference src/transforms.py:158-203 +
+ * the spectrograms.to(device) of src/learn.py:95 + the first operand of the prolog conv, src/models.py:370): the same
+ * arithmetic, but the result is written as the prolog conv's packed operand — bf16 [batch * frames_out][n_mels], row =
+ * b * frames_out + frame — straight into a bf16 plan's input buffer (tn_plan_prolog_input), so no float32
+ * [batch][n_mels][frames] tensor and no packing pass exist; tn_forward_prepacked then runs the network on it.
+ * out_or_null: optionally ALSO the float32 [batch][n_mels][frames_out] tensor (tests). */
+int tn_mel_forward_batch_packed(tn_mel* m, const float* waves, int32_t batch, int64_t n_samples_max, const int64_t* lengths,
+                                const double* rates, const uint8_t* freq_mask, const uint8_t* time_mask, int32_t frames_out,
+                                void* packed_bf16, float* out_or_null, void* stream);
 
 /* ---- per-kernel timing with HIP events on the launch stream (roofline measurement) ----------------
  * Kernel classes: the heavy kernels of one mega-block sub-block (there are n_mega_blocks*n_sub_blocks

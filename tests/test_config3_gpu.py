@@ -34,7 +34,7 @@ def ragged_waveforms(B, seed, lo=2.0, hi=20.0):
     return wav, nsamp, rnd
 
 
-def front_end(wav, nsamp, rnd, stretch=True):
+def front_end(wav, nsamp, rnd, stretch=True, into=None):
     from titanet_amd.transforms import MelSpectrogram
     B = wav.shape[0]
     mel = MelSpectrogram(SR, n_fft=512, win_length=400, hop_length=HOP, n_mels=80)
@@ -49,7 +49,7 @@ def front_end(wav, nsamp, rnd, stretch=True):
         t0 = rnd.randrange(0, frames[b] - 4); t1 = min(frames[b], t0 + rnd.randrange(1, max(2, int(0.15 * frames[b]))))
         fm[b, f0:f1] = True; tm[b, t0:t1] = True
         fms.append((f0, f1)); tms.append((t0, t1))
-    x = mel.batch(wav.cuda(), lengths=nsamp, rates=rates, freq_masks=fm, time_masks=tm)
+    x = mel.batch(wav.cuda(), lengths=nsamp, rates=rates, freq_masks=fm, time_masks=tm, into=into)
     return x, frames, rates, fms, tms
 
 
@@ -116,3 +116,43 @@ def test_m10_padded_batch_equals_each_utterance_alone_and_trains():
     l2 = float(tr.step(x, y, lengths=lengths)[2])
     assert np.isfinite(l1) and np.isfinite(l2) and torch.isfinite(m.flat_parameters()).all()
     assert torch.isfinite(m.flat_gradients()).all() and float(m.flat_gradients().norm()) > 0
+
+
+def test_front_end_fused_into_the_prolog_operand():
+    """configs[3] "mel + SpecAugment fused into the prolog kernel": MelSpectrogram.batch(..., into=model) writes the prolog
+    conv's packed bf16 operand itself (tn_mel_forward_batch_packed -> tn_plan_prolog_input -> tn_forward_prepacked): same
+    embeddings / loss / gradient as the float32 spectrogram tensor fed through model(x, lengths=...)."""
+    from titanet_amd import LOSSES, TitaNet
+    B = 12
+    torch.manual_seed(0)
+    m = TitaNet.get_titanet(n_mega_blocks=2, model_size="m", loss_function=LOSSES["ce"](192, 40, device="cuda"), dropout=0.1,
+                            device="cuda", precision="bf16").train()
+    y = torch.randint(0, 40, (B,), generator=torch.Generator().manual_seed(1)).cuda()
+    res = []
+    for fused in (False, True):
+        wav, nsamp, rnd = ragged_waveforms(B, seed=4, lo=2.0, hi=8.0)
+        x, frames, *_ = front_end(wav, nsamp, rnd, into=m if fused else None)
+        m._seed_base, m._step = 11, 0
+        m.zero_grad()
+        if fused:
+            assert type(x).__name__ == "PackedSpectrograms" and x.shape == (B, 80, max(frames))
+            emb, _, lv = m(x, speakers=y)                       # the lengths ride in the handle
+        else:
+            emb, _, lv = m(x, speakers=y, lengths=torch.tensor(frames))
+        lv.backward()
+        torch.cuda.synchronize()
+        res.append((emb.detach().cpu().numpy(), float(lv), m.flat_gradients().clone().cpu().numpy()))
+    e = rel_err(res[1][0], res[0][0])
+    cos = float(res[1][2] @ res[0][2] / (np.linalg.norm(res[1][2]) * np.linalg.norm(res[0][2])))
+    print(f"fused vs tensor path: emb {e:.2e}, loss {res[1][1]:.5f} / {res[0][1]:.5f}, gradient cosine {cos:.6f}")
+    # identical bf16 operand bits; what differs is the summation order of the atomics-accumulated statistics
+    assert e < 2e-2 and abs(res[1][1] - res[0][1]) < 2e-2 and cos > 0.995
+    # eval, equal lengths, the f32 twin of the packed operand
+    m.eval()
+    from titanet_amd.transforms import MelSpectrogram
+    mel = MelSpectrogram(SR, n_fft=512, win_length=400, hop_length=HOP, n_mels=80)
+    w = torch.randn(4, 32000, generator=torch.Generator().manual_seed(2)) * 0.05
+    with torch.no_grad():
+        a = m(mel.batch(w.cuda())).cpu().numpy()
+        b = m(mel.batch(w.cuda(), into=m)).cpu().numpy()
+    assert rel_err(b, a) < 1e-6, rel_err(b, a)

@@ -18,7 +18,7 @@ EXPORTS = [
     "tn_plan_bind", "tn_forward", "tn_backward", "tn_adam_step", "tn_debug_fetch", "tn_version", "tn_profile_begin",
     "tn_profile_read", "tn_profile_sample", "tn_mel_create", "tn_mel_destroy", "tn_mel_num_frames", "tn_mel_forward", "tn_mel_forward_batch", "tn_plan_step_tick",
     "tn_plan_step_set", "tn_adam_step_plan", "tn_plan_set_lr", "tn_head_save_floats", "tn_head_forward", "tn_head_backward",
-    "tn_forward_masked", "tn_plan_set_grad_groups", "tn_plan_num_grad_buckets", "tn_plan_grad_bucket", "tn_plan_wait_grad_bucket",
+    "tn_forward_masked", "tn_forward_prepacked", "tn_plan_prolog_input", "tn_mel_forward_batch_packed", "tn_plan_set_grad_groups", "tn_plan_num_grad_buckets", "tn_plan_grad_bucket", "tn_plan_wait_grad_bucket",
 ]
 
 
@@ -98,6 +98,10 @@ def load():
     lib.tn_mel_num_frames.restype = i64
     lib.tn_mel_forward.argtypes = [vp, vp, i32, i64, vp, vp, vp]
     lib.tn_mel_forward_batch.argtypes = [vp, vp, i32, i64, vp, vp, vp, vp, i32, vp, vp]
+    lib.tn_mel_forward_batch_packed.argtypes = [vp, vp, i32, i64, vp, vp, vp, vp, i32, vp, vp, vp]
+    lib.tn_plan_prolog_input.argtypes = [vp]
+    lib.tn_plan_prolog_input.restype = vp
+    lib.tn_forward_prepacked.argtypes = [vp, vp, vp, i32, C.c_uint64, vp, vp, vp, vp]
     lib.tn_version.restype = C.c_char_p
     for name in EXPORTS:
         fn = getattr(lib, name)

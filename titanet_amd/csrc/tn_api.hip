@@ -640,9 +640,11 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   // ---- prolog: dense k=3 conv as an im2col GEMM (reference src/models.py:370, :398)
   if (p->prolog_taps) {
     // packed operand: one transposing cast of the input, then the GEMM reads 16-byte vectors (a scalar gather from the
-    // [B][C][T] float layout cost 100 us here, and 190 us in the weight gradient)
+    // [B][C][T] float layout cost 100 us here, and 190 us in the weight gradient).  spec == null: the mel front end wrote
+    // the packed operand itself (tn_mel_forward_batch_packed into tn_plan_prolog_input: no f32 spectrogram, no pack pass)
     const size_t tile = (size_t)c.n_mels * 65 * sizeof(float);
-    hipLaunchKernelGGL(prolog_pack_kernel<AT>, dim3((T + 63) / 64, B), dim3(256), tile, st, spec, c.n_mels, T, rm.len, (AT*)(ws + p->x0));
+    if (spec)
+      hipLaunchKernelGGL(prolog_pack_kernel<AT>, dim3((T + 63) / 64, B), dim3(256), tile, st, spec, c.n_mels, T, rm.len, (AT*)(ws + p->x0));
     hipLaunchKernelGGL(prolog_weight_taps_kernel<AT>, dim3(64), dim3(256), 0, st, params + m->prolog_w, H, c.n_mels, c.prolog_kernel,
                        (AT*)(ws + p->wprolog_taps));
     GemmShape g{M, H, c.n_mels * c.prolog_kernel, ws + p->wprolog_taps};
@@ -929,6 +931,34 @@ extern "C" int tn_forward_masked(tn_plan* p, const float* spectrograms, const in
   // pageable host memory: the runtime stages the bytes before the call returns
   TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->lens, p->lens_host.data(), sizeof(int) * (size_t)p->B, hipMemcpyHostToDevice, (hipStream_t)stream));
   return plan_forward(p, spectrograms, speakers, training, seed, embeddings, preds, loss, (hipStream_t)stream);
+}
+
+extern "C" void* tn_plan_prolog_input(tn_plan* p) {
+  if (!p || !p->bound || !p->prolog_taps || p->prec != TN_PREC_BF16) return nullptr;
+  return p->ws + p->x0;
+}
+
+extern "C" int tn_forward_prepacked(tn_plan* p, const int64_t* lengths_host, const int64_t* speakers, int32_t training, uint64_t seed,
+                                    float* embeddings, int64_t* preds, float* loss, void* stream) {
+  if (!p) return TN_E_BADARG;
+  if (!p->bound) return TN_E_NOTBOUND;
+  if (!p->prolog_taps || p->prec != TN_PREC_BF16) return TN_E_UNSUPPORTED;
+  if (training && p->B < 2) return TN_E_BADARG;
+  p->masked = false;
+  if (lengths_host) {
+    p->lens_host.resize(p->B);
+    long total = 0;
+    for (int b = 0; b < p->B; ++b) {
+      if (lengths_host[b] < 1 || lengths_host[b] > p->T) return TN_E_BADARG;
+      p->lens_host[b] = (int)lengths_host[b];
+      total += lengths_host[b];
+    }
+    if (training && total < 2) return TN_E_BADARG;
+    p->n_valid = (int)total;
+    p->masked = true;
+    TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->lens, p->lens_host.data(), sizeof(int) * (size_t)p->B, hipMemcpyHostToDevice, (hipStream_t)stream));
+  }
+  return plan_forward(p, nullptr, speakers, training, seed, embeddings, preds, loss, (hipStream_t)stream);
 }
 
 extern "C" int tn_backward(tn_plan* p, float grad_scale, const float* grad_scale_dev, const float* grad_embeddings,

@@ -506,6 +506,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       return TN_E_UNSUPPORTED;
     }
     p->prolog_cur = cur;
+    if (grad_input && !p->last_input && !p->prolog_taps) return TN_E_STATE;
     if (grad_input) {
       ProdDy::Args pa{ws + p->dA[cur], ws + p->Y0, H, make_bnbwd(p, m->prolog_bn, M, training)};
       const int n = B * c.n_mels * T;

@@ -139,7 +139,7 @@ __global__ void mel_batch_kernel(const float* __restrict__ waves, int64_t n_samp
                                  const double* __restrict__ rates, const uint8_t* __restrict__ fmask, const uint8_t* __restrict__ tmask,
                                  int T_out, int n_fft, int log2n, int hop, int n_mels, int n_freqs, const float* __restrict__ window,
                                  const float* __restrict__ fb, const int* __restrict__ range, const float* __restrict__ twiddle,
-                                 float* __restrict__ out) {
+                                 float* __restrict__ out, unsigned short* __restrict__ packed) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* re = reinterpret_cast<float*>(smem);
   float* im = re + n_fft;
@@ -199,9 +199,21 @@ __global__ void mel_batch_kernel(const float* __restrict__ waves, int64_t n_samp
     __syncthreads();
   }
   __syncthreads();
-  for (int i = tid; i < n_mels * MEL_FT; i += blockDim.x) {
-    const int m = i / MEL_FT, jj = i % MEL_FT;
-    if (j0 + jj < T_out) out[((size_t)b * n_mels + m) * T_out + j0 + jj] = tile[m * (MEL_FT + 1) + jj];
+  if (out) {
+    for (int i = tid; i < n_mels * MEL_FT; i += blockDim.x) {
+      const int m = i / MEL_FT, jj = i % MEL_FT;
+      if (j0 + jj < T_out) out[((size_t)b * n_mels + m) * T_out + j0 + jj] = tile[m * (MEL_FT + 1) + jj];
+    }
+  }
+  if (packed) {
+    // the prolog conv's operand layout: rows x n_mels bf16, row = b * T_out + frame (what prolog_pack_kernel would make of
+    // `out`): the MEL_FT frames of this workgroup are one contiguous run
+    unsigned short* pb = packed + ((size_t)b * T_out + j0) * n_mels;
+    const int nfr = min(MEL_FT, T_out - j0);
+    for (int i = tid; i < nfr * n_mels; i += blockDim.x) {
+      const int jj = i / n_mels, m = i - jj * n_mels;
+      pb[i] = __builtin_bit_cast(unsigned short, (__bf16)tile[m * (MEL_FT + 1) + jj]);
+    }
   }
 }
 
@@ -262,15 +274,31 @@ extern "C" void tn_mel_destroy(tn_mel* m) {
 
 extern "C" int64_t tn_mel_num_frames(const tn_mel* m, int64_t n_samples) { return m ? 1 + n_samples / m->hop : 0; }
 
+static int mel_batch_launch(tn_mel* m, const float* waves, int32_t batch, int64_t n_samples_max, const int64_t* lengths,
+                            const double* rates, const uint8_t* freq_mask, const uint8_t* time_mask, int32_t frames_out,
+                            float* out, unsigned short* packed, void* stream);
 extern "C" int tn_mel_forward_batch(tn_mel* m, const float* waves, int32_t batch, int64_t n_samples_max, const int64_t* lengths,
                                     const double* rates, const uint8_t* freq_mask, const uint8_t* time_mask, int32_t frames_out,
                                     float* out, void* stream) {
-  if (!m || !waves || !out || batch <= 0 || n_samples_max <= 0 || frames_out <= 0) return TN_E_BADARG;
+  if (!out) return TN_E_BADARG;
+  return mel_batch_launch(m, waves, batch, n_samples_max, lengths, rates, freq_mask, time_mask, frames_out, out, nullptr, stream);
+}
+extern "C" int tn_mel_forward_batch_packed(tn_mel* m, const float* waves, int32_t batch, int64_t n_samples_max, const int64_t* lengths,
+                                           const double* rates, const uint8_t* freq_mask, const uint8_t* time_mask,
+                                           int32_t frames_out, void* packed_bf16, float* out_or_null, void* stream) {
+  if (!packed_bf16) return TN_E_BADARG;
+  return mel_batch_launch(m, waves, batch, n_samples_max, lengths, rates, freq_mask, time_mask, frames_out, out_or_null,
+                          (unsigned short*)packed_bf16, stream);
+}
+static int mel_batch_launch(tn_mel* m, const float* waves, int32_t batch, int64_t n_samples_max, const int64_t* lengths,
+                            const double* rates, const uint8_t* freq_mask, const uint8_t* time_mask, int32_t frames_out,
+                            float* out, unsigned short* packed, void* stream) {
+  if (!m || !waves || batch <= 0 || n_samples_max <= 0 || frames_out <= 0) return TN_E_BADARG;
   const size_t smem = (size_t)(2 * m->n_fft + 2 * (m->n_freqs + 3) + m->n_mels + m->n_mels * (MEL_FT + 1)) * sizeof(float);
   const int threads = m->n_fft / 2 < 64 ? 64 : (m->n_fft / 2 > 1024 ? 1024 : m->n_fft / 2);
   hipLaunchKernelGGL(mel_batch_kernel, dim3((frames_out + MEL_FT - 1) / MEL_FT, batch), dim3(threads), smem, (hipStream_t)stream, waves,
                      n_samples_max, lengths, rates, freq_mask, time_mask, frames_out, m->n_fft, m->log2n, m->hop, m->n_mels, m->n_freqs,
-                     m->window, m->fb, m->range, m->twiddle, out);
+                     m->window, m->fb, m->range, m->twiddle, out, packed);
   return (int)hipGetLastError();
 }
 

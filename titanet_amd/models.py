@@ -44,6 +44,23 @@ class _Plan:
         self.generation = 0          # forwards run on this plan (a backward belongs to exactly one of them)
 
 
+class PackedSpectrograms:
+    """A batch the mel front end wrote straight into a plan's prolog operand (``MelSpectrogram.batch(..., into=model)``:
+    bf16 rows x n_mels, no float32 ``[B, n_mels, T]`` tensor).  ``model(packed, speakers)`` consumes it; ``lengths`` (valid
+    frames per utterance) ride along and become the padding mask of a ragged batch."""
+
+    requires_grad = False
+
+    def __init__(self, plan, generation, batch, n_mels, frames, lengths, device):
+        self.plan, self.generation = plan, generation
+        self.shape = (batch, n_mels, frames)
+        self.lengths, self.device = lengths, device
+        self.is_cuda = True
+
+    def dim(self):
+        return 3
+
+
 class _TitaNetFunction(torch.autograd.Function):
     """One autograd node for the whole network: forward = tn_forward, backward = tn_backward."""
 
@@ -51,7 +68,7 @@ class _TitaNetFunction(torch.autograd.Function):
     def forward(ctx, spectrograms, anchor, module, speakers, lengths=None):
         emb, preds, loss, plan = module._native_forward(spectrograms, speakers, lengths=lengths)
         ctx.module, ctx.plan, ctx.generation = module, plan, plan.generation
-        ctx.in_shape = spectrograms.shape if spectrograms.requires_grad else None
+        ctx.in_shape = spectrograms.shape if (isinstance(spectrograms, torch.Tensor) and spectrograms.requires_grad) else None
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(preds)
         return emb, preds, loss
@@ -296,7 +313,7 @@ class TitaNet(nn.Module):
         gradient (``tn_forward_masked``, include/titanet_amd.h); ``None`` = the reference's semantics."""
         if speakers is not None:
             assert self.loss_function is not None, "Loss function should not be None in training mode"
-        needs_grad = torch.is_grad_enabled() and (spectrograms.requires_grad or any(p.requires_grad for p in self.parameters()))
+        needs_grad = torch.is_grad_enabled() and (bool(getattr(spectrograms, "requires_grad", False)) or any(p.requires_grad for p in self.parameters()))
         if needs_grad:
             if self._anchor.device != spectrograms.device:
                 self._anchor = torch.zeros(1, device=spectrograms.device, requires_grad=True)
@@ -356,14 +373,23 @@ class TitaNet(nn.Module):
             raise ValueError(f"expected spectrograms of shape [B, {self._cfg.n_mels}, T], got {tuple(spectrograms.shape)}")
         if not spectrograms.is_cuda:
             raise RuntimeError("titanet_amd.TitaNet.forward needs ROCm device tensors; there is no CPU execution path")
-        x = spectrograms.detach()
-        if x.dtype != torch.float32 or not x.is_contiguous():
-            x = x.contiguous().float()
-        B, _, T = x.shape
+        packed = spectrograms if isinstance(spectrograms, PackedSpectrograms) else None
+        if packed is not None:
+            x = None
+            if lengths is None:
+                lengths = packed.lengths
+        else:
+            x = spectrograms.detach()
+            if x.dtype != torch.float32 or not x.is_contiguous():
+                x = x.contiguous().float()
+        B, _, T = spectrograms.shape
         if self.training and B < 2:
             raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
         plan = self._get_plan(B, T)
-        dev = x.device
+        if packed is not None and (packed.plan is not plan or plan.handle is None or packed.generation != plan.generation):
+            raise RuntimeError("titanet_amd: this PackedSpectrograms batch was written for another plan (the model changed mode, "
+                               "precision or ran another batch of this shape since MelSpectrogram.batch(..., into=model))")
+        dev = spectrograms.device
         emb = torch.empty(B, self._cfg.emb, dtype=torch.float32, device=dev)
         preds = loss = y = None
         if speakers is not None:
@@ -376,7 +402,18 @@ class TitaNet(nn.Module):
             seed = (self._seed_base + self._step * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
             self._step += 1
         stream = torch.cuda.current_stream(dev).cuda_stream
-        if lengths is None:
+        if packed is not None:
+            ln = None
+            if lengths is not None:
+                ln = torch.as_tensor(lengths).detach().to(device="cpu", dtype=torch.int64).contiguous()
+                if ln.numel() != B or int(ln.min()) < 1 or int(ln.max()) > T:
+                    raise ValueError(f"lengths must be {B} values in [1, {T}]")
+                if int(ln.min()) == T:
+                    ln = None
+            check(self._lib.tn_forward_prepacked(plan.handle, C.c_void_p(ln.data_ptr() if ln is not None else 0), _ptr(y),
+                                                 1 if self.training else 0, C.c_uint64(seed), _ptr(emb), _ptr(preds), _ptr(loss),
+                                                 C.c_void_p(stream)), "tn_forward_prepacked")
+        elif lengths is None:
             check(self._lib.tn_forward(plan.handle, _ptr(x), _ptr(y), 1 if self.training else 0, C.c_uint64(seed), _ptr(emb),
                                        _ptr(preds), _ptr(loss), C.c_void_p(stream)), "tn_forward")
         else:

@@ -66,12 +66,15 @@ class MelSpectrogram:
         start = int(min_value.long())
         return start, start + int(value.long())
 
-    def batch(self, waveforms, masks=None, lengths=None, rates=None, freq_masks=None, time_masks=None):
+    def batch(self, waveforms, masks=None, lengths=None, rates=None, freq_masks=None, time_masks=None, into=None):
         """[B, A] float waveforms -> [B, n_mels, frames] on the GPU (the collate_fn layout, zero beyond an utterance's end).
 
         masks: optional int32 [B, 4] = (f_start, f_end, t_start, t_end), one interval per axis (``tn_mel_forward``).
         lengths: int64 [B] valid samples of each zero-padded waveform (ragged batch); rates: float64 [B] SpecAugment
-        time-stretch rates; freq_masks / time_masks: bool [B, n_mels] / [B, frames] unions of mask intervals."""
+        time-stretch rates; freq_masks / time_masks: bool [B, n_mels] / [B, frames] unions of mask intervals.
+        into: a bf16 / fp8 ``TitaNet`` on the same device — the spectrogram is then written STRAIGHT into that model's prolog
+        operand (bf16 rows x n_mels; no float32 tensor, no packing pass) and a ``PackedSpectrograms`` handle is returned;
+        ``model(handle, speakers)`` runs the network on it, ragged batches with their padding mask (BASELINE configs[3])."""
         if waveforms.dim() != 2:
             raise ValueError("expected waveforms of shape [B, A]")
         if not torch.cuda.is_available():
@@ -80,7 +83,7 @@ class MelSpectrogram:
         B, A = w.shape
         stream = torch.cuda.current_stream(self.device).cuda_stream
         vp = C.c_void_p
-        if lengths is None and rates is None and freq_masks is None and time_masks is None:
+        if lengths is None and rates is None and freq_masks is None and time_masks is None and into is None:
             T = 1 + A // self.hop_length
             out = torch.empty(B, self.n_mels, T, dtype=torch.float32, device=self.device)
             m = masks.to(device=self.device, dtype=torch.int32).contiguous() if masks is not None else None
@@ -103,17 +106,27 @@ class MelSpectrogram:
         T = max(frames)
         if time_masks is not None:
             T = max(T, time_masks.shape[1])
-        out = torch.empty(B, self.n_mels, T, dtype=torch.float32, device=self.device)
+        out = None if into is not None else torch.empty(B, self.n_mels, T, dtype=torch.float32, device=self.device)
         ln_d, rt_d = ln.to(self.device), rt.to(self.device)
         fm = freq_masks.to(device=self.device, dtype=torch.uint8).contiguous() if freq_masks is not None else None
         tm = None
         if time_masks is not None:
             tm = torch.zeros(B, T, dtype=torch.uint8, device=self.device)
             tm[:, :time_masks.shape[1]] = time_masks.to(device=self.device, dtype=torch.uint8)
+        self.last_frames = frames
+        if into is not None:
+            from .models import PackedSpectrograms
+            plan = into._get_plan(B, T)
+            dst = self._lib.tn_plan_prolog_input(plan.handle)
+            if not dst:
+                raise RuntimeError("MelSpectrogram.batch(into=model) needs a bf16 / fp8 model (fp32 plans read the float32 tensor)")
+            check(self._lib.tn_mel_forward_batch_packed(self._mel(), vp(w.data_ptr()), B, A, vp(ln_d.data_ptr()), vp(rt_d.data_ptr()),
+                                                        vp(fm.data_ptr() if fm is not None else 0), vp(tm.data_ptr() if tm is not None else 0),
+                                                        T, vp(dst), vp(0), vp(stream)), "tn_mel_forward_batch_packed")
+            return PackedSpectrograms(plan, plan.generation, B, self.n_mels, T, torch.tensor(frames, dtype=torch.int64), self.device)
         check(self._lib.tn_mel_forward_batch(self._mel(), vp(w.data_ptr()), B, A, vp(ln_d.data_ptr()), vp(rt_d.data_ptr()),
                                              vp(fm.data_ptr() if fm is not None else 0), vp(tm.data_ptr() if tm is not None else 0),
                                              T, vp(out.data_ptr()), vp(stream)), "tn_mel_forward_batch")
-        self.last_frames = frames
         return out
 
     def n_frames(self, n_samples, rate=1.0):
