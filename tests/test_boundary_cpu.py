@@ -142,3 +142,16 @@ def test_hot_path_kernels_do_not_spill():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "resource_usage.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "pgemm_nt_kernel" in r.stdout and "dgrad_dw_v6_kernel" in r.stdout
+
+
+def test_no_reads_of_in_flight_inline_asm_load_registers():
+    """tools/check_asm_hazards.py: in the generated gfx950 assembly no instruction reads a register that an inline-asm
+    `global_load_dword` is still filling before the inline-asm `s_waitcnt vmcnt` that retires it (hipcc schedules copies
+    there when it can: it believes the value exists once the asm statement has run)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_asm_hazards.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "tn_bwd.hip: 0 reads" in r.stdout

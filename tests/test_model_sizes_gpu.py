@@ -113,3 +113,102 @@ def test_wide_kernels_agree_with_generic_path(size):
     # per tensor against the oracle: the slab path is no further from it than the generic path (bf16 noise level)
     for k, e1, e0 in rows:
         assert e1 < max(0.35, 1.5 * e0), (k, e1, e0)
+
+
+@pytest.mark.parametrize("size", ["m", "l"])
+def test_wide_kernels_with_padding_mask_agree_with_generic_path(size):
+    """Variable-length batches on the wide models' fast kernels (BASELINE configs[3] is TitaNet-M on ragged batches): padding
+    rows read as zeros and are STORED as zeros by dw_fwd_slab / combine_fwd, the pipelined GEMM takes their y == bias out of
+    the BatchNorm statistics again (PGemmEpiArgs.pad_rows), dS is zero there (bn_bwd_apply), dw_bwd_slab masks both its
+    operand and its output.  Against the generic masked templates (TN_GENERIC=1) and the float64 oracle with the same
+    lengths and dropout masks; lengths chosen so that strips are fully valid, fully padding and cut by the length."""
+    import os
+    from tests.util import mask_fn_for
+    case = _case(size, 2 if size == "m" else 1, 5, 300, 37)
+    lengths = torch.tensor([300, 41, 163, 2, 299])
+    x, y = case_inputs(case, torch.float32)
+    for b, n in enumerate(lengths.tolist()):
+        x[b, :, n:] = 7.0                       # whatever the padding holds is ignored
+    res = {}
+    for flag in ("0", "1"):
+        if flag == "0":
+            os.environ["TN_GENERIC"] = "1"
+        try:
+            m = build(case, "ce", precision="bf16", dropout=0.1).train()
+            m._seed_base, m._step = 77, 0
+            emb, preds, lv = m(x.cuda(), speakers=y.cuda(), lengths=lengths)
+            lv.backward()
+            torch.cuda.synchronize()
+            bufs = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items() if "running_" in k}
+            res[flag] = (emb.detach().cpu().numpy(), {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters()}, float(lv), bufs)
+        finally:
+            os.environ.pop("TN_GENERIC", None)
+        del m
+    sd = case_state_dict(case, "ce", torch.float64)
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running_" not in k:
+            v.requires_grad_(True)
+    xo, yo = case_inputs(case, torch.float64)
+    out = O.titanet_forward(sd, xo, oracle_cfg(case, dropout=0.1), training=True, speakers=yo, lengths=lengths, loss="ce",
+                            mask_fn=mask_fn_for(77, 0.1))
+    out.loss.backward()
+    e_emb = rel_err(res["1"][0], res["0"][0])
+    e_orc = rel_err(res["1"][0], out.normalized.detach().numpy())
+    keys = [k for k in res["0"][1] if (".conv_block.0.conv." in k or "skip_connection.0" in k or k == "encoder.epilog.conv_block.0.weight")
+            and not k.endswith("conv.0.bias")]
+    a1 = np.concatenate([res["1"][1][k].ravel() for k in keys]); a0 = np.concatenate([res["0"][1][k].ravel() for k in keys])
+    ao = np.concatenate([sd[k].grad.numpy().ravel() for k in keys])
+    cos01 = float(a1 @ a0 / (np.linalg.norm(a1) * np.linalg.norm(a0)))
+    cos1o = float(a1 @ ao / (np.linalg.norm(a1) * np.linalg.norm(ao)))
+    cos0o = float(a0 @ ao / (np.linalg.norm(a0) * np.linalg.norm(ao)))
+    rows = [(k, rel_err(res["1"][1][k], sd[k].grad.numpy()), rel_err(res["0"][1][k], sd[k].grad.numpy())) for k in keys]
+    # BatchNorm running statistics: the statistics of the valid rows only (the pad_rows correction) — tight, they are f32 sums
+    e_buf = max(rel_err(res["1"][3][k], res["0"][3][k]) for k in res["1"][3] if "num_batches" not in k)
+    print(size, f"emb fast vs generic {e_emb:.2e}, vs oracle {e_orc:.2e}; loss {res['1'][2]:.4f} / {res['0'][2]:.4f} / {float(out.loss):.4f}; "
+          f"gradient cosine fast-generic {cos01:.4f}, fast-oracle {cos1o:.4f}, generic-oracle {cos0o:.4f}; running stats {e_buf:.2e}; "
+          f"worst {sorted(rows, key=lambda r: -r[1])[:3]}")
+    assert e_emb < 3e-2 and e_orc < 8e-2
+    assert abs(res["1"][2] - float(out.loss)) < 0.1 * max(1.0, abs(float(out.loss)))
+    assert e_buf < 2e-2, e_buf
+    assert cos01 > 0.98 and cos1o > min(0.93, cos0o - 0.01)
+    for k, e1, e0 in rows:
+        assert e1 < max(0.35, 1.5 * e0), (k, e1, e0)
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_wide_model_gradients_at_scale_agree_with_generic_path(masked):
+    """64 k rows (32 x 2000 frames): every workgroup of the slab kernels walks several tiles, so their cross-tile pipelining is
+    exercised — the skip-path addend rows of dw_bwd_slab are inline-asm loads retired by a counted wait, and a compiler copy
+    scheduled above that wait once produced non-finite prolog gradients only at such sizes (tools/check_asm_hazards.py is
+    the static check).  Fast path vs TN_GENERIC=1: finite, and the same gradient."""
+    import os
+    from titanet_amd import LOSSES, TitaNet
+    B, T = 32, 2000
+    g = torch.Generator().manual_seed(5)
+    lengths = torch.randint(T // 10, T, (B,), generator=g)
+    lengths[0] = T
+    x = torch.randn(B, 80, T, generator=g) * 0.11 - 0.1
+    y = torch.randint(0, 251, (B,), generator=g).cuda()
+    grads = {}
+    for mode in ("generic", "fast"):
+        if mode == "generic":
+            os.environ["TN_GENERIC"] = "1"
+        try:
+            torch.manual_seed(0)
+            m = TitaNet.get_titanet(n_mega_blocks=2, model_size="m", loss_function=LOSSES["ce"](192, 251, device="cuda"), dropout=0.1,
+                                    device="cuda", precision="bf16").train()
+            m._seed_base, m._step = 5, 0
+            emb, preds, lv = m(x.cuda(), speakers=y, lengths=lengths if masked else None)
+        finally:
+            os.environ.pop("TN_GENERIC", None)
+        lv.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(m.flat_gradients()).all(), mode
+        grads[mode] = {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
+        del m
+    for k in ("encoder.prolog.conv_block.0.weight", "encoder.mega_blocks.0.skip_connection.0.weight",
+              "encoder.mega_blocks.0.sub_blocks.0.conv_block.0.conv.0.weight", "encoder.mega_blocks.1.sub_blocks.0.conv_block.0.conv.1.weight"):
+        a, b = grads["fast"][k].ravel(), grads["generic"][k].ravel()
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+        print(k, "cosine fast vs generic", cos)
+        assert cos > 0.98, (k, cos)

@@ -595,12 +595,14 @@ int gemm_store(const GemmShape& g, const typename Prod::Args& pa, const EpiStore
 // plain stored bf16 operand, big problem: the pipelined LDS-DMA GEMM (tn_pgemm.h); -1000 = not applicable
 template <typename AT>
 int gemm_plain_pipe(const tn_plan* p, const GemmShape& g, const void* X, int ldx, const BnAct& act, const EpiStoreArgs& ea, hipStream_t st) {
-  if (sizeof(AT) != 2 || p->masked || p->generic || ea.rm.len) return -1000;
-  if (act.mode != 0 || act.relu || act.drop_thr || act.rm.len) return -1000;
+  // variable-length batches: every plain operand of this path is STORED with zero padding rows (dw_fwd_slab, combine_fwd),
+  // so the masks of the activation / epilogue have nothing left to do except for the statistics: y == bias on those rows
+  if (sizeof(AT) != 2 || p->generic || (p->masked && g.M != p->M)) return -1000;
+  if (act.mode != 0 || act.relu || act.drop_thr) return -1000;
   if (g.K % 32 || g.N % 64 || g.N > 3072 || ldx % 8 || ea.ldy % 2) return -1000;
   if (g.K < 256) return -1000;
   PGemmNtArgs pa{(const bf16_t*)X, ldx};
-  PGemmEpiArgs pe{(bf16_t*)ea.Y, ea.ldy, ea.bias, ea.stats, ea.colscale};
+  PGemmEpiArgs pe{(bf16_t*)ea.Y, ea.ldy, ea.bias, ea.stats, ea.colscale, p->masked ? (float)(p->M - p->n_valid) : 0.f};
   return launch_pgemm_nt(g, pa, pe, st);
 }
 
@@ -705,7 +707,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
           // anyway) and the pointwise GEMM reads it as a plain operand
           uint8_t* q8 = (p->fp8 && sizeof(AT) == 2) ? (uint8_t*)(ws + p->q8) : nullptr;
           rc = -1000;
-          if (sizeof(AT) == 2 && !p->masked && p->wide_dw_bwd) {
+          if (sizeof(AT) == 2 && p->wide_dw_bwd) {
             DwFwdSlabArgs fa;
             memset(&fa, 0, sizeof(fa));
             fa.X = (const bf16_t*)cur; fa.act = acur; fa.wdw = params + sb.wdw; fa.bdw = params + sb.bdw;

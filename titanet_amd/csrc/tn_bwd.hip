@@ -9,6 +9,32 @@
 #include "tn_pgemm.h"
 #include "tn_v2_bwd_kernels.h"
 #include "tn_v2_wide_kernels.h"
+#ifdef TN_DEBUG_NAN
+#include <stdio.h>
+__global__ void dbg_count_bad_kernel(const unsigned short* p, size_t n, int is_f32, unsigned* out) {
+  unsigned c = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    if (is_f32) { const unsigned u = reinterpret_cast<const unsigned*>(p)[i]; c += ((u >> 23) & 0xff) == 0xff; }
+    else c += ((p[i] >> 7) & 0xff) == 0xff;
+  }
+  if (c) atomicAdd(out, c);
+}
+static void dbg_check(const char* name, const void* ptr, size_t n, int is_f32, hipStream_t st) {
+  static unsigned* d = nullptr;
+  if (!d) (void)hipMalloc(&d, 4);
+  (void)hipMemsetAsync(d, 0, 4, st);
+  hipLaunchKernelGGL(dbg_count_bad_kernel, dim3(512), dim3(256), 0, st, (const unsigned short*)ptr, n, is_f32, d);
+  unsigned h = 0;
+  (void)hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, st);
+  (void)hipStreamSynchronize(st);
+  fprintf(stderr, "[nan] %-28s %u non-finite of %zu (%s)\n", name, h, n, hipGetErrorString(hipGetLastError()));
+}
+#define DBG(name, off, n) dbg_check(name, ws + (off), (size_t)(n), 0, st)
+#define DBGF(name, ptr, n) dbg_check(name, ptr, (size_t)(n), 1, st)
+#else
+#define DBG(name, off, n)
+#define DBGF(name, ptr, n)
+#endif
 
 namespace {
 
@@ -72,20 +98,25 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   const int use_v2 = p->masked ? 0 : p->use_v2;     // variable-length batches: generic templates (see forward)
   if (p->masked && c.simple_pool) return TN_E_UNSUPPORTED;
   auto identity_rows = [&]() { BnAct a = identity_act(); a.rm = plan_row_mask(p); return a; };
-  // wide models (hidden 512 / 1024, bf16, un-masked, train): every 1x1 conv's backward = one in-place BatchNorm-backward
+  // wide models (hidden 512 / 1024, bf16, train; variable-length batches: dS = 0 on padding rows, so the padding rows of the
+  // other operand never matter): every 1x1 conv's backward = one in-place BatchNorm-backward
   // pass (dS) + the two pipelined LDS-DMA GEMMs of tn_pgemm.h on stored operands (data gradient dS * W, weight gradient
   // dS^T * Q straight into the gradient buffer), layer by layer
-  const bool pipe = sizeof(AT) == 2 && !use_v2 && p->wide_wgrad && !p->masked && training && H % 256 == 0 && D % 256 == 0;
+  const bool pipe = sizeof(AT) == 2 && !use_v2 && p->wide_wgrad && training && H % 256 == 0 && D % 256 == 0;
   const bool batched_wgrad = sizeof(AT) == 2 && use_v2 && training && p->wg2_layers > 0;
   auto pipe_layer = [&](size_t dz, size_t y, const BnRef& bn, int Cout, const WcRef& wc, int Cin, size_t dx_out, const void* q, bool q_plain,
                         const BnAct& qact, int64_t wgrad_off) -> int {
+    DBG("pipe dZ in", dz, (size_t)M * Cout); DBG("pipe Y", y, (size_t)M * Cout);
+    DBGF("pipe bsums", ws + p->bsums[bn.id], TN_NREP * 2 * Cout); DBGF("pipe fstats", ws + p->stats[bn.id], TN_NREP * 2 * Cout);
     int rc = launch_bn_bwd_apply((bf16_t*)(ws + dz), (const bf16_t*)(ws + y), make_bnbwd(p, bn, M, training), M, Cout, st);
     if (rc) return rc;
+    DBG("pipe dS", dz, (size_t)M * Cout);
     GemmShape g{M, Cin, Cout, ws + wc.wt};
     PGemmNtArgs pa{(const bf16_t*)(ws + dz), Cout};
     PGemmEpiArgs pe{(bf16_t*)(ws + dx_out), Cin, nullptr, nullptr, nullptr};
     rc = launch_pgemm_nt(g, pa, pe, st);
     if (rc) return rc;
+    DBG("pipe dX", dx_out, (size_t)M * Cin);
     if (q_plain) {
       PGemmTnArgs ta{(const bf16_t*)(ws + dz), Cout, Cout, (const bf16_t*)q, Cin, Cin, M, grads + wgrad_off, Cin, 0, 0};
       ProfScope ps(p, TN_PROF_BWD_WGRAD, st);
@@ -95,7 +126,8 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     ProdPlain::Args qa{q, Cin, qact};
     return launch_wgrad<AT, ProdPlain, ProdPlain>(M, Cout, Cin, pp, qa, 0, slabs, p->slab_bytes, grads + wgrad_off, st);
   };
-  auto is_plain = [](const BnAct& a) { return a.mode == 0 && !a.relu && !a.drop_thr && !a.rm.len; };
+  // (a row mask on an otherwise plain operand is moot here: its partner dS is zero on the padding rows)
+  auto is_plain = [](const BnAct& a) { return a.mode == 0 && !a.relu && !a.drop_thr; };
   const bool v2_bwd = sizeof(AT) == 2 && use_v2;
   const int nb = c.n_mega_blocks;
   const int per_blk = nsub + 1;
@@ -377,6 +409,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
                            params + mb.se_w1, params + mb.se_w2, T, H, Hr, (AT*)(ws + bw.dY[nsub - 1]), bsum(mb.sub[nsub - 1].bn));
       }
     }
+    DBG("block dOUT", p->dA[cur], (size_t)M * H); DBG("combine dZk", bw.dZk, (size_t)M * H); DBG("combine dY3", bw.dY[nsub - 1], (size_t)M * H);
     // ---- skip connection: d S = BN-backward(dZ); dXs = dS * W_skip; d W_skip = dS^T X
     if (pipe) {
       int rc = pipe_layer(bw.dZk, bw.S, mb.bnskip, H, bw.wskip, H, p->dXs, xin, is_plain(actx), actx, mb.wskip);
@@ -476,7 +509,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         da.bsumsX = (i == 0) ? bsum(m->prolog_bn) : nullptr;
       }
       int rc = -1000;
-      if (sizeof(AT) == 2 && !p->masked && H % V2_C == 0 && (c.kernel == 7 || c.kernel == 11) && p->wide_dw_bwd) {
+      if (sizeof(AT) == 2 && H % V2_C == 0 && (c.kernel == 7 || c.kernel == 11) && p->wide_dw_bwd) {
         // wide models: streaming slab kernel with the tap windows in registers (tn_v2_bwd_kernels.h)
         DwBwdSlabArgs sa;
         memset(&sa, 0, sizeof(sa));
@@ -492,6 +525,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         rc = launch_dw_bwd<AT>(da, c.kernel, st);
       }
       if (rc) return rc;
+      DBG("dw_bwd OUT", (const char*)da.OUT - ws, (size_t)M * H);
     }
     cur ^= 1;
     if (grouped && next_bucket < (int)p->buckets.size() && p->buckets[next_bucket].blk_lo == i && !p->buckets[next_bucket].prolog) {

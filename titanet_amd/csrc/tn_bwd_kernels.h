@@ -1267,6 +1267,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ 
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
     const int c0 = (int)(i % VC) * 8;
     float z[8], y[8];
+    if (bn.rm.len && !tn_row_valid(bn.rm, (uint32_t)(i / VC))) {     // padding rows carry no gradient
+#pragma unroll
+      for (int u = 0; u < 8; ++u) z[u] = 0.f;
+      store8(dZ + i * 8, z);
+      continue;
+    }
     load8(dZ + i * 8, z);
     load8(Y + i * 8, y);
 #pragma unroll

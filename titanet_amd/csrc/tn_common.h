@@ -300,6 +300,14 @@ __device__ __forceinline__ float tn_dot_batched(const float* __restrict__ w, int
 // helpers of the slab kernels of the wide models (dw_bwd_slab, dw_fwd_slab): LDS-DMA, 2 / 4 channels per lane
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) char tn_lds_char;
+// wave-uniform 32-bit load through the scalar cache (lgkmcnt).  A compiler-visible VECTOR load inside these loops would be
+// waited for with vmcnt(0) — behind the next tile's LDS-DMA, which hipcc does not see (in-order counter): serialised
+__device__ __forceinline__ int tn_sload_i32(const int* base, int index) {
+  int v;
+  const int off = __builtin_amdgcn_readfirstlane(index) * 4;
+  asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(base), "s"(off) : "memory");
+  return v;
+}
 __device__ __forceinline__ void tn_dma16(const void* gptr, unsigned lds_addr) {
   unsigned keep;
   // hidden from hipcc's waitcnt bookkeeping (cdna_hip_programming.md: M0 written in the statement that reads it)

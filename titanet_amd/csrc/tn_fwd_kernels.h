@@ -204,6 +204,7 @@ __global__ __launch_bounds__(512, 2) void dw_fwd_slab_kernel(DwFwdSlabArgs a) {
   const int slab = blockIdx.x % nslab, first = blockIdx.x / nslab, stride = gridDim.x / nslab;
   const int cb = slab * 256;
   const uint32_t dkey = tn_act_key(a.act), dthr = a.act.drop_thr;
+  const int* __restrict__ len = a.act.rm.len;                    // valid frames per utterance or null (uniform)
   if (tid < 256) {
     float s = 1.f, h = 0.f;
     if (FL & 1) bn_scale_shift(a.act, a.C, cb + tid, s, h);
@@ -243,7 +244,31 @@ __global__ __launch_bounds__(512, 2) void dw_fwd_slab_kernel(DwFwdSlabArgs a) {
     const int out0 = tile * 64, raw0 = out0 - PADR;
     const int l0 = strip * RS;
     const int g_first = raw0 + l0, g_last = g_first + KD + RS - 2;
-    const bool fast = g_first >= 0 && g_last < a.M && (g_first % a.T) + KD + RS - 2 < a.T;   // wave-uniform
+    // variable-length batches (a.act.rm.len): frames >= len[b] are padding — they read as zeros and are WRITTEN as zeros (the
+    // pointwise GEMM then sees a plain operand whose padding rows give y = bias exactly, tn_pgemm.h pad_rows)
+    const int tf = g_first >= 0 ? g_first % a.T : 0;
+    const bool inside = g_first >= 0 && g_last < a.M && tf + KD + RS - 2 < a.T;              // window inside one utterance
+    int Lf = a.T;
+    if (len && inside) Lf = tn_sload_i32(len, g_first / a.T);
+    const bool fast = inside && tf + KD + RS - 2 < Lf;                                       // wave-uniform
+    auto row_ok = [&](int gr) -> bool {                                                      // wave-uniform argument
+      if (gr < 0 || gr >= a.M) return false;
+      if (!len) return true;
+      const int b = gr / a.T;
+      return gr - b * a.T < tn_sload_i32(len, b);
+    };
+    if (len && inside && tf + PADR >= Lf) {
+      // every output row of the strip is padding
+      float z[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) z[i] = 0.f;
+#pragma unroll
+      for (int o = 0; o < RS; ++o) {
+        const int gr = out0 + l0 + o;
+        st_ch<CH>(a.Q + (size_t)gr * a.C + cb + cl, z);
+        if (CH == 4 && a.Q8) *reinterpret_cast<uint32_t*>(a.Q8 + (size_t)gr * a.C + cb + cl) = 0u;
+      }
+    } else
     // one path: the window of activated rows rolls down the strip either way (a row is activated ONCE — with the dropout
     // hash per tap the boundary strips, 9 % of them at T = 300, cost more than all the others together); strips whose window
     // leaves the utterance of an output row only add a wave-uniform test per tap
@@ -251,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void dw_fwd_slab_kernel(DwFwdSlabArgs a) {
       float A[KD][CH];
       auto place = [&](int j, int slot) {
         const int gr = g_first + j;
-        if (fast || (gr >= 0 && gr < a.M)) {
+        if (fast || row_ok(gr)) {
           ld_ch<CH>(Xs + (l0 + j) * 256 + cl, A[slot]);
           act_c<FL, CH>(A[slot], sc, sh, dkey, dthr, (uint32_t)gr, a.C, cb + cl);
         } else {
@@ -283,6 +308,10 @@ __global__ __launch_bounds__(512, 2) void dw_fwd_slab_kernel(DwFwdSlabArgs a) {
               for (int i = 0; i < CH; ++i) q[i] = fmaf(wd[k][i], A[(o + k) % KD][i], q[i]);
             }
           }
+          if (len && !row_ok(gr)) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) q[i] = 0.f;
+          }
         }
         if (fast || gr < a.M) {
           st_ch<CH>(a.Q + (size_t)gr * a.C + cb + cl, q);
@@ -303,7 +332,7 @@ inline int launch_dw_fwd_slab_t(DwFwdSlabArgs a, int grid, hipStream_t st) {
 }
 // -1000: no specialisation (caller runs dw_fwd_kernel)
 inline int launch_dw_fwd_slab(DwFwdSlabArgs a, int KD, hipStream_t st) {
-  if (a.C % 256 != 0 || a.act.rm.len) return -1000;
+  if (a.C % 256 != 0) return -1000;
   a.ntiles = (a.M + 63) / 64;
   const int nslab = a.C / 256;
   int per = 256 / nslab;
@@ -454,8 +483,9 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(const AT* __restrict__
     load8(Y3 + (size_t)row * C + c0, y);
     load8(gate + (size_t)b * C + c0, g);
     act8(y, sc3 + c0, sh3 + c0, act3, (uint32_t)row, C, c0);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) o[q] = fmaxf(s[q] * scS[c0 + q] + shS[c0 + q] + g[q] * y[q], 0.f);
+    const bool pad = act3.rm.len && !tn_row_valid(act3.rm, (uint32_t)row);     // padding rows are stored as zeros: the block
+#pragma unroll                                                                 // output is a plain operand for its consumers
+    for (int q = 0; q < 8; ++q) o[q] = pad ? 0.f : fmaxf(s[q] * scS[c0 + q] + shS[c0 + q] + g[q] * y[q], 0.f);
     if (drop_thr) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) o[q] *= inv_keep;

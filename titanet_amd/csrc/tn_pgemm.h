@@ -65,6 +65,8 @@ struct PGemmEpiArgs {
   const float* bias;       // [N] or null
   float* stats;            // [TN_NREP][2][N] column sums / sums of squares of y over the rows < M, or null
   const float* colscale;   // [N] or null: y = acc * colscale[n] + bias[n]
+  float pad_rows;          // variable-length batches: that many rows < M of A are all-zero padding (y == bias there, exactly):
+                           // their contribution is taken out of `stats` again (sums over the valid rows only)
 };
 
 // DBG (tuning only): 1 no MFMA, 2 no DMA after the prologue, 4 linear DMA source (wrong results), 8 no output stores
@@ -237,6 +239,10 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
         if (ea.stats) {
           s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64);
           q0 += __shfl_xor(q0, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+          if (mt_ == 0 && wm == 0 && ea.pad_rows != 0.f) {       // once per column: one wave of the first row tile carries the correction
+            s0 = fmaf(-ea.pad_rows, bv[0], s0); s1 = fmaf(-ea.pad_rows, bv[1], s1);
+            q0 = fmaf(-ea.pad_rows * bv[0], bv[0], q0); q1 = fmaf(-ea.pad_rows * bv[1], bv[1], q1);
+          }
           float* sp = ea.stats + (size_t)((blockIdx.x % TN_NREP) * 2 + fh) * g.N + ncol;     // lower half: sums, upper: squares
           pg_atomic_add(sp, fh ? q0 : s0);
           pg_atomic_add(sp + 1, fh ? q1 : s1);

@@ -608,24 +608,23 @@ inline int launch_combine_bwd2_v2(const CombineBwd2V2Args& a, int B, hipStream_t
 //   * strips whose window crosses an utterance / batch boundary take a per-tap path with wave-uniform tests.
 // FL bits as in dw_bwd_v4: 1 BatchNorm on load of X, 2 ReLU, 4 dropout, 8 skip-path addend.
 // ==========================================================================================
-// wait until at most n (wave-uniform, even, <= 10) younger vector-memory operations are outstanding, naming the registers of
-// the asm loads this retires (so that no consumer is scheduled above the wait)
-template <int RS>
-__device__ __forceinline__ void tn_wait_add(int n, uint32_t (&r)[RS]) {
-#define TN_WAIT_NAMED(N)                                                                                            \
-  do {                                                                                                              \
-    asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4 % RS]), "+v"(r[5 % RS]), "+v"(r[6 % RS]), "+v"(r[7 % RS])); \
-    if (RS > 8) asm volatile("" : "+v"(r[8 % RS]), "+v"(r[9 % RS]), "+v"(r[10 % RS]), "+v"(r[11 % RS]), "+v"(r[12 % RS]), "+v"(r[13 % RS]), "+v"(r[14 % RS]), "+v"(r[15 % RS])); \
-  } while (0)
-  switch (n) {
-    case 0: TN_WAIT_NAMED(0); break;
-    case 2: TN_WAIT_NAMED(2); break;
-    case 4: TN_WAIT_NAMED(4); break;
-    case 6: TN_WAIT_NAMED(6); break;
-    case 8: TN_WAIT_NAMED(8); break;
-    default: TN_WAIT_NAMED(10); break;
-  }
-#undef TN_WAIT_NAMED
+// wait until at most N younger vector-memory operations are outstanding, naming the registers of the asm loads this retires
+// (no consumer is scheduled above the wait).  ONE statement with a compile-time count: a switch over run-time counts made
+// hipcc merge the per-case "+v" values with v_mov copies placed BEFORE the wait — reads of registers whose loads were still
+// in flight (non-finite gradients now and then at large batches).  The callers therefore issue the same number of DMA
+// instructions on every wave and every tile (dma_tile<PADDED>).
+template <int N, int RS>
+__device__ __forceinline__ void tn_wait_add(uint32_t (&r)[RS]) {
+  static_assert(RS == 4 || RS == 8 || RS == 16, "register count of the addend rows");
+  if constexpr (RS == 16)
+    asm volatile("s_waitcnt vmcnt(%16)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]),
+                   "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15])
+                 : "n"(N));
+  else if constexpr (RS == 8)
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "n"(N));
+  else
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N));
 }
 struct DwBwdSlabArgs {
   const bf16_t* dD; const bf16_t* X; BnAct actX;
@@ -660,6 +659,7 @@ __global__ __launch_bounds__(512, 2) void dw_bwd_slab_kernel(DwBwdSlabArgs a) {
   const int cb = slab * V2_C;                                  // first channel of the slab
   const float mscale = (FL & 4) ? a.actX.inv_keep : 1.f;
   const uint32_t dkey = tn_act_key(a.actX), dthr = a.actX.drop_thr;
+  const int* __restrict__ len = a.actX.rm.len;                 // valid frames per utterance or null (uniform)
   if (tid < V2_C) {
     float s = 1.f, h = 0.f, mean = 0.f, rstd = 1.f;
     if (FL & 1) { bn_scale_shift(a.actX, a.C, cb + tid, s, h); bn_mean_rstd(a.actX, a.C, cb + tid, mean, rstd); }
@@ -670,11 +670,15 @@ __global__ __launch_bounds__(512, 2) void dw_bwd_slab_kernel(DwBwdSlabArgs a) {
   // every compiler-visible load is complete before the first DMA: the waits below are plain vmcnt(0)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // this wave's rows of a tile: 2 rows (1 KB) per instruction, rows 2 * (wave + 8 i)
+  // (with the skip-path addend every wave issues NPIECE pieces — a wave with one piece less repeats its first one — so that
+  //  the count in the wait for the addend rows is a compile-time constant, see tn_wait_add)
+  constexpr int NPIECE = (ROWS / 2 + 7) / 8;
   auto dma_tile = [&](int tile, int buf) {
     const int raw0 = tile * 64 - PADR;
 #pragma unroll
-    for (int i = 0; i < (ROWS / 2 + 7) / 8; ++i) {
-      const int r = 2 * (wave + 8 * i);
+    for (int i = 0; i < NPIECE; ++i) {
+      int r = 2 * (wave + 8 * i);
+      if (HAS_ADD && r >= ROWS) r = 2 * wave;
       if (r < ROWS) {
         int gr = raw0 + r + (lane >> 5);
         gr = gr < 0 ? 0 : (gr >= a.M ? a.M - 1 : gr);          // rows outside the tensor: any valid row (never used)
@@ -725,11 +729,10 @@ __global__ __launch_bounds__(512, 2) void dw_bwd_slab_kernel(DwBwdSlabArgs a) {
     }
     const bool more = tile + stride < a.ntiles;
     if (more) dma_tile(tile + stride, buf ^ 1);
+    else if (HAS_ADD) dma_tile(tile, buf ^ 1);                // last tile: the same count of DMA instructions (into the free buffer)
     float addv[HAS_ADD ? RS : 1][CH];
     if constexpr (HAS_ADD) {
-      // DMA instructions this wave just issued: 2 per 2-row piece, pieces r = 2 (wave + 8 i) < ROWS
-      const int n_dma = more ? 2 * ((ROWS / 2 - wave + 7) / 8) : 0;
-      tn_wait_add<NADD>(__builtin_amdgcn_readfirstlane(n_dma), addr_);
+      tn_wait_add<2 * NPIECE, NADD>(addr_);                   // 2 DMA instructions per piece were issued after the addend loads
 #pragma unroll
       for (int o = 0; o < RS; ++o)
 #pragma unroll
@@ -741,8 +744,20 @@ __global__ __launch_bounds__(512, 2) void dw_bwd_slab_kernel(DwBwdSlabArgs a) {
     const bf16_t* Ds = reinterpret_cast<const bf16_t*>(smem + buf * 2 * TILE_B);
     const bf16_t* Xs = reinterpret_cast<const bf16_t*>(smem + buf * 2 * TILE_B + TILE_B);
     const int g_first = raw0 + l0, g_last = g_first + KD + RS - 2;   // window rows l0 .. l0 + KD + RS - 2
-    const bool fast = g_first >= 0 && g_last < a.M && (g_first % a.T) + KD + RS - 2 < a.T;   // wave-uniform
-    if (fast) {
+    // variable-length batches: dD is zero on padding rows (the BatchNorm-backward pass writes dS = 0 there); padding rows
+    // of X read as zeros (no tap-weight gradient through them) and the data gradient is WRITTEN as zero there
+    const int tf = g_first >= 0 ? g_first % a.T : 0;
+    const bool inside = g_first >= 0 && g_last < a.M && tf + KD + RS - 2 < a.T;              // window inside one utterance
+    int Lf = a.T;
+    if (len && inside) Lf = tn_sload_i32(len, g_first / a.T);
+    const bool fast = inside && tf + KD + RS - 2 < Lf;                                       // wave-uniform
+    if (len && inside && tf + PADR >= Lf) {
+      float z[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) z[i] = 0.f;
+#pragma unroll
+      for (int o = 0; o < RS; ++o) st_ch<CH>(a.OUT + (size_t)(out0 + l0 + o) * a.C + cb + cl, z);
+    } else if (fast) {
       // d w[k] = sum_r dD[r] A[r + k - pad] is summed here over the A rows of the strip (r' = r + k - pad): its dD operand is
       // then dD[r' - k + pad], the SAME row the data gradient of output row r' multiplies with w[k] — one window (of dD) serves
       // both sums and the activation is evaluated once per output row, not once per window row.
@@ -798,6 +813,14 @@ __global__ __launch_bounds__(512, 2) void dw_bwd_slab_kernel(DwBwdSlabArgs a) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) { dA[i] = 0.f; gb[i] += Dc[i]; Ac[i] = Yc[i]; }
         act_c<(FL & 7), CH>(Ac, sc, sh, dkey, dthr, (uint32_t)gr, a.C, cb + cl);
+        bool pad = false;
+        if (len) {
+          pad = t >= tn_sload_i32(len, gr / a.T);
+        }
+        if (pad) {
+#pragma unroll
+          for (int i = 0; i < CH; ++i) Ac[i] = 0.f;
+        }
 #pragma unroll
         for (int k = 0; k < KD; ++k) {
           const int tb = t - k + PADR;               // frame of dD[gr - k + PADR]: inside this utterance?
@@ -814,6 +837,10 @@ __global__ __launch_bounds__(512, 2) void dw_bwd_slab_kernel(DwBwdSlabArgs a) {
           ld_ch<CH>(a.ADD + oo, ad);
 #pragma unroll
           for (int i = 0; i < CH; ++i) dA[i] += ad[i];
+        }
+        if (pad) {
+#pragma unroll
+          for (int i = 0; i < CH; ++i) dA[i] = 0.f;
         }
         if (HAS_MASK) {
 #pragma unroll

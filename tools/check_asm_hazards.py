@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Static check of the one hazard hipcc cannot see: a register that an inline-asm load (`global_load_dword vN, ...` between
+;;#ASMSTART / ;;#ASMEND) is still filling must not be read before the inline-asm `s_waitcnt vmcnt(..)` that retires it.  The
+compiler believes the value exists as soon as the asm statement has "executed", so any copy it schedules in between (PHI
+copies of a switch over "+v" operands did exactly that in dw_bwd_slab: non-finite gradients now and then) reads stale data.
+
+    python tools/check_asm_hazards.py [file.hip ...]      # exit 1 on a finding
+"""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "titanet_amd", "csrc")
+sys.path.insert(0, ROOT)
+from titanet_amd.csrc.build import FLAGS, SOURCES  # noqa: E402
+
+
+def regs_of(tok):
+    """v12 -> {12}; v[4:7] -> {4..7}"""
+    out = set()
+    for m in re.finditer(r"\bv(\d+)\b", tok):
+        out.add(int(m.group(1)))
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", tok):
+        out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def check_asm(text):
+    findings = []
+    func = None
+    pending = {}          # register -> line of the asm load filling it
+    in_asm = False
+    for n, line in enumerate(text.split("\n"), 1):
+        s = line.strip()
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            func, pending = m.group(1), {}
+            continue
+        if s.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if s.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not s or s.startswith(";") or s.startswith("."):
+            continue
+        code = s.split(";")[0]
+        if in_asm:
+            if re.match(r"s_waitcnt\s+vmcnt", code):
+                pending = {}
+            m = re.match(r"global_load_dword(?:x\d)?\s+(v\d+|v\[\d+:\d+\])\s*,", code)
+            if m and "lds" not in code:
+                for r in regs_of(m.group(1)):
+                    pending[r] = n
+            continue
+        if code.startswith("s_endpgm"):
+            pending = {}
+            continue
+        if pending:
+            if re.match(r"s_waitcnt\s+vmcnt\(0\)", code):
+                pending = {}
+                continue
+            ops = code.split(None, 1)
+            used = regs_of(ops[1]) if len(ops) > 1 else set()
+            hit = used & set(pending)
+            if hit:
+                findings.append((func, n, code, sorted(hit)))
+    return findings
+
+
+def main():
+    srcs = [os.path.basename(a) for a in sys.argv[1:]] or SOURCES
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(src):
+        cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + [f for f in FLAGS if f != "-fPIC"] + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", "-"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            raise SystemExit(r.stderr[-2000:])
+        return src, check_asm(r.stdout)
+    bad = 0
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for src, f in ex.map(one, srcs):
+            print(f"{src}: {len(f)} reads of in-flight asm-load registers")
+            for func, n, code, regs in f[:20]:
+                print(f"   {func[:60]} line {n}: {code}   (v{regs})")
+            bad += len(f)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
