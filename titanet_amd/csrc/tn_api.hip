@@ -914,12 +914,14 @@ extern "C" int tn_forward(tn_plan* p, const float* spectrograms, const int64_t* 
   return plan_forward(p, spectrograms, speakers, training, seed, embeddings, preds, loss, (hipStream_t)stream);
 }
 
-extern "C" int tn_forward_masked(tn_plan* p, const float* spectrograms, const int64_t* lengths_host, const int64_t* speakers,
-                                 int32_t training, uint64_t seed, float* embeddings, int64_t* preds, float* loss, void* stream) {
-  if (!lengths_host) return tn_forward(p, spectrograms, speakers, training, seed, embeddings, preds, loss, stream);
-  if (!p || !spectrograms) return TN_E_BADARG;
-  if (!p->bound) return TN_E_NOTBOUND;
-  if (training && p->B < 2) return TN_E_BADARG;
+// the valid-frame counts travel as KERNEL ARGUMENTS (copied at launch): an H2D copy from pageable host memory blocks the
+// calling thread until the stream has drained (a sleep / wake-up round trip per step on the host), a pinned staging buffer
+// would have to outlive the in-flight steps that still read it
+struct LensChunk { int v[512]; };
+__global__ void lens_write_kernel(LensChunk c, int n, int* __restrict__ dst) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = c.v[i];
+}
+static int plan_set_lengths(tn_plan* p, const int64_t* lengths_host, int training, hipStream_t st) {
   p->lens_host.resize(p->B);
   long total = 0;
   for (int b = 0; b < p->B; ++b) {
@@ -930,8 +932,22 @@ extern "C" int tn_forward_masked(tn_plan* p, const float* spectrograms, const in
   if (training && total < 2) return TN_E_BADARG;
   p->n_valid = (int)total;
   p->masked = true;
-  // pageable host memory: the runtime stages the bytes before the call returns
-  TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->lens, p->lens_host.data(), sizeof(int) * (size_t)p->B, hipMemcpyHostToDevice, (hipStream_t)stream));
+  for (int b0 = 0; b0 < p->B; b0 += 512) {
+    LensChunk c;
+    const int n = std::min(512, p->B - b0);
+    memcpy(c.v, p->lens_host.data() + b0, sizeof(int) * (size_t)n);
+    hipLaunchKernelGGL(lens_write_kernel, dim3(1), dim3(256), 0, st, c, n, (int*)(p->ws + p->lens) + b0);
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int tn_forward_masked(tn_plan* p, const float* spectrograms, const int64_t* lengths_host, const int64_t* speakers,
+                                 int32_t training, uint64_t seed, float* embeddings, int64_t* preds, float* loss, void* stream) {
+  if (!lengths_host) return tn_forward(p, spectrograms, speakers, training, seed, embeddings, preds, loss, stream);
+  if (!p || !spectrograms) return TN_E_BADARG;
+  if (!p->bound) return TN_E_NOTBOUND;
+  if (training && p->B < 2) return TN_E_BADARG;
+  { int rc = plan_set_lengths(p, lengths_host, training, (hipStream_t)stream); if (rc) return rc; }
   return plan_forward(p, spectrograms, speakers, training, seed, embeddings, preds, loss, (hipStream_t)stream);
 }
 
@@ -948,17 +964,8 @@ extern "C" int tn_forward_prepacked(tn_plan* p, const int64_t* lengths_host, con
   if (training && p->B < 2) return TN_E_BADARG;
   p->masked = false;
   if (lengths_host) {
-    p->lens_host.resize(p->B);
-    long total = 0;
-    for (int b = 0; b < p->B; ++b) {
-      if (lengths_host[b] < 1 || lengths_host[b] > p->T) return TN_E_BADARG;
-      p->lens_host[b] = (int)lengths_host[b];
-      total += lengths_host[b];
-    }
-    if (training && total < 2) return TN_E_BADARG;
-    p->n_valid = (int)total;
-    p->masked = true;
-    TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->lens, p->lens_host.data(), sizeof(int) * (size_t)p->B, hipMemcpyHostToDevice, (hipStream_t)stream));
+    int rc = plan_set_lengths(p, lengths_host, training, (hipStream_t)stream);
+    if (rc) return rc;
   }
   return plan_forward(p, nullptr, speakers, training, seed, embeddings, preds, loss, (hipStream_t)stream);
 }

@@ -42,6 +42,33 @@ class MelSpectrogram:
         self.device = torch.device(device)
         self._lib = _lib.load()
         self._handle = None
+        self._ring, self._ring_i = [None] * 4, 0
+
+    def _upload(self, parts):
+        """Small per-batch host arrays (lengths, rates, masks) -> device tensors through ONE asynchronous copy from a pinned
+        staging slot (a ring of 4, each guarded by an event).  ``tensor.to(device)`` from pageable memory blocks the calling
+        thread until the stream has drained — one sleep / wake-up round trip per array and step, which on a busy host cost more
+        than the whole network step (configs[3] leg: 26 -> 30-70 ms)."""
+        offs, total = [], 0
+        for t in parts:
+            offs.append(total)
+            total += (t.numel() * t.element_size() + 15) // 16 * 16
+        k = self._ring_i % len(self._ring)
+        self._ring_i += 1
+        slot = self._ring[k]
+        if slot is None or slot[0].numel() < total:
+            cap = max(4096, 1 << (total - 1).bit_length())
+            slot = self._ring[k] = (torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=self.device),
+                                    torch.cuda.Event())
+        else:
+            slot[2].synchronize()                      # the copy that last used this slot (4 batches ago) has run
+        host, dev, ev = slot
+        for t, o in zip(parts, offs):
+            n = t.numel() * t.element_size()
+            host[o:o + n].view(t.dtype).copy_(t.reshape(-1))
+        dev[:total].copy_(host[:total], non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        return [dev[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for t, o in zip(parts, offs)]
 
     def _mel(self):
         if self._handle is None:
@@ -107,12 +134,17 @@ class MelSpectrogram:
         if time_masks is not None:
             T = max(T, time_masks.shape[1])
         out = None if into is not None else torch.empty(B, self.n_mels, T, dtype=torch.float32, device=self.device)
-        ln_d, rt_d = ln.to(self.device), rt.to(self.device)
-        fm = freq_masks.to(device=self.device, dtype=torch.uint8).contiguous() if freq_masks is not None else None
-        tm = None
+        parts = [ln, rt]
+        if freq_masks is not None:
+            parts.append(freq_masks.detach().to(device="cpu", dtype=torch.uint8).contiguous())
         if time_masks is not None:
-            tm = torch.zeros(B, T, dtype=torch.uint8, device=self.device)
-            tm[:, :time_masks.shape[1]] = time_masks.to(device=self.device, dtype=torch.uint8)
+            tm_h = torch.zeros(B, T, dtype=torch.uint8)
+            tm_h[:, :time_masks.shape[1]] = time_masks.detach().to(device="cpu", dtype=torch.uint8)
+            parts.append(tm_h)
+        up = self._upload(parts)
+        ln_d, rt_d = up[0], up[1]
+        fm = up[2] if freq_masks is not None else None
+        tm = up[-1] if time_masks is not None else None
         self.last_frames = frames
         if into is not None:
             from .models import PackedSpectrograms
