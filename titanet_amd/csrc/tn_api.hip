@@ -197,6 +197,10 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   p->bsums.resize(m->n_bn);
   for (int i = 0; i < m->n_bn; ++i) p->stats[i] = b.take((size_t)TN_NREP * 2 * m->all_bn[i].C * sizeof(float));
   p->loss_acc = b.take(256);
+  p->tail_parts = 1;
+  // (utterances of >= 512 frames only: the summation tree of the SE mean changes with the number of parts, and the short
+  //  fixed-length batches keep embeddings that do not depend on the batch they are computed in, bit for bit)
+  if (batch * 2 <= 256 && frames >= 512) p->tail_parts = std::max(1, std::min(std::min(256 / batch, 16), frames / 128));
   p->zero_bytes = ((b.off + 255) & ~(size_t)255) - p->zero_begin;
   b.off = p->zero_begin + p->zero_bytes;
   // ---- region cleared at the start of every backward (so a backward can be repeated from one forward,
@@ -208,11 +212,13 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     p->wg2_count = b.take(sizeof(int) * (size_t)(c.n_mega_blocks * (c.n_sub_blocks + 1) * hs * hs + (D / 256 + 1) * hs + 2 * (D / 256) + 1));
   }
   p->dw_gacc = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * TN_NREP * (c.kernel + 1) * H * sizeof(float));
+  if (p->tail_parts > 1) p->dgate_acc = b.take((size_t)c.n_mega_blocks * batch * H * sizeof(float));
   p->bzero_bytes = ((b.off + 255) & ~(size_t)255) - p->bzero_begin;
   b.off = p->bzero_begin + p->bzero_bytes;
   // ---- device-resident step state {uint64 step; uint32 word; ...}: cleared once at bind, advanced by tn_plan_step_tick
   p->step_state = b.take(64);
   p->lens = b.take(sizeof(int) * (size_t)batch);
+  if (p->tail_parts > 1) p->se_acc = b.take((size_t)batch * p->tail_parts * H * sizeof(float));      // one block at a time
   // ---- compute-precision weights
   auto wc = [&](size_t n, size_t k) {
     WcRef r; r.w = b.take(n * k * e); r.wt = b.take(n * k * e);
@@ -750,9 +756,14 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
         rc1 = launch_se_squeeze_v2(sa, B, st);
         if (rc1 > 0) return rc1;
       }
-      if (rc1 == -1000)
+      if (rc1 == -1000) {
+        float* acc = p->tail_parts > 1 ? (float*)(ws + p->se_acc) : nullptr;
+        if (acc)     // partial column sums from tail_parts workgroups per utterance, then the two mat-vecs per utterance
+          hipLaunchKernelGGL(se_squeeze_fc_kernel<AT>, dim3(B, p->tail_parts), dim3(512), smem, st, (const AT*)cur, acur, T, H, Hr,
+                             params + mb.se_w1, params + mb.se_w2, (float*)(ws + bw.m), (float*)(ws + bw.h), (float*)(ws + bw.g), acc, 1, p->tail_parts);
         hipLaunchKernelGGL(se_squeeze_fc_kernel<AT>, dim3(B), dim3(512), smem, st, (const AT*)cur, acur, T, H, Hr,
-                           params + mb.se_w1, params + mb.se_w2, (float*)(ws + bw.m), (float*)(ws + bw.h), (float*)(ws + bw.g));
+                           params + mb.se_w1, params + mb.se_w2, (float*)(ws + bw.m), (float*)(ws + bw.h), (float*)(ws + bw.g), acc, acc ? 2 : 0, p->tail_parts);
+      }
       BnAct acts = make_act(p, mb.bnskip, M, training, 0, 0.f, seed, 0);
       uint32_t thr = 0, key = 0;
       float ik = 1.f;
@@ -843,9 +854,14 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       rc = gemm_store<AT, ProdPlain>(g2, pa2, ea2, 0, st);
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(asp_pool_fwd_kernel<AT>, dim3(B, (D + 511) / 512), dim3(256), 0, st, (const AT*)(ws + p->E), acte,
-                       (const AT*)(ws + p->EN), T, D, 1e-6f, (float*)(ws + p->pooled), (float*)(ws + p->smax),
-                       (float*)(ws + p->sinv), (float*)(ws + p->qv), statp(m->pool_bn));
+    if (p->tail_parts > 1)
+      hipLaunchKernelGGL((asp_pool_fwd_kernel<AT, 16, 16>), dim3(B, (D + 127) / 128), dim3(256), 0, st, (const AT*)(ws + p->E), acte,
+                         (const AT*)(ws + p->EN), T, D, 1e-6f, (float*)(ws + p->pooled), (float*)(ws + p->smax),
+                         (float*)(ws + p->sinv), (float*)(ws + p->qv), statp(m->pool_bn));
+    else
+      hipLaunchKernelGGL(asp_pool_fwd_kernel<AT>, dim3(B, (D + 511) / 512), dim3(256), 0, st, (const AT*)(ws + p->E), acte,
+                         (const AT*)(ws + p->EN), T, D, 1e-6f, (float*)(ws + p->pooled), (float*)(ws + p->smax),
+                         (float*)(ws + p->sinv), (float*)(ws + p->qv), statp(m->pool_bn));
   }
   // ---- decoder tail + loss head (reference src/models.py:504-513, src/losses.py)
   {

@@ -263,10 +263,16 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
                        (const AT*)(ws + p->E), acte, T, D, (AT*)(ws + p->dEbn), bsum(m->epi_bn));
   } else
   {
-    hipLaunchKernelGGL(asp_bwd_de_kernel<AT>, dim3(B, (D + 511) / 512), dim3(256), 0, st, (const AT*)(ws + p->E), acte,
-                       (const AT*)(ws + p->EN), T, D, 1e-6f, (const float*)(ws + p->pooled), (const float*)(ws + p->qv),
-                       (const float*)(ws + p->smax), (const float*)(ws + p->sinv), (const float*)(ws + p->dpooled),
-                       (AT*)(ws + p->dE), (AT*)(ws + p->dEbn), grads + m->asp_bout);
+    if (p->tail_parts > 1)
+      hipLaunchKernelGGL((asp_bwd_de_kernel<AT, 16, 16>), dim3(B, (D + 127) / 128), dim3(256), 0, st, (const AT*)(ws + p->E), acte,
+                         (const AT*)(ws + p->EN), T, D, 1e-6f, (const float*)(ws + p->pooled), (const float*)(ws + p->qv),
+                         (const float*)(ws + p->smax), (const float*)(ws + p->sinv), (const float*)(ws + p->dpooled),
+                         (AT*)(ws + p->dE), (AT*)(ws + p->dEbn), grads + m->asp_bout);
+    else
+      hipLaunchKernelGGL(asp_bwd_de_kernel<AT>, dim3(B, (D + 511) / 512), dim3(256), 0, st, (const AT*)(ws + p->E), acte,
+                         (const AT*)(ws + p->EN), T, D, 1e-6f, (const float*)(ws + p->pooled), (const float*)(ws + p->qv),
+                         (const float*)(ws + p->smax), (const float*)(ws + p->sinv), (const float*)(ws + p->dpooled),
+                         (AT*)(ws + p->dE), (AT*)(ws + p->dEbn), grads + m->asp_bout);
     // d W_out[c][a] = sum_r dEN[r][c] * hid[r][a]      (units of the batched weight-gradient launch when that runs)
     const bool asp_batched = batched_wgrad && p->wg2_asp_units > 0;
     if (!asp_batched) {
@@ -379,13 +385,18 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         rc1 = launch_combine_bwd1_v2(c1, B, st);
         if (rc1 > 0) return rc1;
       }
+      // generic kernels: tail_parts workgroups per utterance for small batches of long utterances (dgate accumulated in
+      // the pre-zeroed dgate_acc, pass 2 reads it and writes dpre2)
+      const int parts = p->tail_parts;
+      float* dgate_acc = parts > 1 ? (float*)(ws + p->dgate_acc) + (size_t)i * B * H : nullptr;
       if (rc1 == -1000)
-      hipLaunchKernelGGL(k1, dim3(B), dim3(512), smem, st, (const AT*)(ws + p->dA[cur]), (const float*)(ws + bw.g),
+      hipLaunchKernelGGL(k1, dim3(B, parts), dim3(512), smem, st, (const AT*)(ws + p->dA[cur]), (const float*)(ws + bw.g),
                          (const AT*)(ws + bw.Y[nsub - 1]), act3, (const AT*)(ws + bw.S), acts, T, H, inv_keep, othr, okey,
                          (const uint32_t*)(ws + p->step_state) + 2, (AT*)(ws + bw.dZk),
-                         (float*)(ws + ((v2_bwd && Hr == 16) ? bw.dgate : bw.dpre2)), bsum(mb.bnskip));
+                         dgate_acc ? dgate_acc : (float*)(ws + ((v2_bwd && Hr == 16) ? bw.dgate : bw.dpre2)), bsum(mb.bnskip));
       int rc2 = -1000;
-      if (v2_bwd && Hr == 16) {
+      const bool split = rc1 == -1000 && dgate_acc;        // the generic pass 1 ran in parts: so does pass 2
+      if (v2_bwd && Hr == 16 && !split) {
         // pass 1 left dgate in bw.dpre2; copy-free hand-over: pass 2 (v2) reads it from bw.dgate, so move the pointer roles:
         // pass 1 wrote to bw.dgate (see above), pass 2 writes bw.dpre2
         CombineBwd2V2Args ca;
@@ -399,13 +410,14 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         if (rc2 > 0) return rc2;
       }
       if (rc2 == -1000) {
-        if (v2_bwd && Hr == 16)   // pass 1 wrote dgate to bw.dgate; the generic pass 2 works in place on bw.dpre2
+        if (v2_bwd && Hr == 16 && !split)   // pass 1 wrote dgate to bw.dgate; the generic pass 2 works in place on bw.dpre2
           TN_CHECK_HIP(hipMemcpyAsync(ws + bw.dpre2, ws + bw.dgate, (size_t)B * H * sizeof(float), hipMemcpyDeviceToDevice, st));
         smem = (size_t)(7 * H + ((Hr + 3) & ~3) + TG * 2 * H) * sizeof(float);
         auto k2 = combine_bwd2_kernel<AT>;
         if (smem > 64 * 1024) TN_CHECK_HIP(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(k2, dim3(B), dim3(512), smem, st, (const AT*)(ws + bw.dZk), (const AT*)(ws + bw.Y[nsub - 1]), act3,
-                           (const float*)(ws + bw.g), (const float*)(ws + bw.h), (float*)(ws + bw.dpre2), (float*)(ws + bw.dpre1),
+        hipLaunchKernelGGL(k2, dim3(B, split ? parts : 1), dim3(512), smem, st, (const AT*)(ws + bw.dZk), (const AT*)(ws + bw.Y[nsub - 1]), act3,
+                           (const float*)(ws + bw.g), (const float*)(ws + bw.h), split ? (const float*)dgate_acc : (const float*)(ws + bw.dpre2),
+                           (float*)(ws + bw.dpre2), (float*)(ws + bw.dpre1),
                            params + mb.se_w1, params + mb.se_w2, T, H, Hr, (AT*)(ws + bw.dY[nsub - 1]), bsum(mb.sub[nsub - 1].bn));
       }
     }

@@ -487,6 +487,11 @@ __global__ __launch_bounds__(512) void combine_bwd1_kernel(const AT* __restrict_
   __syncthreads();
   const uint32_t okey = key_add ? drop_key + *key_add : drop_key;
   const int vc = tid % CV, tg = tid / CV, c0 = vc * 8;
+  // gridDim.y workgroups per utterance (small batches of long utterances), each a range of frames; frames >= len[b] are
+  // padding: not read, their gradient written as zero.  With more than one part dgate is ACCUMULATED (pre-zeroed buffer)
+  const int L = act3.rm.len ? act3.rm.len[b] : T;
+  const int per = (T + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int t_lo = (int)blockIdx.y * per, t_end = min(T, t_lo + per), t_hi = min(L, t_end);
   if (tg < TG) {
     float dg[8], s1[8], s2[8];
 #pragma unroll
@@ -499,12 +504,12 @@ __global__ __launch_bounds__(512) void combine_bwd1_kernel(const AT* __restrict_
       k3[i] = sc3[c0 + i]; h3[i] = sh3[c0 + i];
     }
     constexpr int U = 2;
-    for (int t0 = tg; t0 < T; t0 += TG * U) {
+    for (int t0 = t_lo + tg; t0 < t_hi; t0 += TG * U) {
       float d[U][8], y[U][8], sv[U][8];
 #pragma unroll
       for (int q = 0; q < U; ++q) {
         const int t = t0 + q * TG;
-        if (t < T) {
+        if (t < t_hi) {
           const size_t o = ((size_t)b * T + t) * C + c0;
           load8(dOUT + o, d[q]);
           load8(Y3 + o, y[q]);
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(512) void combine_bwd1_kernel(const AT* __restrict_
 #pragma unroll
       for (int q = 0; q < U; ++q) {
         const int t = t0 + q * TG;
-        if (t < T) {
+        if (t < t_hi) {
           const uint32_t row = (uint32_t)b * T + t;
           float u[8];
           act8(y[q], k3, h3, act3, row, C, c0);
@@ -539,6 +544,13 @@ __global__ __launch_bounds__(512) void combine_bwd1_kernel(const AT* __restrict_
         }
       }
     }
+    // padding frames of this workgroup's range: no gradient (written, not read)
+    {
+      float z[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) z[i] = 0.f;
+      for (int t = max(t_lo, L) + tg; t < t_end; t += TG) store8(dZ + ((size_t)b * T + t) * C + c0, z);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       part[(tg * 3 + 0) * C + c0 + i] = dg[i];
@@ -551,7 +563,8 @@ __global__ __launch_bounds__(512) void combine_bwd1_kernel(const AT* __restrict_
   for (int c = tid; c < C; c += NT) {
     float a = 0.f, x1 = 0.f, x2 = 0.f;
     for (int k = 0; k < TG; ++k) { a += part[(k * 3 + 0) * C + c]; x1 += part[(k * 3 + 1) * C + c]; x2 += part[(k * 3 + 2) * C + c]; }
-    dgate[(size_t)b * C + c] = a;
+    if (gridDim.y > 1) atomic_add_f32(&dgate[(size_t)b * C + c], a);
+    else dgate[(size_t)b * C + c] = a;
     atomic_add_f32(&bsumsS[(size_t)(rep * 2 + 0) * C + c], x1);
     atomic_add_f32(&bsumsS[(size_t)(rep * 2 + 1) * C + c], x2);
   }
@@ -566,7 +579,7 @@ __global__ __launch_bounds__(512) void combine_bwd1_kernel(const AT* __restrict_
 template <typename AT>
 __global__ __launch_bounds__(512) void combine_bwd2_kernel(const AT* __restrict__ dZ, const AT* __restrict__ Y3, BnAct act3,
                                                            const float* __restrict__ gate, const float* __restrict__ hid,
-                                                           float* __restrict__ dgate_dpre2, float* __restrict__ dpre1,
+                                                           const float* dgate_in, float* dgate_dpre2, float* __restrict__ dpre1,
                                                            const float* __restrict__ W1, const float* __restrict__ W2,
                                                            int T, int C, int Hr, AT* __restrict__ dYbn,
                                                            float* __restrict__ bsums3) {
@@ -587,9 +600,11 @@ __global__ __launch_bounds__(512) void combine_bwd2_kernel(const AT* __restrict_
     bn_mean_rstd(act3, C, c, m3[c], r3[c]);
     const float g = gate[(size_t)b * C + c];
     gS[c] = g;
-    const float d2 = dgate_dpre2[(size_t)b * C + c] * g * (1.f - g);
+    // (dgate_in == dgate_dpre2: in place, one workgroup per utterance; with gridDim.y parts the two are different buffers
+    //  — every part reads dgate, part 0 writes the per-utterance results)
+    const float d2 = dgate_in[(size_t)b * C + c] * g * (1.f - g);
     p2[c] = d2;
-    dgate_dpre2[(size_t)b * C + c] = d2;
+    if (blockIdx.y == 0) dgate_dpre2[(size_t)b * C + c] = d2;
   }
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6, NW = NT >> 6;
@@ -599,11 +614,14 @@ __global__ __launch_bounds__(512) void combine_bwd2_kernel(const AT* __restrict_
     if (lane == 0) {
       s = (hid[(size_t)b * Hr + j] > 0.f) ? s : 0.f;
       p1[j] = s;
-      dpre1[(size_t)b * Hr + j] = s;
+      if (blockIdx.y == 0) dpre1[(size_t)b * Hr + j] = s;
     }
   }
   __syncthreads();
-  const float invT = 1.f / (float)(act3.rm.len ? max(act3.rm.len[b], 1) : T);   // the SE mean ran over the valid frames
+  const int L = act3.rm.len ? act3.rm.len[b] : T;
+  const int per = (T + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int t_lo = (int)blockIdx.y * per, t_end = min(T, t_lo + per), t_hi = min(L, t_end);
+  const float invT = 1.f / (float)max(L, 1);   // the SE mean ran over the valid frames
   for (int c = tid; c < C; c += NT) {
     const float s = tn_dot_batched(W1 + c, C, p1, 1, Hr);
     dmT[c] = s * invT;
@@ -620,12 +638,12 @@ __global__ __launch_bounds__(512) void combine_bwd2_kernel(const AT* __restrict_
 #pragma unroll
     for (int i = 0; i < 8; ++i) { g8[i] = gS[c0 + i]; dm8[i] = dmT[c0 + i]; m8[i] = m3[c0 + i]; r8[i] = r3[c0 + i]; }
     constexpr int U = 4;
-    for (int t0 = tg; t0 < T; t0 += TG * U) {
+    for (int t0 = t_lo + tg; t0 < t_hi; t0 += TG * U) {
       float d[U][8], y[U][8];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int t = t0 + u * TG;
-        if (t < T) {
+        if (t < t_hi) {
           const size_t o = ((size_t)b * T + t) * C + c0;
           load8(dZ + o, d[u]);
           load8(Y3 + o, y[u]);
@@ -634,7 +652,7 @@ __global__ __launch_bounds__(512) void combine_bwd2_kernel(const AT* __restrict_
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int t = t0 + u * TG;
-        if (t < T) {
+        if (t < t_hi) {
           const uint32_t row = (uint32_t)b * T + t;
           float m[8];
           act8_grad_mask(y[u], m, sc3 + c0, sh3 + c0, act3, row, C, c0);
@@ -648,6 +666,12 @@ __global__ __launch_bounds__(512) void combine_bwd2_kernel(const AT* __restrict_
           store8(dYbn + (size_t)row * C + c0, d[u]);
         }
       }
+    }
+    {
+      float z[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) z[i] = 0.f;
+      for (int t = max(t_lo, L) + tg; t < t_end; t += TG) store8(dYbn + ((size_t)b * T + t) * C + c0, z);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -819,14 +843,14 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(DwBwdArgs a) {
 //   d e   = alpha (dmu' x + dq x^2 - (dmu' mu + dq q))         -> dEN (grad wrt energies), sum -> d b_out
 //   d x   = alpha (dmu' + 2 x dq)  (direct path)               -> DXD (added to the attention path later)
 // ------------------------------------------------------------------------------------------
-template <typename AT>
+template <typename AT, int CVB = 64, int TG = 4>
 __global__ __launch_bounds__(256) void asp_bwd_de_kernel(const AT* __restrict__ E, BnAct actE, const AT* __restrict__ EN,
                                                          int T, int D, float eps, const float* __restrict__ pooled,
                                                          const float* __restrict__ qv, const float* __restrict__ smax,
                                                          const float* __restrict__ sinv, const float* __restrict__ dpooled,
                                                          AT* __restrict__ dEN, AT* __restrict__ DXD,
                                                          float* __restrict__ g_bout) {
-  constexpr int CVB = 64, TG = 4;
+  static_assert(CVB * TG == 256, "256 threads");
   __shared__ float red[TG][CVB * 8];
   __shared__ float scs[CVB * 8], shs[CVB * 8];
   const int tid = threadIdx.x, b = blockIdx.x;

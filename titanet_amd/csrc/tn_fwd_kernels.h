@@ -378,13 +378,17 @@ inline int launch_dw_fwd(const AT* X, const BnAct& act, const float* wdw, const 
 
 // ------------------------------------------------------------------------------------------
 // Squeeze-and-Excitation: m = mean_T act(Y3); h = relu(W1 m); g = sigmoid(W2 h)
-// (reference src/modules.py:173-189).  One workgroup per utterance.
+// (reference src/modules.py:173-189).  One workgroup per utterance — or, for small batches of long utterances (32 x 2000
+// frames would occupy 32 of the 256 CUs), gridDim.y = P workgroups per utterance that store their partial column sums in
+// `acc` ([B][P][C], plain stores: the result does not depend on the order the workgroups run in); a second launch with
+// mode 2 (one workgroup per utterance) adds them in order and turns the sums into mean / h / g.
+//   mode 0: everything in one workgroup;  1: partial sums of frames [p T/P, (p+1) T/P) -> acc[b][p];  2: acc[b][0..parts) -> m, h, g
 // ------------------------------------------------------------------------------------------
 template <typename AT>
 __global__ __launch_bounds__(512) void se_squeeze_fc_kernel(const AT* __restrict__ Y, BnAct act, int T, int C, int Hr,
                                                             const float* __restrict__ W1, const float* __restrict__ W2,
                                                             float* __restrict__ m_out, float* __restrict__ h_out,
-                                                            float* __restrict__ g_out) {
+                                                            float* __restrict__ g_out, float* __restrict__ acc, int mode, int parts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sc = reinterpret_cast<float*>(smem);
   float* sh = sc + C;
@@ -397,24 +401,28 @@ __global__ __launch_bounds__(512) void se_squeeze_fc_kernel(const AT* __restrict
     for (int c = tid; c < C; c += NT) bn_scale_shift(act, C, c, sc[c], sh[c]);
   __syncthreads();
   const int vc = tid % CV, tg = tid / CV;
-  if (tg < TG) {
+  // frames of this workgroup; padding frames (>= len[b]) contribute nothing and are not read
+  const int L = act.rm.len ? act.rm.len[b] : T;
+  const int per = (T + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int t_lo = (int)blockIdx.y * per, t_hi = min(L, t_lo + per);
+  if (tg < TG && mode != 2) {
     float s[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = 0.f;
     // 6 rows in flight per thread (one workgroup per utterance: with one load at a time this loop was an HBM round trip per
     // row, 116 us for the 157 MB of a TitaNet-L tensor)
     constexpr int U = 6;
-    for (int t0 = tg; t0 < T; t0 += TG * U) {
+    for (int t0 = t_lo + tg; t0 < t_hi; t0 += TG * U) {
       float v[U][8];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int t = t0 + u * TG;
-        if (t < T) load8(Y + ((size_t)b * T + t) * C + vc * 8, v[u]);
+        if (t < t_hi) load8(Y + ((size_t)b * T + t) * C + vc * 8, v[u]);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int t = t0 + u * TG;
-        if (t < T) {
+        if (t < t_hi) {
           const uint32_t row = (uint32_t)b * T + t;
           act8(v[u], sc + vc * 8, sh + vc * 8, act, row, C, vc * 8);
 #pragma unroll
@@ -426,10 +434,21 @@ __global__ __launch_bounds__(512) void se_squeeze_fc_kernel(const AT* __restrict
     for (int i = 0; i < 8; ++i) part[tg * C + vc * 8 + i] = s[i];
   }
   __syncthreads();
+  if (mode == 1) {
+    for (int c = tid; c < C; c += NT) {
+      float s = 0.f;
+      for (int k = 0; k < TG; ++k) s += part[k * C + c];
+      acc[((size_t)b * gridDim.y + blockIdx.y) * C + c] = s;
+    }
+    return;
+  }
   for (int c = tid; c < C; c += NT) {
     float s = 0.f;
-    for (int k = 0; k < TG; ++k) s += part[k * C + c];
-    s *= 1.f / (float)(act.rm.len ? max(act.rm.len[b], 1) : T);   // padded rows read as 0 (act8): mean over the valid frames
+    if (mode == 2)
+      for (int k = 0; k < parts; ++k) s += acc[((size_t)b * parts + k) * C + c];
+    else
+      for (int k = 0; k < TG; ++k) s += part[k * C + c];
+    s *= 1.f / (float)max(L, 1);   // mean over the valid frames
     mean[c] = s;
     m_out[(size_t)b * C + c] = s;
   }
@@ -502,13 +521,15 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(const AT* __restrict__
 //   pooled[b][c] = mean, pooled[b][D + c] = std; saves softmax max / 1/sum and q = sum alpha x^2.
 // Also accumulates the BatchNorm1d(2D) batch statistics (reference src/models.py:506).
 // ------------------------------------------------------------------------------------------
-template <typename AT>
+// CVB x TG = 256 threads: CVB vectors of 8 channels x TG time groups per workgroup; grid (B, ceil(D / (8 CVB))).  64 x 4 for
+// large batches, 16 x 16 for small batches of long utterances (4x the workgroups, 4x shorter time loops)
+template <typename AT, int CVB = 64, int TG = 4>
 __global__ __launch_bounds__(256) void asp_pool_fwd_kernel(const AT* __restrict__ E, BnAct actE,
                                                            const AT* __restrict__ EN, int T, int D, float eps,
                                                            float* __restrict__ pooled, float* __restrict__ smax,
                                                            float* __restrict__ sinv, float* __restrict__ qout,
                                                            float* __restrict__ stats) {
-  constexpr int CVB = 64, TG = 4;   // 64 channel-vectors (512 channels) x 4 time groups per block
+  static_assert(CVB * TG == 256, "256 threads");
   __shared__ float red[TG][4][CVB * 8];
   __shared__ float scs[CVB * 8], shs[CVB * 8];
   const int tid = threadIdx.x, b = blockIdx.x;

@@ -153,6 +153,11 @@ struct tn_plan {
   size_t prof_used = 0;
   // variable-length batches (tn_forward_masked): valid frames per utterance
   size_t lens = 0;                      // int32 [B] in the workspace
+  // small batches of long utterances: the per-utterance kernels of the mega-block tail (SE squeeze, combine backward) run as
+  // tail_parts workgroups per utterance; their partial sums meet in se_acc / dgate_acc ([block][B][hidden] floats, cleared
+  // with the backward zero region; se_acc: [B][parts][hidden] partial sums, reused block after block)
+  int tail_parts = 1;
+  size_t se_acc = 0, dgate_acc = 0;
   std::vector<int> lens_host;
   bool masked = false;                  // the last forward carried lengths
   int n_valid = 0;                      // sum of the lengths (rows that enter the [B*T]-row BatchNorm statistics)

@@ -52,3 +52,20 @@ series("unmasked ", lambda: tr.step(xf, y))
 series("full-len ", lambda: tr.step(xf, y, lengths=torch.full((B,), T, dtype=torch.int64)))
 series("masked   ", lambda: tr.step(xf, y, lengths=ln))
 series("mel+masked", lambda: tr.step(mel.batch(wav, lengths=nsamp, rates=rates, freq_masks=fm, time_masks=tm, into=m), y, lengths=ln))
+
+sync()
+for it in range(14):
+    t0 = time.perf_counter()
+    x = mel.batch(wav, lengths=nsamp, rates=rates, freq_masks=fm, time_masks=tm, into=m)
+    t1 = time.perf_counter()
+    tr.step(x, y, lengths=ln)
+    t2 = time.perf_counter()
+    print(f"host it {it}: mel.batch {1e3*(t1-t0):.2f} ms, tr.step {1e3*(t2-t1):.2f} ms")
+sync()
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for it in range(10):
+    x = mel.batch(wav, lengths=nsamp, rates=rates, freq_masks=fm, time_masks=tm, into=m)
+    tr.step(x, y, lengths=ln)
+sync(); pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(8)
