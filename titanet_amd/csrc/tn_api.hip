@@ -600,10 +600,11 @@ int gemm_store(const GemmShape& g, const typename Prod::Args& pa, const EpiStore
 
 // plain stored bf16 operand, big problem: the pipelined LDS-DMA GEMM (tn_pgemm.h); -1000 = not applicable
 template <typename AT>
-int gemm_plain_pipe(const tn_plan* p, const GemmShape& g, const void* X, int ldx, const BnAct& act, const EpiStoreArgs& ea, hipStream_t st) {
+int gemm_plain_pipe(const tn_plan* p, const GemmShape& g, const void* X, int ldx, const BnAct& act, const EpiStoreArgs& ea, hipStream_t st,
+                    bool zero_pad = true) {
   // variable-length batches: every plain operand of this path is STORED with zero padding rows (dw_fwd_slab, combine_fwd),
   // so the masks of the activation / epilogue have nothing left to do except for the statistics: y == bias on those rows
-  if (sizeof(AT) != 2 || p->generic || (p->masked && g.M != p->M)) return -1000;
+  if (sizeof(AT) != 2 || p->generic || (p->masked && (g.M != p->M || !zero_pad))) return -1000;
   if (act.mode != 0 || act.relu || act.drop_thr) return -1000;
   if (g.K % 32 || g.N % 64 || g.N > 3072 || ldx % 8 || ea.ldy % 2) return -1000;
   if (g.K < 256) return -1000;
@@ -713,6 +714,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
           // anyway) and the pointwise GEMM reads it as a plain operand
           uint8_t* q8 = (p->fp8 && sizeof(AT) == 2) ? (uint8_t*)(ws + p->q8) : nullptr;
           rc = -1000;
+          bool q_clean = false;          // the slab kernel stores zeros on padding rows (what the pipelined GEMMs' pad_rows needs)
           if (sizeof(AT) == 2 && p->wide_dw_bwd) {
             DwFwdSlabArgs fa;
             memset(&fa, 0, sizeof(fa));
@@ -720,6 +722,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
             fa.Q = (bf16_t*)(ws + bw.Q[j]); fa.Q8 = q8; fa.M = M; fa.T = T; fa.C = H;
             rc = launch_dw_fwd_slab(fa, c.kernel, st);
             if (rc > 0) return rc;
+            q_clean = rc == 0;
           }
           if (rc == -1000)
             rc = launch_dw_fwd<AT>((const AT*)cur, acur, params + sb.wdw, params + sb.bdw, (AT*)(ws + bw.Q[j]), M, T, H, c.kernel, st, q8);
@@ -729,10 +732,17 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
             GemmShape g8{M, H, H, ws + bw.w8[j]};
             EpiStoreArgs e8 = ea;
             e8.colscale = (const float*)(ws + bw.w8s[j]);
-            rc = launch_gemm_fp8<EpiStore>(g8, q8, e8, st);
+            // the pipelined LDS-DMA GEMM on the 64-k e4m3 MFMA (tn_pgemm.h, F8): 1.25 PFLOP/s at 76800 x 1024 x 1024 vs 0.96
+            rc = -1000;
+            if (!p->generic && H % 64 == 0 && H >= 256 && (!p->masked || q_clean)) {
+              PGemmNtArgs pa8{(const bf16_t*)q8, H};
+              PGemmEpiArgs pe8{(bf16_t*)e8.Y, e8.ldy, e8.bias, e8.stats, e8.colscale, p->masked ? (float)(p->M - p->n_valid) : 0.f};
+              rc = launch_pgemm_nt_f8(g8, pa8, pe8, st);
+            }
+            if (rc == -1000) rc = launch_gemm_fp8<EpiStore>(g8, q8, e8, st);
           } else {
             ProdPlain::Args pq{ws + bw.Q[j], H, identity_act()};
-            rc = gemm_plain_pipe<AT>(p, g, ws + bw.Q[j], H, identity_act(), ea, st);
+            rc = gemm_plain_pipe<AT>(p, g, ws + bw.Q[j], H, identity_act(), ea, st, q_clean);
             if (rc == -1000) rc = gemm_store<AT, ProdPlain>(g, pq, ea, 0, st);
           }
         } else {

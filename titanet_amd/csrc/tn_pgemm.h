@@ -82,10 +82,17 @@ struct PGemmEpiArgs {
 //   phase apart ("ping-pong", a barrier per 8 MFMAs): 0.76 - 0.79, with s_setprio around the MFMAs 0.75;  16-byte output
 //   stores (quad transpose of the packed pairs, 16 instead of 64 store instructions per wave and tile): 4 % slower —
 //   the store cost is the burst itself (every workgroup reaches its epilogue at the same time), not the instruction count.
-template <int DBG = 0>
+//
+// F8 = true: both operands are e4m3 BYTE matrices (pa.A [M][lda] bytes, g.W [N][K] bytes; TN_PREC_FP8 forward: the e4m3 copy
+// of the depthwise output and the per-row-scaled weights, ea.colscale undoes the scales).  Same ring, same 64-byte tile rows
+// (now 64 k per stage), same swizzle and the same two 16-byte fragment reads per operand row and stage — a lane's two pieces
+// (k bytes [16 h, 16 h + 16) and [32 + 16 h, 48 + 16 h) of the 64-k block, the same for both operands) are ONE 32-byte
+// operand of v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales): 8 MFMAs of 64 k per stage instead of 16 of 16 k, half the
+// DMA bytes and half the matrix-pipe time per unit of K.
+template <int DBG = 0, bool F8 = false>
 __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtArgs pa, PGemmEpiArgs ea, int tiles_n, int total_tiles) {
-  constexpr int BK = 32, NSTAGE = 4;
-  constexpr int ROWB = BK * 2;               // bytes of a tile row
+  constexpr int BK = F8 ? 64 : 32, NSTAGE = 4;
+  constexpr int ROWB = 64;                   // bytes of a tile row
   constexpr int CPR = ROWB / 16;             // 16-byte chunks per row
   constexpr int RPI = 64 / CPR;              // rows per DMA instruction (1 KiB)
   constexpr int NQ = 256 / (8 * RPI);        // DMA instructions per wave, operand and stage
@@ -99,7 +106,9 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
   const int wm = wave >> 2, wn = wave & 3;
   const int G = gridDim.x, v = pg_virtual_id(blockIdx.x, G);
   const int KT = g.K / BK;
-  const bf16_t* W = reinterpret_cast<const bf16_t*>(g.W);
+  constexpr int ESZ = F8 ? 1 : 2;            // operand bytes per element
+  const char* Wb = reinterpret_cast<const char*>(g.W);
+  const char* Ab = reinterpret_cast<const char*>(pa.A);
 
   // ---- DMA side: instruction q of this wave fills LDS rows (q*8 + wave) * RPI + lane / CPR of both tiles
   const int dsub = lane / CPR;
@@ -114,15 +123,15 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
       int rb = nt * 256 + (p & ~63) + 2 * (p & 31) + ((p >> 5) & 1);    // weight rows: 2 i + j at LDS row 32 j + i
       ra = ra < g.M ? ra : g.M - 1;            // rows outside the matrix: any valid row (their outputs are never stored)
       rb = rb < g.N ? rb : g.N - 1;
-      offA[q] = (unsigned)ra * (unsigned)pa.lda + chunk * 8;
-      offB[q] = (unsigned)rb * (unsigned)g.K + chunk * 8;
+      offA[q] = ((unsigned)ra * (unsigned)pa.lda) * ESZ + chunk * 16;       // bytes
+      offB[q] = ((unsigned)rb * (unsigned)g.K) * ESZ + chunk * 16;
     }
   };
   auto dma_a = [&](int q, int kt, int stage) {
-    tn_dma16(pa.A + (size_t)offA[q] + kt * BK, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + (q * 8 + wave) * 1024)));
+    tn_dma16(Ab + (size_t)offA[q] + kt * ROWB, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + (q * 8 + wave) * 1024)));
   };
   auto dma_b = [&](int q, int kt, int stage) {
-    tn_dma16(W + (size_t)offB[q] + kt * BK, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + TILE_B + (q * 8 + wave) * 1024)));
+    tn_dma16(Wb + (size_t)offB[q] + kt * ROWB, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + TILE_B + (q * 8 + wave) * 1024)));
   };
   // ---- MFMA side: fragment byte offsets inside a tile (row i of a 32-row block, k-step ks)
   const int fi = lane & 31, fh = lane >> 5;
@@ -191,6 +200,30 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
         for (int i = 0; i < 4; ++i) af[buf][i] = *reinterpret_cast<const bf16x8_t*>(ap + ((i >> 1) * 128 + (i & 1) * 32) * ROWB);
       };
       read_frags(0, 0);
+      if constexpr (F8) {
+        typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+        typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+        read_frags(1, 1);
+        auto join = [](const bf16x8_t& lo, const bf16x8_t& hi) {
+          const i32x4_t l = __builtin_bit_cast(i32x4_t, lo), h = __builtin_bit_cast(i32x4_t, hi);
+          i32x8_t f;
+          f[0] = l[0]; f[1] = l[1]; f[2] = l[2]; f[3] = l[3]; f[4] = h[0]; f[5] = h[1]; f[6] = h[2]; f[7] = h[3];
+          return f;
+        };
+        constexpr int SC1 = 0x7f7f7f7f;          // E8M0 127: block scale 1
+        const i32x8_t b0 = join(bf[0][0], bf[1][0]), b1 = join(bf[0][1], bf[1][1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (!(DBG & 2) && (i & 1) == 0) { dma_a(i >> 1, kt_req, istage); dma_b(i >> 1, kt_req, istage); }     // of the K step three ahead
+          const i32x8_t a8 = join(af[0][i], af[1][i]);
+          if (DBG & 1) {
+            asm volatile("" ::"v"(a8), "v"(b0), "v"(b1));
+          } else {
+            acc[i >> 1][i & 1][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b0, acc[i >> 1][i & 1][0], 0, 0, 0, SC1, 0, SC1);
+            acc[i >> 1][i & 1][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b1, acc[i >> 1][i & 1][1], 0, 0, 0, SC1, 0, SC1);
+          }
+        }
+      } else
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         if (ks == 0) read_frags(1, 1);
@@ -264,9 +297,9 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
   pg_wait<0>();
 }
 
-template <int DBG = 0>
+template <int DBG = 0, bool F8 = false>
 inline int launch_pgemm_nt_t(const GemmShape& g, const PGemmNtArgs& pa, const PGemmEpiArgs& ea, hipStream_t st, int max_wgs) {
-  if (g.K % 32 || g.K <= 0 || pa.lda % 8 || g.N % 64 || g.N > 3072 || ea.ldy % 2 || g.M <= 0) return TN_E_UNSUPPORTED;
+  if (g.K % (F8 ? 64 : 32) || g.K <= 0 || pa.lda % (F8 ? 16 : 8) || g.N % 64 || g.N > 3072 || ea.ldy % 2 || g.M <= 0) return TN_E_UNSUPPORTED;
   if ((long)g.M * pa.lda >= (1L << 32) || (long)g.N * g.K >= (1L << 32) || (long)g.M * ea.ldy * 2 >= (1L << 32)) return TN_E_UNSUPPORTED;
   const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256, total = tiles_m * tiles_n;
   // persistent workgroups with the same number of tiles each (1200 tiles: 240 x 5 beats 256 x 4.7, the last round of which
@@ -278,13 +311,17 @@ inline int launch_pgemm_nt_t(const GemmShape& g, const PGemmNtArgs& pa, const PG
     if (grid > max_wgs) grid = max_wgs & ~7;
   }
   const size_t smem = (size_t)131072 + (size_t)2 * g.N * sizeof(float);
-  auto kern = pgemm_nt_kernel<DBG>;
+  auto kern = pgemm_nt_kernel<DBG, F8>;
   TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g, pa, ea, tiles_n, total);
   return (int)hipGetLastError();
 }
 inline int launch_pgemm_nt(const GemmShape& g, const PGemmNtArgs& pa, const PGemmEpiArgs& ea, hipStream_t st, int max_wgs = 256) {
   return launch_pgemm_nt_t<0>(g, pa, ea, st, max_wgs);
+}
+// e4m3 x e4m3 (pa.A and g.W are byte matrices, pa.lda in bytes = elements)
+inline int launch_pgemm_nt_f8(const GemmShape& g, const PGemmNtArgs& pa, const PGemmEpiArgs& ea, hipStream_t st, int max_wgs = 256) {
+  return launch_pgemm_nt_t<0, true>(g, pa, ea, st, max_wgs);
 }
 
 // ==========================================================================================

@@ -1,0 +1,117 @@
+// Correctness + timing of the e4m3 variant of the pipelined NT GEMM (tn_pgemm.h, F8 = true) against gemm_fp8_nt_kernel.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics tools/pgemm_f8_harness.hip -o tools/pgemm_f8_harness
+//   tools/pgemm_f8_harness [M N K]
+#include "../include/titanet_amd.h"
+#include "../titanet_amd/csrc/tn_pgemm.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %d at %s\n", (int)e, #x); return 1; } } while (0)
+template <class F> float timeit(F f, int n = 20) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) f(i);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < n; ++i) f(i + 3);
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1e3f / n;
+}
+int main(int argc, char** argv) {
+  const int M = argc > 3 ? atoi(argv[1]) : 256 * 300, N = argc > 3 ? atoi(argv[2]) : 1024, K = argc > 3 ? atoi(argv[3]) : 1024;
+  const int NSET = 3;
+  printf("NT GEMM e4m3  M=%d N=%d K=%d  (%.1f GFLOP)\n", M, N, K, 2.0 * M * N * K / 1e9);
+  std::vector<uint8_t> ha((size_t)M * K), hw((size_t)N * K);
+  uint32_t s = 777u;
+  auto rnd8 = [&]() { s = s * 1664525u + 1013904223u; uint8_t b = (uint8_t)(s >> 24); if ((b & 0x7f) >= 0x50) b = (uint8_t)((b & 0x80) | ((b & 0x7f) - 0x30)); return b; };   // |x| < 8: no NaN codes
+  for (auto& v : ha) v = rnd8();
+  for (auto& v : hw) v = rnd8();
+  std::vector<uint8_t*> A(NSET); std::vector<bf16_t*> Y(NSET);
+  for (int i = 0; i < NSET; ++i) {
+    CK(hipMalloc(&A[i], (size_t)M * K)); CK(hipMalloc(&Y[i], (size_t)(M + 256) * N * 2)); CK(hipMemset(Y[i] + (size_t)M * N, 0x5a, (size_t)256 * N * 2));
+    CK(hipMemcpy(A[i], ha.data(), ha.size(), hipMemcpyHostToDevice));
+  }
+  uint8_t* W; bf16_t* Yref; float *bias, *cs, *stats, *stats_ref, *stats_tmp;
+  CK(hipMalloc(&W, (size_t)N * K)); CK(hipMemcpy(W, hw.data(), hw.size(), hipMemcpyHostToDevice));
+  CK(hipMalloc(&Yref, (size_t)M * N * 2));
+  CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&cs, N * 4));
+  CK(hipMalloc(&stats, TN_NREP * 2 * N * 4)); CK(hipMalloc(&stats_ref, TN_NREP * 2 * N * 4)); CK(hipMalloc(&stats_tmp, TN_NREP * 2 * N * 4));
+  { std::vector<float> hb(N), hc(N); for (int i = 0; i < N; ++i) { hb[i] = 0.01f * (i % 17) - 0.05f; hc[i] = 0.001f * (1 + i % 7); }
+    CK(hipMemcpy(bias, hb.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(cs, hc.data(), N * 4, hipMemcpyHostToDevice)); }
+  CK(hipMemset(stats, 0, TN_NREP * 2 * N * 4)); CK(hipMemset(stats_ref, 0, TN_NREP * 2 * N * 4));
+  GemmShape g{M, N, K, W};
+  {
+    EpiStoreArgs ea{Yref, N, bias, stats_ref, RowMask{nullptr, 0}, cs};
+    int rc = launch_gemm_fp8<EpiStore>(g, A[0], ea, 0);
+    if (rc) { printf("reference launch failed %d\n", rc); return 1; }
+  }
+  {
+    PGemmNtArgs pa{(const bf16_t*)A[0], K};
+    PGemmEpiArgs ea{Y[0], N, bias, stats, cs, 0.f};
+    int rc = launch_pgemm_nt_f8(g, pa, ea, 0, 256);
+    if (rc) { printf("pgemm launch failed %d\n", rc); return 1; }
+  }
+  CK(hipDeviceSynchronize());
+  for (int rep = 0; rep < 2; ++rep) {
+    if (rep == 1) {
+      CK(hipMemset(stats, 0, TN_NREP * 2 * N * 4));
+      PGemmNtArgs pa{(const bf16_t*)A[0], K};
+      PGemmEpiArgs ea{Y[0], N, bias, stats, cs, 0.f};
+      for (int i = 0; i < 6; ++i) { pa.A = (const bf16_t*)A[i % NSET]; ea.Y = Y[(i + 1) % NSET]; ea.stats = i == 5 ? stats : stats_tmp; if (i == 5) ea.Y = Y[0]; launch_pgemm_nt_f8(g, pa, ea, 0, 256); }
+      CK(hipDeviceSynchronize());
+      printf("second check (back-to-back launches):\n");
+    }
+    std::vector<unsigned short> y((size_t)M * N), yr((size_t)M * N);
+    CK(hipMemcpy(y.data(), Y[0], y.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(yr.data(), Yref, yr.size() * 2, hipMemcpyDeviceToHost));
+    size_t bad = 0, first = (size_t)-1; double maxd = 0, maxr = 0;
+    for (size_t i = 0; i < y.size(); ++i) {
+      uint32_t a = (uint32_t)y[i] << 16, b = (uint32_t)yr[i] << 16; float fa, fb; memcpy(&fa, &a, 4); memcpy(&fb, &b, 4);
+      const double d = fabs((double)fa - fb);
+      if (d > maxd) maxd = d;
+      if (fabs(fb) > maxr) maxr = fabs(fb);
+      if (y[i] != yr[i]) { if (first == (size_t)-1) first = i; ++bad; }
+    }
+    printf("output: %zu of %zu elements differ bitwise, max abs diff %.4g of max |ref| %.4g (first at row %zu col %zu)\n", bad, y.size(), maxd, maxr,
+           first == (size_t)-1 ? 0 : first / N, first == (size_t)-1 ? 0 : first % N);
+    {
+      std::vector<unsigned short> can((size_t)256 * N);
+      CK(hipMemcpy(can.data(), Y[0] + (size_t)M * N, can.size() * 2, hipMemcpyDeviceToHost));
+      size_t hit = 0;
+      for (auto c : can) hit += c != 0x5a5a;
+      printf("rows beyond M: %zu elements overwritten\n", hit);
+    }
+    std::vector<float> st(TN_NREP * 2 * N), sr(TN_NREP * 2 * N);
+    CK(hipMemcpy(st.data(), stats, st.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(sr.data(), stats_ref, sr.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0;
+    for (int which = 0; which < 2; ++which)
+      for (int n = 0; n < N; ++n) {
+        double a = 0, b = 0;
+        for (int r = 0; r < TN_NREP; ++r) { a += st[(r * 2 + which) * N + n]; b += sr[(r * 2 + which) * N + n]; }
+        worst = fmax(worst, fabs(a - b) / (fabs(b) + 1.0));
+      }
+    printf("statistics: worst relative difference of the column sums %.3g\n", worst);
+  }
+  const double flop = 2.0 * M * N * K;
+  {
+    EpiStoreArgs ea{Yref, N, bias, stats_ref, RowMask{nullptr, 0}, cs};
+    float us = timeit([&](int i) { ea.Y = Y[i % NSET]; launch_gemm_fp8<EpiStore>(g, A[i % NSET], ea, 0); });
+    printf("gemm_fp8_nt_kernel (generic)   : %8.2f us  %.3f PFLOP/s\n", us, flop / us / 1e9);
+  }
+  for (int wgs : {256, 240}) {
+    PGemmNtArgs pa{(const bf16_t*)A[0], K};
+    PGemmEpiArgs ea{Y[0], N, bias, stats, cs, 0.f};
+    float us = timeit([&](int i) { pa.A = (const bf16_t*)A[i % NSET]; ea.Y = Y[i % NSET]; launch_pgemm_nt_f8(g, pa, ea, 0, wgs); });
+    printf("pgemm_nt_kernel e4m3 (%3d wgs) : %8.2f us  %.3f PFLOP/s\n", wgs, us, flop / us / 1e9);
+  }
+  {
+    PGemmNtArgs pa{(const bf16_t*)A[0], K};
+    PGemmEpiArgs ea{Y[0], N, bias, stats, cs, 0.f};
+    float us;
+#define DBGRUN(D, what) us = timeit([&](int i) { pa.A = (const bf16_t*)A[i % NSET]; ea.Y = Y[i % NSET]; launch_pgemm_nt_t<D, true>(g, pa, ea, 0, 256); }); printf("  dbg %-40s: %8.2f us\n", what, us);
+    DBGRUN(1, "no MFMA")
+    DBGRUN(2, "no DMA")
+    DBGRUN(8, "no stores")
+  }
+  return 0;
+}
