@@ -795,7 +795,8 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       }
       if (rc2 == -1000) {
         const int rpb = 64;
-        hipLaunchKernelGGL(combine_fwd_kernel<AT>, dim3((M + rpb - 1) / rpb), dim3(256), (size_t)4 * H * sizeof(float), st,
+        auto kcomb = acur.rm.len ? combine_fwd_kernel<AT, true> : combine_fwd_kernel<AT, false>;
+        hipLaunchKernelGGL(kcomb, dim3((M + rpb - 1) / rpb), dim3(256), (size_t)4 * H * sizeof(float), st,
                            (const AT*)(ws + bw.S), acts, (const AT*)cur, acur, (const float*)(ws + bw.g), (AT*)(ws + bw.OUT), M,
                            T, H, rpb, thr, key, ik, (const uint32_t*)(ws + p->step_state) + 2);
       }

@@ -190,7 +190,8 @@ struct DwFwdSlabArgs {
   uint8_t* Q8;         // [M][C] e4m3 copy for the fp8 pointwise GEMM (TN_PREC_FP8; needs 4 channels per lane) or null
   int M, T, C, ntiles;
 };
-template <int KD, int FL, int CH>
+// MK: variable-length batch (a.act.rm.len), a compile-time flag: the fixed-length instantiation carries none of it
+template <int KD, int FL, int CH, bool MK = false>
 __global__ __launch_bounds__(512, 2) void dw_fwd_slab_kernel(DwFwdSlabArgs a) {
   constexpr int PADR = (KD - 1) / 2, ROWS = 64 + KD - 1, WPS = 4 / CH, RS = 8 * WPS;
   constexpr int TILE_B = ROWS * 512;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void dw_fwd_slab_kernel(DwFwdSlabArgs a) {
   const int slab = blockIdx.x % nslab, first = blockIdx.x / nslab, stride = gridDim.x / nslab;
   const int cb = slab * 256;
   const uint32_t dkey = tn_act_key(a.act), dthr = a.act.drop_thr;
-  const int* __restrict__ len = a.act.rm.len;                    // valid frames per utterance or null (uniform)
+  const int* __restrict__ len = MK ? a.act.rm.len : nullptr;     // valid frames per utterance (uniform)
   if (tid < 256) {
     float s = 1.f, h = 0.f;
     if (FL & 1) bn_scale_shift(a.act, a.C, cb + tid, s, h);
@@ -325,7 +326,8 @@ __global__ __launch_bounds__(512, 2) void dw_fwd_slab_kernel(DwFwdSlabArgs a) {
 template <int KD, int FL>
 inline int launch_dw_fwd_slab_t(DwFwdSlabArgs a, int grid, hipStream_t st) {
   const size_t smem = (size_t)2 * (64 + KD - 1) * 512 + (size_t)(3 + KD) * 256 * sizeof(float);
-  auto kern = dw_fwd_slab_kernel<KD, FL, 4>;       // 4 channels per lane (2 measured 140 vs 103 us with dropout: one hash per 8 channels)
+  // 4 channels per lane (2 measured 140 vs 103 us with dropout: one hash per 8 channels)
+  auto kern = a.act.rm.len ? dw_fwd_slab_kernel<KD, FL, 4, true> : dw_fwd_slab_kernel<KD, FL, 4, false>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -4;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a);
   return (int)hipGetLastError();
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(512) void se_squeeze_fc_kernel(const AT* __restrict
 // ------------------------------------------------------------------------------------------
 // Mega-block tail: OUT = dropout(relu(BN(S) + g * act3(Y3)))   (reference src/models.py:467-472)
 // ------------------------------------------------------------------------------------------
-template <typename AT>
+template <typename AT, bool MK = false>
 __global__ __launch_bounds__(256) void combine_fwd_kernel(const AT* __restrict__ S, BnAct actS,
                                                           const AT* __restrict__ Y3, BnAct act3,
                                                           const float* __restrict__ gate, AT* __restrict__ OUT, int M,
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(const AT* __restrict__
     load8(Y3 + (size_t)row * C + c0, y);
     load8(gate + (size_t)b * C + c0, g);
     act8(y, sc3 + c0, sh3 + c0, act3, (uint32_t)row, C, c0);
-    const bool pad = act3.rm.len && !tn_row_valid(act3.rm, (uint32_t)row);     // padding rows are stored as zeros: the block
+    const bool pad = MK && !tn_row_valid(act3.rm, (uint32_t)row);              // padding rows are stored as zeros: the block
 #pragma unroll                                                                 // output is a plain operand for its consumers
     for (int q = 0; q < 8; ++q) o[q] = pad ? 0.f : fmaxf(s[q] * scS[c0 + q] + shS[c0 + q] + g[q] * y[q], 0.f);
     if (drop_thr) {

@@ -611,8 +611,8 @@ inline int launch_combine_bwd2_v2(const CombineBwd2V2Args& a, int B, hipStream_t
 // wait until at most N younger vector-memory operations are outstanding, naming the registers of the asm loads this retires
 // (no consumer is scheduled above the wait).  ONE statement with a compile-time count: a switch over run-time counts made
 // hipcc merge the per-case "+v" values with v_mov copies placed BEFORE the wait — reads of registers whose loads were still
-// in flight (non-finite gradients now and then at large batches).  The callers therefore issue the same number of DMA
-// instructions on every wave and every tile (dma_tile<PADDED>).
+// in flight (non-finite gradients now and then at large batches).  The caller therefore waits for the SMALLEST number of DMA
+// instructions a wave issues behind the loads, on every tile (the last tile of a workgroup issues a dummy set).
 template <int N, int RS>
 __device__ __forceinline__ void tn_wait_add(uint32_t (&r)[RS]) {
   static_assert(RS == 4 || RS == 8 || RS == 16, "register count of the addend rows");
@@ -638,7 +638,8 @@ struct DwBwdSlabArgs {
 };
 // CH = channels per lane: 4 (one wave per strip of 8 output rows) or 2 (two waves per strip of 16 rows: half the window /
 // weight / accumulator registers per lane, which is what K = 11 needs to stay out of scratch)
-template <int KD, int FL, int CH>
+// MK: variable-length batch (a.actX.rm.len); a compile-time flag so that the fixed-length instantiation carries none of it
+template <int KD, int FL, int CH, bool MK = false>
 __global__ __launch_bounds__(512, 2) void dw_bwd_slab_kernel(DwBwdSlabArgs a) {
   constexpr int PADR = (KD - 1) / 2, ROWS = 64 + KD - 1, NT = 512;
   constexpr int TILE_B = ROWS * 512;                        // bytes of one stream's tile
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(512, 2) void dw_bwd_slab_kernel(DwBwdSlabArgs a) {
   const int cb = slab * V2_C;                                  // first channel of the slab
   const float mscale = (FL & 4) ? a.actX.inv_keep : 1.f;
   const uint32_t dkey = tn_act_key(a.actX), dthr = a.actX.drop_thr;
-  const int* __restrict__ len = a.actX.rm.len;                 // valid frames per utterance or null (uniform)
+  const int* __restrict__ len = MK ? a.actX.rm.len : nullptr;  // valid frames per utterance (uniform)
   if (tid < V2_C) {
     float s = 1.f, h = 0.f, mean = 0.f, rstd = 1.f;
     if (FL & 1) { bn_scale_shift(a.actX, a.C, cb + tid, s, h); bn_mean_rstd(a.actX, a.C, cb + tid, mean, rstd); }
@@ -670,15 +671,14 @@ __global__ __launch_bounds__(512, 2) void dw_bwd_slab_kernel(DwBwdSlabArgs a) {
   // every compiler-visible load is complete before the first DMA: the waits below are plain vmcnt(0)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // this wave's rows of a tile: 2 rows (1 KB) per instruction, rows 2 * (wave + 8 i)
-  // (with the skip-path addend every wave issues NPIECE pieces — a wave with one piece less repeats its first one — so that
-  //  the count in the wait for the addend rows is a compile-time constant, see tn_wait_add)
-  constexpr int NPIECE = (ROWS / 2 + 7) / 8;
+  // (a wave issues NPIECE or NPIECE - 1 pieces; the wait for the addend rows counts NPIECE - 1 of them, see tn_wait_add)
+  constexpr int NPIECE = (ROWS / 2 + 7) / 8, MINPIECE = (ROWS / 2) / 8;
+  static_assert(MINPIECE == NPIECE - 1 || MINPIECE == NPIECE, "pieces per wave");
   auto dma_tile = [&](int tile, int buf) {
     const int raw0 = tile * 64 - PADR;
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
-      int r = 2 * (wave + 8 * i);
-      if (HAS_ADD && r >= ROWS) r = 2 * wave;
+      const int r = 2 * (wave + 8 * i);
       if (r < ROWS) {
         int gr = raw0 + r + (lane >> 5);
         gr = gr < 0 ? 0 : (gr >= a.M ? a.M - 1 : gr);          // rows outside the tensor: any valid row (never used)
@@ -732,7 +732,9 @@ __global__ __launch_bounds__(512, 2) void dw_bwd_slab_kernel(DwBwdSlabArgs a) {
     else if (HAS_ADD) dma_tile(tile, buf ^ 1);                // last tile: the same count of DMA instructions (into the free buffer)
     float addv[HAS_ADD ? RS : 1][CH];
     if constexpr (HAS_ADD) {
-      tn_wait_add<2 * NPIECE, NADD>(addr_);                   // 2 DMA instructions per piece were issued after the addend loads
+      // at least 2 * MINPIECE DMA instructions were issued after the addend loads (a wave with one piece more also waits
+      // for its oldest piece: issued right behind the addend rows, it lands with them)
+      tn_wait_add<2 * MINPIECE, NADD>(addr_);
 #pragma unroll
       for (int o = 0; o < RS; ++o)
 #pragma unroll
@@ -887,7 +889,7 @@ inline int launch_dw_bwd_slab_t(DwBwdSlabArgs a, int grid, hipStream_t st) {
   constexpr int ROWS = 64 + KD - 1;
   const size_t tiles = (size_t)4 * ROWS * 512, red = (size_t)8 * (KD + 3) * V2_C * sizeof(float);
   const size_t smem = (tiles > red ? tiles : red) + (size_t)2 * V2_C * sizeof(float);
-  auto kern = dw_bwd_slab_kernel<KD, FL, (KD >= 7 ? 2 : 4)>;
+  auto kern = a.actX.rm.len ? dw_bwd_slab_kernel<KD, FL, (KD >= 7 ? 2 : 4), true> : dw_bwd_slab_kernel<KD, FL, (KD >= 7 ? 2 : 4), false>;
   TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a);
   return (int)hipGetLastError();

@@ -10,6 +10,9 @@ m = TitaNet.get_titanet(n_mega_blocks=nb, model_size=size, loss_function=loss, d
 tr = Trainer(m)
 x = torch.randn(256, 80, 300, device="cuda") * 0.11 - 0.1
 y = torch.randint(0, 251, (256,), device="cuda")
+if os.environ.get('POISON'):
+    x[:] = float('nan')
 for _ in range(6):
-    tr.step(x, y)
+    out = tr.step(x, y)
 torch.cuda.synchronize()
+print('loss', float(out[2]), 'params finite', bool(torch.isfinite(m.flat_parameters()).all()))
