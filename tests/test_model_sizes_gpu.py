@@ -212,3 +212,24 @@ def test_wide_model_gradients_at_scale_agree_with_generic_path(masked):
         cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
         print(k, "cosine fast vs generic", cos)
         assert cos > 0.98, (k, cos)
+
+
+@pytest.mark.parametrize("size,nb,precision", [("m", 10, "bf16"), ("l", 5, "bf16"), ("l", 5, "fp8")])
+def test_bench_shapes_of_the_wide_models_train_with_finite_parameters(size, nb, precision):
+    """BASELINE configs[2] / [4] at the shape bench.py times (batch 256, 80 x 300): three optimizer steps leave every parameter
+    finite and the loss moves down.  (The round-2 race in dw_bwd_slab poisoned the prolog gradient at exactly this size; the
+    step then ran ~5 % FASTER on the non-finite weights — constant operands, higher matrix-pipe clocks — so a throughput
+    number alone does not show it.)"""
+    from titanet_amd import LOSSES, TitaNet
+    from titanet_amd.trainer import Trainer
+    torch.manual_seed(0)
+    m = TitaNet.get_titanet(n_mega_blocks=nb, model_size=size, loss_function=LOSSES["ce"](192, 251, device="cuda"), dropout=0.1,
+                            device="cuda", precision=precision).train()
+    tr = Trainer(m)
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(256, 80, 300, generator=g) * 0.11 - 0.10).cuda()
+    y = torch.randint(0, 251, (256,), generator=g).cuda()
+    losses = [float(tr.step(x, y)[2]) for _ in range(4)]
+    assert all(np.isfinite(v) for v in losses), losses
+    assert torch.isfinite(m.flat_gradients()).all() and torch.isfinite(m.flat_parameters()).all()
+    assert losses[-1] < losses[0], losses
