@@ -115,16 +115,18 @@ def test_wide_kernels_agree_with_generic_path(size):
         assert e1 < max(0.35, 1.5 * e0), (k, e1, e0)
 
 
-@pytest.mark.parametrize("size", ["m", "l"])
+@pytest.mark.parametrize("size", ["m", "l", "s"])
 def test_wide_kernels_with_padding_mask_agree_with_generic_path(size):
     """Variable-length batches on the wide models' fast kernels (BASELINE configs[3] is TitaNet-M on ragged batches): padding
     rows read as zeros and are STORED as zeros by dw_fwd_slab / combine_fwd, the pipelined GEMM takes their y == bias out of
     the BatchNorm statistics again (PGemmEpiArgs.pad_rows), dS is zero there (bn_bwd_apply), dw_bwd_slab masks both its
     operand and its output.  Against the generic masked templates (TN_GENERIC=1) and the float64 oracle with the same
-    lengths and dropout masks; lengths chosen so that strips are fully valid, fully padding and cut by the length."""
+    lengths and dropout masks; lengths chosen so that strips are fully valid, fully padding and cut by the length.
+    size "s": the specialised hidden-256 kernels (sub_fwd_v5 / v4 with the tile mask, se_squeeze_v2, combine_fwd_v2, the
+    statistics corrected by stats_pad_fixup_kernel behind each GEMM)."""
     import os
     from tests.util import mask_fn_for
-    case = _case(size, 2 if size == "m" else 1, 5, 300, 37)
+    case = _case(size, 1 if size == "l" else 2, 5, 300, 37)
     lengths = torch.tensor([300, 41, 163, 2, 299])
     x, y = case_inputs(case, torch.float32)
     for b, n in enumerate(lengths.tolist()):

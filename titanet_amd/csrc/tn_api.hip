@@ -630,9 +630,16 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   const float pd = c.dropout;
   auto statp = [&](const BnRef& bn) -> float* { return training ? (float*)(ws + p->stats[bn.id]) : nullptr; };
   // variable-length batches run the generic kernel templates (the mask lives in their activation-on-load and epilogues)
-  const int use_v2 = p->masked ? 0 : p->use_v2;
+  // variable-length batches: the specialised forward kernels take the padding mask when an utterance spans at least one row
+  // tile (T >= 64); padding rows are stored as zeros, and the BatchNorm statistics of a GEMM fed with all-zero rows (y == bias
+  // there) are corrected right behind it
+  const int use_v2 = (p->masked && T < 64) ? 0 : p->use_v2;
   const RowMask rm = plan_row_mask(p);
   if (p->masked && c.simple_pool) return TN_E_UNSUPPORTED;
+  auto pad_fixup = [&](float* stats, const float* bias, int C) {
+    if (p->masked && training && stats && p->M > p->n_valid)
+      hipLaunchKernelGGL(stats_pad_fixup_kernel<0>, dim3(1), dim3(256), 0, st, stats, bias, (float)(p->M - p->n_valid), C, 1);
+  };
 
   TN_CHECK_HIP(hipMemsetAsync(ws + p->zero_begin, 0, p->zero_bytes, st));
   if (p->n_cast > 0) {
@@ -681,6 +688,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
                         (bf16_t*)(ws + bw.S), statp(mb.bnskip), M, T, 0,
                         bw.wskip.sw ? (const uint4*)(ws + bw.wskip.sw) : nullptr, nullptr};
         rc = launch_sub_fwd_v4<1, false>(va, 256, st);
+        if (rc == 0) pad_fixup(statp(mb.bnskip), params + mb.bskip, H);
       }
       if (rc == -1000) {
         GemmShape g{M, H, H, wsel<AT>(p, mb.wskip, bw.wskip)};
@@ -708,6 +716,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
                           bw.wpw[j].sw ? (const uint4*)(ws + bw.wpw[j].sw) : nullptr,
                           (p->save_q && training) ? (bf16_t*)(ws + bw.Q[j]) : nullptr};
           rc = launch_sub_fwd_v5<3, true>(va, 256, st);
+          if (rc == 0) pad_fixup(statp(sb.bn), params + sb.bpw, H);
           if (rc == -1000) rc = gemm_store<AT, ProdDw>(g, pa, ea, c.kernel, st);
         } else if (p->split_dw && p->save_q) {
           // wide models: the depthwise output is produced once by a streaming kernel (it is kept for the weight gradients
@@ -762,7 +771,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
         SeSqueezeV2Args sa;
         memset(&sa, 0, sizeof(sa));
         sa.Y = (const bf16_t*)cur; sa.act = acur; sa.W1 = params + mb.se_w1; sa.W2 = params + mb.se_w2;
-        sa.m_out = (float*)(ws + bw.m); sa.h_out = (float*)(ws + bw.h); sa.g_out = (float*)(ws + bw.g); sa.T = T;
+        sa.m_out = (float*)(ws + bw.m); sa.h_out = (float*)(ws + bw.h); sa.g_out = (float*)(ws + bw.g); sa.T = T; sa.len = rm.len;
         rc1 = launch_se_squeeze_v2(sa, B, st);
         if (rc1 > 0) return rc1;
       }
@@ -787,7 +796,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
         CombineFwdV2Args ca;
         memset(&ca, 0, sizeof(ca));
         ca.S = (const bf16_t*)(ws + bw.S); ca.actS = acts; ca.Y3 = (const bf16_t*)cur; ca.act3 = acur;
-        ca.gate = (const float*)(ws + bw.g); ca.OUT = (bf16_t*)(ws + bw.OUT); ca.T = T; ca.parts = 4;
+        ca.gate = (const float*)(ws + bw.g); ca.OUT = (bf16_t*)(ws + bw.OUT); ca.T = T; ca.parts = 4; ca.len = rm.len;
         ca.drop_thr = thr; ca.drop_key = key; ca.inv_keep = ik;
         ca.key_add = (const uint32_t*)(ws + p->step_state) + 2;
         rc2 = launch_combine_fwd_v2(ca, B, st);
@@ -815,6 +824,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       wa.Y = (bf16_t*)(ws + p->E); wa.stats = statp(m->epi_bn); wa.M = M; wa.N = D;
       int rc = launch_wide_out_v2<256, 0>(wa, 256, st);
       if (rc) return rc;
+      pad_fixup(statp(m->epi_bn), params + m->epi_b, D);
     } else {
       GemmShape g{M, D, H, wsel<AT>(p, m->epi_w, p->wepi)};
       ProdPlain::Args pa{xin, H, actx};

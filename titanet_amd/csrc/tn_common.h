@@ -314,6 +314,36 @@ __device__ __forceinline__ void tn_dma16(const void* gptr, unsigned lds_addr) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gptr), "s"(lds_addr) : "memory");
 }
+// ------------------------------------------------------------------------------------------
+// Padding mask of a tile of <= T consecutive rows (variable-length batches): the tile touches at most two utterances, so
+// three wave-uniform numbers decide every row:  valid(gr) = gr < e0 ? gr < lim0 : gr < lim1
+//   e0 = first row of the second utterance, lim0 / lim1 = first padding row of the first / second one.
+// ------------------------------------------------------------------------------------------
+struct TileMask { int e0, lim0, lim1; };
+__device__ __forceinline__ TileMask tn_tile_mask(const int* len, int T, int M, int row0) {
+  const int r0 = row0 < 0 ? 0 : row0;
+  const int b0 = r0 / T, nb = M / T;
+  TileMask m;
+  m.e0 = (b0 + 1) * T;
+  m.lim0 = b0 * T + tn_sload_i32(len, b0 < nb ? b0 : nb - 1);
+  m.lim1 = m.e0 + tn_sload_i32(len, b0 + 1 < nb ? b0 + 1 : nb - 1);
+  return m;
+}
+__device__ __forceinline__ bool tn_tile_valid(const TileMask& m, int gr) { return gr < m.e0 ? gr < m.lim0 : gr < m.lim1; }
+
+// Σy, Σy² of a BatchNorm input take the padding rows of a variable-length batch out again: the fast kernels compute those
+// rows from all-zero operands, so y == bias there exactly (rounded to bf16 where the statistics are taken from the stored
+// values), `pad` rows of them.  One workgroup; replica 0 carries the correction.
+template <int DUMMY = 0>
+__global__ void stats_pad_fixup_kernel(float* __restrict__ stats, const float* __restrict__ bias, float pad, int C, int round_bf16) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float b = bias ? bias[c] : 0.f;
+    if (round_bf16) b = __uint_as_float((uint32_t)f2bf(b) << 16);
+    atomicAdd(&stats[c], -pad * b);
+    atomicAdd(&stats[C + c], -pad * b * b);
+  }
+}
+
 template <int FL, int CH>
 __device__ __forceinline__ void act_c(float (&v)[CH], const float (&sc)[CH], const float (&sh)[CH], uint32_t key, uint32_t thr, uint32_t row, int C, int c) {
   if (FL & 1) {

@@ -89,8 +89,11 @@ __device__ __forceinline__ void act8_t(float v[8], const float sc[8], const floa
 // sub_fwd_v4: persistent MFMA kernel (W resident in registers) with the activation flags as template parameters, workgroup-uniform fast paths for
 // interior tiles (no row-range tests) and single-utterance tiles (no tap-boundary tests: 79 % of the tiles at
 // T = 300), and accumulators that start from the bias.
-template <int KD, bool DW, int FL>
+// MK (variable-length batch, a.act.rm.len): padding rows read as zeros.  Only for the activation-on-load variants of the skip
+// conv (block 0 reads the raw prolog output); stored block outputs already hold zeros there.
+template <int KD, bool DW, int FL, bool MK = false>
 __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v4_kernel(SubFwdV2Args a) {
+  static_assert(!(MK && DW), "the masked variant exists for the skip conv only");
   constexpr int PADR = DW ? (KD - 1) / 2 : 0;
   constexpr int OUTR = DW ? V2_R - (KD - 1) : V2_R;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -174,7 +177,21 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v4_kernel(SubFwdV2Args a) {
     // exist: everything but the first / last tile) skip the per-row range tests.
     const bool interior = raw0 >= 0 && raw0 + V2_R <= a.M;                  // workgroup-uniform
     const bool one_utt = interior && (raw0 % a.T) + V2_R <= a.T;           // ... and inside ONE utterance
-    if (interior) {
+    if (MK) {
+      const TileMask tm = tn_tile_mask(a.act.rm.len, a.T, a.M, raw0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = rq + 16 * q, gr = raw0 + r;
+        float v[8];
+        unpack8(pf[q], v);
+        if (gr >= 0 && gr < a.M && tn_tile_valid(tm, gr)) act8_t<FL>(v, sc, sh, dkey, dthr, (uint32_t)gr, c0);
+        else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        }
+        store8(As + r * V2_AP + c0, v);
+      }
+    } else if (interior) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int r = rq + 16 * q;
@@ -311,6 +328,9 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v4_kernel(SubFwdV2Args a) {
 template <int KD, bool DW, int FL>
 inline int launch_sub_fwd_v4_t(SubFwdV2Args a, int grid, size_t smem, hipStream_t st) {
   auto kern = sub_fwd_v4_kernel<KD, DW, FL>;
+  if constexpr (!DW && FL != 0) {
+    if (a.act.rm.len) kern = sub_fwd_v4_kernel<KD, DW, FL, true>;
+  } else if (a.act.rm.len && (DW || a.act.mode != 0)) return -1000;
   TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
   return (int)hipGetLastError();
@@ -343,6 +363,7 @@ struct CombineFwdV2Args {
   const float* gate;     // [B][256]
   bf16_t* OUT;
   int T, parts;
+  const int* len;        // valid frames per utterance or null: padding rows are written as zeros
   uint32_t drop_thr, drop_key;
   float inv_keep;
   const uint32_t* key_add;   // see BnAct::key_add
@@ -374,7 +395,13 @@ __global__ __launch_bounds__(256) void combine_fwd_v2_kernel(CombineFwdV2Args a)
     if (DROP) { scS[i] *= a.inv_keep; shS[i] *= a.inv_keep; g[i] *= a.inv_keep; }   // relu(k x) = k relu(x), k > 0
   }
   const int per = (a.T + a.parts - 1) / a.parts;
-  const int t0 = part * per, t1 = min(a.T, t0 + per);
+  const int t0 = part * per, t_end = min(a.T, t0 + per);
+  const int L = a.len ? a.len[b] : a.T;
+  const int t1 = min(L, t_end);
+  {
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (int t = max(t0, L) + rq; t < t_end; t += 8) *reinterpret_cast<uint4*>(a.OUT + ((size_t)b * a.T + t) * V2_C + c0) = z;
+  }
   const uint32_t dkey3 = tn_act_key(a.act3), dthr3 = a.act3.drop_thr;
   const uint32_t okey = a.key_add ? a.drop_key + *a.key_add : a.drop_key;
   constexpr int U = 4;
@@ -427,6 +454,7 @@ struct SeSqueezeV2Args {
   const float* W2;     // [256][16]
   float* m_out; float* h_out; float* g_out;
   int T;
+  const int* len;      // valid frames per utterance or null: the mean runs over them
 };
 template <int FL>
 __global__ __launch_bounds__(512) void se_squeeze_v2_kernel(SeSqueezeV2Args a) {
@@ -457,17 +485,18 @@ __global__ __launch_bounds__(512) void se_squeeze_v2_kernel(SeSqueezeV2Args a) {
   for (int i = 0; i < 8; ++i) { sc[i] = cst[c0 + i]; sh[i] = cst[V2_C + c0 + i]; acc[i] = 0.f; }
   const uint32_t dkey = tn_act_key(a.act), dthr = a.act.drop_thr;
   constexpr int U = 4;
-  for (int tb = tg; tb < a.T; tb += 16 * U) {
+  const int L = a.len ? a.len[b] : a.T;
+  for (int tb = tg; tb < L; tb += 16 * U) {
     uint4 ry[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = tb + 16 * u;
-      if (t < a.T) ry[u] = *reinterpret_cast<const uint4*>(a.Y + ((size_t)b * a.T + t) * V2_C + c0);
+      if (t < L) ry[u] = *reinterpret_cast<const uint4*>(a.Y + ((size_t)b * a.T + t) * V2_C + c0);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = tb + 16 * u;
-      if (t < a.T) {
+      if (t < L) {
         float v[8];
         unpack8(ry[u], v);
         act8_t<FL>(v, sc, sh, dkey, dthr, (uint32_t)b * a.T + t, c0);
@@ -483,7 +512,7 @@ __global__ __launch_bounds__(512) void se_squeeze_v2_kernel(SeSqueezeV2Args a) {
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) s += part[k][tid];
-    s *= 1.f / (float)a.T;
+    s *= 1.f / (float)max(L, 1);
     mean[tid] = s;
     a.m_out[(size_t)b * V2_C + tid] = s;
   }
@@ -531,7 +560,10 @@ inline int launch_se_squeeze_v2(const SeSqueezeV2Args& a, int B, hipStream_t st)
 // and one MFMA-bound wave to pick from, the operand tile is double buffered, and only two workgroup barriers
 // per tile remain.  The B-operand LDS reads halve (4 consumer waves instead of 8 re-read the tile).
 // ------------------------------------------------------------------------------------------
-template <int KD, bool DW, int FL>
+// MK (variable-length batch, a.act.rm.len): the producers read padding rows as zeros and WRITE the depthwise output of padding
+// rows as zeros (operand tile and kept copy), so the GEMM gives y == bias there: the host takes those rows out of the
+// statistics again (stats_pad_fixup_kernel) and the weight gradients see a zero operand row.
+template <int KD, bool DW, int FL, bool MK = false>
 __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
   constexpr int PADR = DW ? (KD - 1) / 2 : 0;
   constexpr int OUTR = DW ? V2_R - (KD - 1) : V2_R;
@@ -593,14 +625,23 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) prefetch_q(tile, q);
     };
+    TileMask tm = {0, 0, 0};
     auto produce_act = [&](int tile, bf16_t* As) {
       const int raw0 = tile * OUTR - PADR;
       const bool interior = raw0 >= 0 && raw0 + V2_R <= a.M;
+      if (MK) tm = tn_tile_mask(a.act.rm.len, a.T, a.M, raw0);         // (produce_stencil of the same tile reuses it)
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int r = rq + 8 * q, gr = raw0 + r;
         float v[8];
         unpack8(pf[q], v);
+        if (MK) {
+          if (gr >= 0 && gr < a.M && tn_tile_valid(tm, gr)) act8_t<FL>(v, sc, sh, dkey, dthr, (uint32_t)gr, c0);
+          else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = 0.f;
+          }
+        } else
         if (interior || (gr >= 0 && gr < a.M)) act8_t<FL>(v, sc, sh, dkey, dthr, (uint32_t)gr, c0);
         if (DW) store8(Xa + r * V2_C + c0, v);
         else store8(As + r * V2_AP + c0, v);
@@ -610,7 +651,8 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
     };
     auto produce_stencil = [&](int tile, bf16_t* As) {
       const int out0 = tile * OUTR, raw0 = out0 - PADR;
-      const bool one_utt = raw0 >= 0 && raw0 + V2_R <= a.M && (raw0 % a.T) + V2_R <= a.T;
+      // (masked: the fast path also needs every row of the tile to be a valid frame)
+      const bool one_utt = raw0 >= 0 && raw0 + V2_R <= a.M && (raw0 % a.T) + V2_R <= a.T && (!MK || raw0 + V2_R <= tm.lim0);
 #pragma unroll
       for (int grp = 0; grp < 2; ++grp) {
         const int o0 = grp * 32 + rq * 4;
@@ -652,6 +694,10 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
 #pragma unroll
                   for (int i = 0; i < 8; ++i) acc[i] = fmaf(wd[k][i], win[q + k][i], acc[i]);
                 }
+              }
+              if (MK && !tn_tile_valid(tm, out0 + o)) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = 0.f;
               }
             }
             store8(As + o * V2_AP + c0, acc);
@@ -770,7 +816,7 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
 
 template <int KD, bool DW, int FL>
 inline int launch_sub_fwd_v5_t(SubFwdV2Args a, int grid, size_t smem, hipStream_t st) {
-  auto kern = sub_fwd_v5_kernel<KD, DW, FL>;
+  auto kern = a.act.rm.len ? sub_fwd_v5_kernel<KD, DW, FL, true> : sub_fwd_v5_kernel<KD, DW, FL, false>;
   TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
   return (int)hipGetLastError();

@@ -56,8 +56,10 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < ho.size(); ++i) { const double d = fabs((double)ho[i] - hr[i]); if (d > worst) { worst = d; wi = i; } scale = fmax(scale, fabs((double)hr[i])); }
   printf("max abs diff %.4g at (%zu, %zu) [%.5g vs %.5g], max |ref| %.4g -> relative %.3g\n", worst, wi / nq, wi % nq, ho[wi], hr[wi], scale, worst / scale);
   const double flop = 2.0 * rows * np * nq;
-  float us = timeit([&](int i) { a.P = P[i & 1]; a.Q = Q[i & 1]; launch_pgemm_tn(a, 0); });
-  printf("pgemm_tn_kernel : %8.2f us  %.3f PFLOP/s   (P + Q once = %.0f MB -> %.2f TB/s)\n", us, flop / us / 1e9, (hp.size() + hq.size()) * 2 / 1e6,
-         (hp.size() + hq.size()) * 2 / us / 1e6);
+  for (int wgs : {256, 192, 128, 96, 64}) {
+    float us = timeit([&](int i) { a.P = P[i & 1]; a.Q = Q[i & 1]; launch_pgemm_tn(a, 0, wgs); });
+    printf("pgemm_tn_kernel (%3d wgs) : %8.2f us  %.3f PFLOP/s   (P + Q once = %.0f MB -> %.2f TB/s)\n", wgs, us, flop / us / 1e9, (hp.size() + hq.size()) * 2 / 1e6,
+           (hp.size() + hq.size()) * 2 / us / 1e6);
+  }
   return 0;
 }
