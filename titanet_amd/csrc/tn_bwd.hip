@@ -95,7 +95,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
 
   TN_CHECK_HIP(hipMemsetAsync(grads, 0, (size_t)m->n_params * sizeof(float), st));
   TN_CHECK_HIP(hipMemsetAsync(ws + p->bzero_begin, 0, p->bzero_bytes, st));
-  const int use_v2 = p->masked ? 0 : p->use_v2;     // variable-length batches: generic templates (see forward)
+  const int use_v2 = (p->masked && T < 64) ? 0 : p->use_v2;     // variable-length batches: as the forward
   if (p->masked && c.simple_pool) return TN_E_UNSUPPORTED;
   auto identity_rows = [&]() { BnAct a = identity_act(); a.rm = plan_row_mask(p); return a; };
   // wide models (hidden 512 / 1024, bf16, train; variable-length batches: dS = 0 on padding rows, so the padding rows of the
@@ -161,6 +161,9 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       const int upb = per_blk * p->wg2_upl;      // weight-gradient units per mega block
       int first = has_blocks ? bk.blk_lo * upb : nb * upb;
       int count = (has_blocks ? (bk.blk_hi - bk.blk_lo + 1) * upb : 0) + (bk.tail ? p->wg2_epi_slabs + p->wg2_asp_units : 0);
+      // variable-length batches: the first unit (block 0's skip conv: its other operand is the ACTIVATED prolog output, not
+      // zero on padding rows) is done by the generic masked kernel instead (see the skip connection below)
+      if (p->masked && has_blocks && bk.blk_lo == 0) { first += p->wg2_upl; count -= p->wg2_upl; }
       if (has_blocks && bk.tail && bk.blk_hi != nb - 1) { rc_fin = TN_E_STATE; return; }   // ranges must be contiguous
       if (count > 0) {
         const int chunks = (M + 31) / 32;
@@ -174,7 +177,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         {
           ProfScope ps(p, TN_PROF_BWD_WGRAD, st);
           hipLaunchKernelGGL(kern, dim3(p->wg2_grid), dim3(V2_NT), smem, st, (const WgradV2Desc*)(ws + p->wg2_desc) + first, count, M, T,
-                             chunks, upw, (int*)(ws + p->wg2_count) + first, seed);
+                             chunks, upw, (int*)(ws + p->wg2_count) + first, seed, 1.f / (float)(p->masked ? std::max(p->n_valid, 1) : M));
         }
         hipLaunchKernelGGL(wgrad_v2_reduce_kernel, dim3(32, count), dim3(256), 0, st, (const WgradV2Out*)(ws + p->wg2_out) + first,
                            (const int*)(ws + p->wg2_count) + first);
@@ -405,7 +408,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         ca.gate = (const float*)(ws + bw.g); ca.hid = (const float*)(ws + bw.h); ca.dgate = (const float*)(ws + bw.dgate);
         ca.dpre2 = (float*)(ws + bw.dpre2); ca.dpre1 = (float*)(ws + bw.dpre1);
         ca.W1 = params + mb.se_w1; ca.W2 = params + mb.se_w2; ca.dYbn = (bf16_t*)(ws + bw.dY[nsub - 1]);
-        ca.bsums3 = bsum(mb.sub[nsub - 1].bn); ca.T = T; ca.parts = 2;
+        ca.bsums3 = bsum(mb.sub[nsub - 1].bn); ca.T = T; ca.parts = 2; ca.len = plan_row_mask(p).len;
         rc2 = launch_combine_bwd2_v2(ca, B, st);
         if (rc2 > 0) return rc2;
       }
@@ -431,7 +434,8 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       ProdDy::Args pa{ws + bw.dZk, ws + bw.S, H, make_bnbwd(p, mb.bnskip, M, training)};
       ProdPlain::Args qa{xin, H, actx};
       int rc = 0;
-      if (!batched_wgrad) rc = launch_wgrad<AT, ProdDy, ProdPlain>(M, H, H, pa, qa, 0, slabs, p->slab_bytes, grads + mb.wskip, st);
+      if (!batched_wgrad || (p->masked && i == 0))
+        rc = launch_wgrad<AT, ProdDy, ProdPlain>(M, H, H, pa, qa, 0, slabs, p->slab_bytes, grads + mb.wskip, st);
       if (rc) return rc;
       if (v2_bwd) {
         DgradV2Args va;

@@ -211,7 +211,9 @@ template <int KD, bool ALLOW_DW>
 __global__ __launch_bounds__(V2_NT, 2) void wgrad_batched_v2_kernel(const WgradV2Desc* __restrict__ descs, int n_layers,
                                                                      int M, int T, int chunks_per_layer,
                                                                      int units_per_wg, int* __restrict__ part_count,
-                                                                     uint64_t seed) {
+                                                                     uint64_t seed, float inv_n_rows) {
+  // inv_n_rows: 1 / (rows the BatchNorm statistics ran over) — the descriptors are written once per plan with 1 / M, a
+  // variable-length batch has fewer valid rows every step
   constexpr int PADR = (KD - 1) / 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* Pt = reinterpret_cast<bf16_t*>(smem);                 // [32][288]
@@ -235,10 +237,15 @@ __global__ __launch_bounds__(V2_NT, 2) void wgrad_batched_v2_kernel(const WgradV
     __syncthreads();
     if (tid < V2_C) {
       BnBwd bb;
-      bb.fstats = d.fstats; bb.bsums = d.bsums; bb.gamma = d.gamma; bb.inv_n = d.inv_n; bb.eps = d.eps; bb.batch = d.batch;
+      bb.fstats = d.fstats; bb.bsums = d.bsums; bb.gamma = d.gamma; bb.inv_n = inv_n_rows; bb.eps = d.eps; bb.batch = d.batch;
       float k0 = 1.f, k1 = 0.f, k2 = 0.f, s, h;
       if (d.fstats) bn_bwd_coefs(bb, d.statC, d.chan0 + tid, k0, k1, k2);
-      bn_scale_shift(d.actX, d.ldq, d.q0 + tid, s, h);
+      {
+        BnAct ax;
+        ax.stats = d.actX.stats; ax.gamma = d.actX.gamma; ax.beta = d.actX.beta; ax.inv_n = inv_n_rows; ax.eps = d.actX.eps; ax.mode = d.actX.mode;
+        ax.drop_thr = d.actX.drop_thr; ax.inv_keep = d.actX.inv_keep;
+        bn_scale_shift(ax, d.ldq, d.q0 + tid, s, h);
+      }
       cst[tid] = k0; cst[V2_C + tid] = k1; cst[2 * V2_C + tid] = k2; cst[3 * V2_C + tid] = s; cst[4 * V2_C + tid] = h;
       cst[5 * V2_C + tid] = dw ? d.bdw[tid] : 0.f;
 #pragma unroll
@@ -476,6 +483,7 @@ struct CombineBwd2V2Args {
   bf16_t* dYbn;
   float* bsums3;
   int T, parts;
+  const int* len;     // valid frames per utterance or null: the SE mean ran over them; padding rows get a zero gradient
 };
 template <int FL3>
 __global__ __launch_bounds__(512) void combine_bwd2_v2_kernel(CombineBwd2V2Args a) {
@@ -487,7 +495,12 @@ __global__ __launch_bounds__(512) void combine_bwd2_v2_kernel(CombineBwd2V2Args 
   const int lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / a.parts, prt = blockIdx.x % a.parts;
   const int per = (a.T + a.parts - 1) / a.parts;
-  const int t0 = prt * per, t1 = min(a.T, t0 + per);
+  const int L = a.len ? a.len[b] : a.T;
+  const int t0 = prt * per, t_end = min(a.T, t0 + per), t1 = min(L, t_end);
+  {
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (int t = max(t0, L) + tg; t < t_end; t += 16) *reinterpret_cast<uint4*>(a.dYbn + ((size_t)b * a.T + t) * V2_C + c0) = z;
+  }
   constexpr int U = 2;
   uint4 rd[U], ry[U];
   auto fetch = [&](int tb) {
@@ -532,7 +545,7 @@ __global__ __launch_bounds__(512) void combine_bwd2_v2_kernel(CombineBwd2V2Args 
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < HR; ++j) s = fmaf(a.W1[(size_t)j * V2_C + tid], p1[j], s);
-    dmT[tid] = s / (float)a.T;
+    dmT[tid] = s / (float)max(L, 1);
   }
   __syncthreads();
   float sc[8], sh[8], g[8], dm[8], s1[8], s2[8];
@@ -1060,7 +1073,9 @@ struct DgradDwArgs {
   int M, T, ntiles;
 };
 
-template <int FL>
+// MK (variable-length batch, a.bn.rm.len): dS = 0 on padding rows (their dD then adds nothing to the valid rows next to them),
+// padding rows of X read as zeros (no tap-weight gradient through them), the data gradient is written as zero there.
+template <int FL, bool MK = false>
 __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
   constexpr int KD = 3, NT = V2_NT;
   constexpr bool HAS_MASK = (FL & 7) != 0, HAS_ADD = (FL & 8) != 0;
@@ -1115,6 +1130,8 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
   }
   for (; tile < a.ntiles; tile += gridDim.x) {
     const int g0 = tile * V6_OUT - 1;          // global row of tile row 0
+    TileMask tm = {0, 0, 0};
+    if (MK) tm = tn_tile_mask(a.bn.rm.len, a.T, a.M, g0);
     __syncthreads();   // (1) the previous tile's stencil is done with Dt / Xs, its MFMAs with Pt
     // ---- BN backward on load -> Pt;  raw X rows -> Xs
 #pragma unroll
@@ -1133,10 +1150,11 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
         *reinterpret_cast<float4*>(k2v) = *reinterpret_cast<const float4*>(cst + 2 * V2_C + c0);
         *reinterpret_cast<float4*>(k2v + 4) = *reinterpret_cast<const float4*>(cst + 2 * V2_C + c0 + 4);
         const bool ok = gr >= 0 && gr < a.M;
+        const bool valid = !MK || tn_tile_valid(tm, gr);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float v = fmaf(k0v[i], z[i], fmaf(k1v[i], y[i], k2v[i]));
-          z[i] = ok ? v : z[i];
+          z[i] = ok ? (valid ? v : 0.f) : z[i];
         }
       }
       store8(Pt + r * V2_AP + c0, z);
@@ -1169,7 +1187,8 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
       const int NR = nr4 ? 4 : 3;
       const int i0 = nr4 ? 1 + 4 * wave : 25 + 3 * (wave - 6);     // first output row of the strip (tile row index)
       const int gfirst = g0 + i0 - 1, glast = g0 + i0 + NR;        // window rows i0-1 .. i0+NR
-      const bool fast = gfirst >= 0 && glast < a.M && (gfirst % a.T) + NR + 1 < a.T;   // wave-uniform
+      // (masked: the strip lies inside one utterance, so its rows are valid frames iff the last one is)
+      const bool fast = gfirst >= 0 && glast < a.M && (gfirst % a.T) + NR + 1 < a.T && (!MK || tn_tile_valid(tm, glast - 1));   // wave-uniform
       auto ldD = [&](int i, float* D) { unpack4(*reinterpret_cast<const uint2*>(Dt + i * V2_AP + c4), D); };
       auto ldX = [&](int i, float* Yr) { unpack4(*reinterpret_cast<const uint2*>(Xs + i * V2_C + c4), Yr); };
       uint2 addv[4];
@@ -1236,11 +1255,16 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
           const int i = i0 + q, gr = g0 + i;
           if (i > V6_OUT || gr < 0 || gr >= a.M) continue;
           const int t = gr % a.T;
+          const bool pad = MK && !tn_tile_valid(tm, gr);
           float Dc[4], Dn[4], Dp[4], Ac[4], Yc[4], dA[4];
           ldD(i, Dc); ldX(i, Yc);
 #pragma unroll
           for (int c = 0; c < 4; ++c) Ac[c] = Yc[c];
           act4_t<FL>(Ac, sc, sh, dkey, dthr, (uint32_t)gr, c4);
+          if (pad) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Ac[c] = 0.f;
+          }
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             gb[c] += Dc[c];
@@ -1262,6 +1286,10 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
             unpack4(*reinterpret_cast<const uint2*>(a.ADD + (size_t)gr * V2_C + c4), ad);
 #pragma unroll
             for (int c = 0; c < 4; ++c) dA[c] += ad[c];
+          }
+          if (pad) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dA[c] = 0.f;
           }
           if (HAS_MASK) {
 #pragma unroll
@@ -1308,7 +1336,7 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
 
 template <int FL>
 inline int launch_dgrad_dw_v6_t(DgradDwArgs a, int grid, size_t smem, hipStream_t st) {
-  auto kern = dgrad_dw_v6_kernel<FL>;
+  auto kern = a.bn.rm.len ? dgrad_dw_v6_kernel<FL, true> : dgrad_dw_v6_kernel<FL, false>;
   TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
   return (int)hipGetLastError();
