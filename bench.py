@@ -274,7 +274,27 @@ def other_configs(dev):
                 "mfma_util": round(flops / dt / MFMA_PEAK_BF16, 4), "includes": "mel front end + SpecAugment inside the step",
                 "params_finite": bool(torch.isfinite(m.flat_parameters()).all())}
 
+    def masked_s():
+        # the headline model on a zero-padded batch with lengths (the collate_fn layout, lengths U(60, 300) frames): the padding
+        # mask rides through the specialised kernels (tile masks, zero-stored padding rows, corrected statistics)
+        B, T = 256, 300
+        loss = LOSSES["ce"](192, n_classes, device=dev)
+        m = TitaNet.get_titanet(n_mega_blocks=17, model_size="s", loss_function=loss, dropout=0.1, device=dev, precision="bf16").train()
+        tr = Trainer(m)
+        g = torch.Generator().manual_seed(7)
+        x = (torch.randn(B, 80, T, generator=g) * 0.11 - 0.10).to(dev)
+        y = torch.randint(0, n_classes, (B,), generator=g).to(dev)
+        ln = torch.randint(T // 5, T + 1, (B,), generator=g)
+        ln[0] = T
+        dt = _timed_steps(lambda: tr.step(x, y, lengths=ln), 3, 8)
+        valid = int(ln.sum())
+        return {"workload": f"TitaNet-S/17 fwd+bwd+Adam, ce head, batch {B}, zero-padded 80x{T} + lengths (padding mask), bf16",
+                "ms_per_step": round(dt * 1e3, 3), "utt_per_s": round(B / dt, 1), "valid_frames": valid, "padded_frames": B * T,
+                "bound": "hbm", "frac": round(ALG_BYTES_PER_UTT_BF16 * (B / dt) / 1e9 / HBM_PEAK_GBS, 4),
+                "params_finite": bool(torch.isfinite(m.flat_parameters()).all())}
+
     leg("s17_arcface_b256", lambda: fixed("s", 17, "bf16", "arc"))
+    leg("s17_padded_masked_b256", masked_s)
     leg("m10_ragged_mel_specaug_masked", ragged_m)
     leg("m10_b256", lambda: fixed("m", 10, "bf16", "ce", steps=6))
     leg("l5_fp8_b256", lambda: fixed("l", 5, "fp8", "ce", steps=5))

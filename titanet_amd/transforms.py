@@ -61,7 +61,8 @@ class MelSpectrogram:
             slot = self._ring[k] = (torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=self.device),
                                     torch.cuda.Event())
         else:
-            slot[2].synchronize()                      # the copy that last used this slot (4 batches ago) has run
+            while not slot[2].query():                 # the copy that last used this slot (4 batches ago) has run; spin (a
+                pass                                   # blocking wait sleeps, and waking up costs milliseconds on a busy host)
         host, dev, ev = slot
         for t, o in zip(parts, offs):
             n = t.numel() * t.element_size()
