@@ -48,11 +48,13 @@ class MelSpectrogram:
         """Small per-batch host arrays (lengths, rates, masks) -> device tensors through ONE asynchronous copy from a pinned
         staging slot (a ring of 4, each guarded by an event).  ``tensor.to(device)`` from pageable memory blocks the calling
         thread until the stream has drained — one sleep / wake-up round trip per array and step, which on a busy host cost more
-        than the whole network step (configs[3] leg: 26 -> 30-70 ms)."""
+        than the whole network step (configs[3] leg: 26 -> 30-70 ms).  ``parts``: (source tensor, dtype, shape) — the source
+        is converted and zero-padded to ``shape`` INSIDE the pinned slot (no temporaries: host allocations were the next stall)."""
+        import math
         offs, total = [], 0
-        for t in parts:
+        for _, dt, shape in parts:
             offs.append(total)
-            total += (t.numel() * t.element_size() + 15) // 16 * 16
+            total += (math.prod(shape) * torch.empty(0, dtype=dt).element_size() + 15) // 16 * 16
         k = self._ring_i % len(self._ring)
         self._ring_i += 1
         slot = self._ring[k]
@@ -64,12 +66,19 @@ class MelSpectrogram:
             while not slot[2].query():                 # the copy that last used this slot (4 batches ago) has run; spin (a
                 pass                                   # blocking wait sleeps, and waking up costs milliseconds on a busy host)
         host, dev, ev = slot
-        for t, o in zip(parts, offs):
-            n = t.numel() * t.element_size()
-            host[o:o + n].view(t.dtype).copy_(t.reshape(-1))
+        out = []
+        for (src, dt, shape), o in zip(parts, offs):
+            n = math.prod(shape) * torch.empty(0, dtype=dt).element_size()
+            view = host[o:o + n].view(dt).view(shape)
+            if tuple(src.shape) == tuple(shape):
+                view.copy_(src)
+            else:                                      # time masks narrower than the padded batch: zero beyond them
+                view.zero_()
+                view[:, :src.shape[1]].copy_(src)
+            out.append(dev[o:o + n].view(dt).view(shape))
         dev[:total].copy_(host[:total], non_blocking=True)
         ev.record(torch.cuda.current_stream(self.device))
-        return [dev[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for t, o in zip(parts, offs)]
+        return out
 
     def _mel(self):
         if self._handle is None:
@@ -135,13 +144,11 @@ class MelSpectrogram:
         if time_masks is not None:
             T = max(T, time_masks.shape[1])
         out = None if into is not None else torch.empty(B, self.n_mels, T, dtype=torch.float32, device=self.device)
-        parts = [ln, rt]
+        parts = [(ln, torch.int64, (B,)), (rt, torch.float64, (B,))]
         if freq_masks is not None:
-            parts.append(freq_masks.detach().to(device="cpu", dtype=torch.uint8).contiguous())
+            parts.append((freq_masks.detach(), torch.uint8, (B, self.n_mels)))
         if time_masks is not None:
-            tm_h = torch.zeros(B, T, dtype=torch.uint8)
-            tm_h[:, :time_masks.shape[1]] = time_masks.detach().to(device="cpu", dtype=torch.uint8)
-            parts.append(tm_h)
+            parts.append((time_masks.detach(), torch.uint8, (B, T)))
         up = self._upload(parts)
         ln_d, rt_d = up[0], up[1]
         fm = up[2] if freq_masks is not None else None
