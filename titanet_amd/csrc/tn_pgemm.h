@@ -463,6 +463,9 @@ inline int launch_pgemm_tn(PGemmTnArgs a, hipStream_t st, int max_wgs = 256) {
   const int units = (a.np / 256) * (a.nq / 256);
   if (units > max_wgs) return TN_E_UNSUPPORTED;
   const int nsteps = (a.rows + 31) / 32;
+  // 4 slabs (512 x 512 weights): every workgroup ends with 65536 atomics, and 64 row splits make that 16.7 M per layer — as
+  // long as the K loop itself.  48 splits (192 workgroups): 75.7 vs 85.9 us at 76800 rows (tools/pgemm_tn_harness)
+  if (units == 4 && max_wgs == 256) max_wgs = 192;
   int splits = max_wgs / units;
   if (splits > nsteps) splits = nsteps;
   a.steps_per_split = (nsteps + splits - 1) / splits;
