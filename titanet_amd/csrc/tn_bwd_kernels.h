@@ -478,6 +478,7 @@ __global__ __launch_bounds__(512) void combine_bwd1_kernel(const AT* __restrict_
   float* part = gS + C;   // [TG][3][C]
   const int tid = threadIdx.x, NT = blockDim.x, b = blockIdx.x;
   const int CV = C / 8, TG = NT / CV;
+  act3 = tn_resolve_key(act3);
   for (int c = tid; c < C; c += NT) {
     bn_scale_shift(act3, C, c, sc3[c], sh3[c]);
     bn_mean_rstd(actS, C, c, mS[c], rS[c]);
@@ -595,6 +596,7 @@ __global__ __launch_bounds__(512) void combine_bwd2_kernel(const AT* __restrict_
   float* part = p1 + ((Hr + 3) & ~3);   // [TG][2][C]
   const int tid = threadIdx.x, NT = blockDim.x, b = blockIdx.x;
   const int CV = C / 8, TG = NT / CV;
+  act3 = tn_resolve_key(act3);
   for (int c = tid; c < C; c += NT) {
     bn_scale_shift(act3, C, c, sc3[c], sh3[c]);
     bn_mean_rstd(act3, C, c, m3[c], r3[c]);

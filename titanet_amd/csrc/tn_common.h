@@ -213,6 +213,13 @@ __device__ __forceinline__ void bn_scale_shift(const BnAct& a, int C, int c, flo
 
 __device__ __forceinline__ uint32_t tn_act_key(const BnAct& a) { return a.key_add ? a.drop_key + *a.key_add : a.drop_key; }
 
+// the dropout key with the plan's per-step word folded in ONCE: act8 / act8_grad_mask otherwise dereference key_add (a global
+// load) for every 8-element vector of a streaming loop
+__device__ __forceinline__ BnAct tn_resolve_key(BnAct a) {
+  if (a.drop_thr && a.key_add) { a.drop_key += *a.key_add; a.key_add = nullptr; }
+  return a;
+}
+
 // apply act to 8 consecutive channels of row `row` (element index = row*C + c0 + i)
 __device__ __forceinline__ void act8(float v[8], const float* sc, const float* sh, const BnAct& a,
                                      uint32_t row, int C, int c0) {

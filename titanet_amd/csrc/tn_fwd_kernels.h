@@ -399,6 +399,7 @@ __global__ __launch_bounds__(512) void se_squeeze_fc_kernel(const AT* __restrict
   float* part = hbuf + ((Hr + 3) & ~3);   // [TG][C]
   const int tid = threadIdx.x, NT = blockDim.x, b = blockIdx.x;
   const int CV = C / 8, TG = NT / CV;
+  act = tn_resolve_key(act);
   if (act.mode != 0)
     for (int c = tid; c < C; c += NT) bn_scale_shift(act, C, c, sc[c], sh[c]);
   __syncthreads();
@@ -488,6 +489,7 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(const AT* __restrict__
   float* sc3 = shS + C;
   float* sh3 = sc3 + C;
   const int tid = threadIdx.x, NT = blockDim.x;
+  act3 = tn_resolve_key(act3);
   for (int c = tid; c < C; c += NT) {
     bn_scale_shift(actS, C, c, scS[c], shS[c]);
     bn_scale_shift(act3, C, c, sc3[c], sh3[c]);
