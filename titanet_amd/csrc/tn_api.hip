@@ -835,6 +835,8 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
     }
   }
   BnAct acte = make_act(p, m->epi_bn, M, training, 1, 0.f, seed, 0);
+  // the attention GEMMs (1536 <-> 128) do not depend on the hidden width: the wide models run them on the same kernels
+  const bool attn_v2 = sizeof(AT) == 2 && !p->generic && D % 256 == 0 && A == 128 && ((use_v2 && H == 256) || (H >= 512 && !use_v2 && p->wide_dw_bwd));
   if (c.simple_pool) {
     // ---- simple pool (reference src/models.py:497-502): mean over time, then Linear(D, 2D) in f32
     hipLaunchKernelGGL(mean_pool_fwd_kernel<AT>, dim3(B, (D + 511) / 512), dim3(256), 0, st, (const AT*)(ws + p->E), acte, T, D,
@@ -848,7 +850,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   // ---- attentive statistics pooling (reference src/models.py:553-584)
   {
     int rc;
-    if (sizeof(AT) == 2 && use_v2 && H == 256 && D % 256 == 0 && A == 128) {
+    if (attn_v2) {
       WideInArgs wa;
       memset(&wa, 0, sizeof(wa));
       wa.A = (const bf16_t*)(ws + p->E); wa.act = acte; wa.W = (const bf16_t*)wsel<AT>(p, m->asp_win, p->wwin);
@@ -861,7 +863,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       rc = gemm_store<AT, ProdPlain, EpiStoreTanh>(g1, pa1, ea1, 0, st);
     }
     if (rc) return rc;
-    if (sizeof(AT) == 2 && use_v2 && H == 256 && D % 256 == 0 && A == 128) {
+    if (attn_v2) {
       WideOutArgs wa;
       memset(&wa, 0, sizeof(wa));
       wa.X = (const bf16_t*)(ws + p->HID); wa.W = (const bf16_t*)wsel<AT>(p, m->asp_wout, p->wwout); wa.bias = params + m->asp_bout;

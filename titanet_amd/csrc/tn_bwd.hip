@@ -249,6 +249,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   }
   // ================= attentive statistics pooling =================
   BnAct acte = make_act(p, m->epi_bn, M, training, 1, 0.f, seed, 0);
+  const bool attn_v2 = sizeof(AT) == 2 && !p->generic && D % 256 == 0 && A == 128 && ((use_v2 && H == 256) || (H >= 512 && !use_v2 && p->wide_dw_bwd));
   if (c.simple_pool) {
     // ================= simple pool: Linear(D, 2D) over B rows, then the mean over time =================
     const float* dpool = (const float*)(ws + p->dpooled);
@@ -287,7 +288,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     // d hid_pre = (dEN * W_out) .* (1 - hid^2)
     {
       int rc;
-      if (sizeof(AT) == 2 && use_v2 && H == 256 && D % 256 == 0 && A == 128) {
+      if (attn_v2) {
         WideInArgs wa;
         memset(&wa, 0, sizeof(wa));
         wa.A = (const bf16_t*)(ws + p->dE); wa.W = (const bf16_t*)wt(p->wwout); wa.H = (const bf16_t*)(ws + p->HID);
@@ -311,7 +312,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     // d x = dHP * W_in + direct term; through the epilog relu -> dEbn (+ BN backward sums)
     {
       int rc;
-      if (sizeof(AT) == 2 && use_v2 && H == 256 && D % 256 == 0 && A == 128) {
+      if (attn_v2) {
         WideOutArgs wa;
         memset(&wa, 0, sizeof(wa));
         wa.X = (const bf16_t*)(ws + p->dHP); wa.W = (const bf16_t*)wt(p->wwin); wa.Y = (bf16_t*)(ws + p->dEbn);

@@ -413,24 +413,23 @@ __global__ __launch_bounds__(512) void se_squeeze_fc_kernel(const AT* __restrict
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = 0.f;
     // 6 rows in flight per thread (one workgroup per utterance: with one load at a time this loop was an HBM round trip per
-    // row, 116 us for the 157 MB of a TitaNet-L tensor)
+    // row, 116 us for the 157 MB of a TitaNet-L tensor).  Branch-free: rows past the end are CLAMPED to the last one and
+    // added with weight zero — predicated loads compiled to one exec-masked block (with its own wait) per row, 2 TB/s
     constexpr int U = 6;
     for (int t0 = t_lo + tg; t0 < t_hi; t0 += TG * U) {
       float v[U][8];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int t = t0 + u * TG;
-        if (t < t_hi) load8(Y + ((size_t)b * T + t) * C + vc * 8, v[u]);
+        const int t = min(t0 + u * TG, t_hi - 1);
+        load8(Y + ((size_t)b * T + t) * C + vc * 8, v[u]);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int t = t0 + u * TG;
-        if (t < t_hi) {
-          const uint32_t row = (uint32_t)b * T + t;
-          act8(v[u], sc + vc * 8, sh + vc * 8, act, row, C, vc * 8);
+        const uint32_t row = (uint32_t)b * T + min(t, t_hi - 1);
+        act8(v[u], sc + vc * 8, sh + vc * 8, act, row, C, vc * 8);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) s[i] += v[u][i];
-        }
+        for (int i = 0; i < 8; ++i) s[i] += (t < t_hi) ? v[u][i] : 0.f;
       }
     }
 #pragma unroll
