@@ -78,3 +78,54 @@ def test_generic_and_specialised_paths_agree():
     print("generic", res["0"], "specialised", res["31"])
     assert abs(res["0"][0] - res["31"][0]) < 3e-2
     assert res["0"][2] > 0.97 and res["31"][2] > 0.97
+
+
+def _fast_vs_generic(cfg, lengths=None):
+    import os
+    from titanet_amd import LOSSES, TitaNet
+    out = {}
+    for mode in ("generic", "fast"):
+        if mode == "generic":
+            os.environ["TN_GENERIC"] = "1"
+        try:
+            torch.manual_seed(cfg["wseed"])
+            m = TitaNet.get_titanet(n_mega_blocks=cfg["blocks"], model_size="s", loss_function=LOSSES["ce"](192, cfg["ncls"], device="cuda"),
+                                    dropout=cfg["p"], device="cuda", precision="bf16", simple_pool=cfg.get("simple", False)).train()
+            m._seed_base, m._step = 777, 0
+            g = torch.Generator().manual_seed(cfg["xseed"])
+            x = (torch.randn(cfg["B"], 80, cfg["T"], generator=g) * 0.11 - 0.1).cuda()
+            y = torch.randint(0, cfg["ncls"], (cfg["B"],), generator=g).cuda()
+            emb, _, lv = m(x, speakers=y, lengths=lengths)
+        finally:
+            os.environ.pop("TN_GENERIC", None)
+        lv.backward()
+        torch.cuda.synchronize()
+        out[mode] = (emb.detach().float().cpu().numpy(), {k: p.grad.detach().float().cpu().numpy().copy() for k, p in m.named_parameters()})
+        del m
+    return out
+
+
+def test_simple_pool_on_the_specialised_path():
+    """`simple_pool=True` with the hidden-256 bf16 kernels: the epilog conv's fragment-order weight copy is part of the swizzle
+    table whatever the pooling layer is (it used to be left unwritten: embeddings off by 140 %, found by tools/fuzz_paths.py)."""
+    import numpy as np
+    r = _fast_vs_generic(dict(B=5, T=201, p=0.1, blocks=2, ncls=11, simple=True, wseed=837094312, xseed=626172329))
+    e = float(np.linalg.norm(r["fast"][0] - r["generic"][0]) / np.linalg.norm(r["generic"][0]))
+    a = np.concatenate([v.ravel() for v in r["fast"][1].values()]); b = np.concatenate([v.ravel() for v in r["generic"][1].values()])
+    cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+    assert np.isfinite(a).all() and e < 5e-2 and cos > 0.97, (e, cos)
+
+
+def test_padding_mask_every_weight_gradient_slab():
+    """Variable-length batch on the batched weight-gradient launch: the launch drops block 0's skip unit (done by the generic masked
+    kernel), which changes how the (layer, chunk) units are cut into workgroups — the partial-slab capacity must cover that
+    partition too (an overflow corrupted the gradients of neighbouring layers: cosine 0.36 for the attention output weights)."""
+    import numpy as np
+    g = torch.Generator().manual_seed(976519419)
+    lengths = torch.tensor([95, 142, 113, 14, 102, 121, 128, 98, 72, 94, 63, 130, 137, 146, 75, 7, 19, 44, 78, 60, 151, 151, 15, 100, 124])
+    r = _fast_vs_generic(dict(B=25, T=151, p=0.0, blocks=1, ncls=45, wseed=329160110, xseed=976519419), lengths=lengths)
+    for k in ("decoder.pool.0.out_linear.weight", "decoder.pool.0.in_linear.weight", "encoder.epilog.conv_block.0.weight",
+              "encoder.mega_blocks.0.sub_blocks.2.conv_block.0.conv.1.weight", "encoder.mega_blocks.0.skip_connection.0.weight"):
+        a, b = r["fast"][1][k].ravel(), r["generic"][1][k].ravel()
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+        assert cos > 0.99, (k, cos)

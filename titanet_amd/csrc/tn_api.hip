@@ -374,9 +374,13 @@ void plan_layout_tail(tn_plan* p) {
     for (const auto& bk : p->buckets) {
       const int layers = (bk.blk_hi >= bk.blk_lo ? (bk.blk_hi - bk.blk_lo + 1) * per_blk : 0) + (bk.tail ? p->wg2_epi_slabs + p->wg2_asp_units : 0);
       if (layers == 0) continue;
-      const long total = (long)layers * chunks;
-      const int upw = (int)((total + p->wg2_grid - 1) / p->wg2_grid);
-      maxparts = std::max(maxparts, (chunks + upw - 1) / upw + 1);
+      // (variable-length batches launch the group of block 0 without its first layer: both partitions must fit)
+      for (int drop = 0; drop <= ((bk.blk_hi >= bk.blk_lo && bk.blk_lo == 0) ? p->wg2_upl : 0); drop += std::max(p->wg2_upl, 1)) {
+        if (layers - drop <= 0) break;
+        const long total = (long)(layers - drop) * chunks;
+        const int upw = (int)((total + p->wg2_grid - 1) / p->wg2_grid);
+        maxparts = std::max(maxparts, (chunks + upw - 1) / upw + 1);
+      }
     }
     p->wg2_maxparts = maxparts;
     p->wg2_slabs = b.take((size_t)p->wg2_layers * p->wg2_maxparts * 256 * 256 * sizeof(float));
@@ -494,8 +498,11 @@ extern "C" int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbu
       sd.push_back(SwzDesc{(const bf16_t*)(p->ws + r.wt), (uint4*)(p->ws + r.swt), 256, 256});
     };
     // the wide kernels' weights: epilog conv [D][H], ASP energies [D][A], and W_in^T [D][A] for the backward
+    // (the epilog conv's fragment-order copy is read whatever the pooling layer is: with `simple_pool` it used to be left
+    //  unwritten, and the wide epilog kernel multiplied by whatever the workspace held — found by tools/fuzz_paths.py)
+    if (p->use_v2 && c.hidden == 256 && c.enc_out % 256 == 0 && p->wepi.sw)
+      sd.push_back(SwzDesc{(const bf16_t*)(p->ws + p->wepi.w), (uint4*)(p->ws + p->wepi.sw), c.enc_out, c.hidden});
     if (p->use_v2 && !c.simple_pool && c.hidden == 256 && c.enc_out % 256 == 0 && c.attn_hidden == 128) {
-      if (p->wepi.sw) sd.push_back(SwzDesc{(const bf16_t*)(p->ws + p->wepi.w), (uint4*)(p->ws + p->wepi.sw), c.enc_out, c.hidden});
       if (p->wwout.sw) sd.push_back(SwzDesc{(const bf16_t*)(p->ws + p->wwout.w), (uint4*)(p->ws + p->wwout.sw), c.enc_out, c.attn_hidden});
       if (p->wwin.swt) sd.push_back(SwzDesc{(const bf16_t*)(p->ws + p->wwin.wt), (uint4*)(p->ws + p->wwin.swt), c.enc_out, c.attn_hidden});
     }

@@ -18,21 +18,25 @@ def run(mask, cfg):
         lf = LOSSES["ce"](192, cfg["ncls"], device="cuda")
     else:
         lf = LOSSES["arc"](192, cfg["ncls"], device="cuda", scale=30, margin=0.2)
-    m = TitaNet.get_titanet(n_mega_blocks=cfg["blocks"], model_size="s", loss_function=lf, dropout=cfg["p"], device="cuda",
+    m = TitaNet.get_titanet(n_mega_blocks=cfg["blocks"], model_size=cfg.get("size", "s"), loss_function=lf, dropout=cfg["p"], device="cuda",
                             precision="bf16", simple_pool=cfg["simple"])
     m._seed_base, m._step = 777, 0
     g = torch.Generator().manual_seed(cfg["xseed"])
     x = (torch.randn(cfg["B"], 80, cfg["T"], generator=g) * 0.11 - 0.1).cuda()
     y = torch.randint(0, cfg["ncls"], (cfg["B"],), generator=g).cuda()
+    lengths = None
+    if cfg.get("masked"):
+        lengths = torch.randint(1, cfg["T"] + 1, (cfg["B"],), generator=g)
+        lengths[int(torch.randint(0, cfg["B"], (1,), generator=g))] = cfg["T"]
     if cfg["train"]:
         m.train()
-        emb, preds, loss = m(x, speakers=y)
+        emb, preds, loss = m(x, speakers=y, lengths=lengths)
         loss.backward()
         grad = torch.cat([p.grad.flatten() for p in m.parameters()]).float().cpu()
         return emb.detach().float().cpu(), float(loss), grad
     m.eval()
     with torch.no_grad():
-        emb = m(x)
+        emb = m(x, lengths=lengths)
     return emb.float().cpu(), 0.0, None
 
 
@@ -44,7 +48,12 @@ def main():
         cfg = dict(B=int(rng.integers(3, 40)), T=int(rng.choice([33, 64, 65, 100, 151, 201, 300, 301, 417])),
                    p=float(rng.choice([0.0, 0.1, 0.3])), head=str(rng.choice(["ce", "arc"])), blocks=int(rng.integers(1, 4)),
                    ncls=int(rng.integers(5, 60)), simple=bool(rng.random() < 0.2), train=bool(rng.random() < 0.8),
-                   wseed=int(rng.integers(1 << 30)), xseed=int(rng.integers(1 << 30)))
+                   wseed=int(rng.integers(1 << 30)), xseed=int(rng.integers(1 << 30)),
+                   size=str(rng.choice(["s", "s", "m", "l"])), masked=bool(rng.random() < 0.6))
+        if cfg["size"] != "s":
+            cfg["blocks"] = min(cfg["blocks"], 2)
+        if cfg["masked"]:
+            cfg["simple"] = False              # (the mean-pool decoder has no masked variant)
         e0, l0, g0 = run("0", cfg)
         e1, l1, g1 = run(None, cfg)
         er = float((e1 - e0).norm() / e0.norm())
