@@ -19,7 +19,9 @@ def run(mask, cfg):
     else:
         lf = LOSSES["arc"](192, cfg["ncls"], device="cuda", scale=30, margin=0.2)
     m = TitaNet.get_titanet(n_mega_blocks=cfg["blocks"], model_size=cfg.get("size", "s"), loss_function=lf, dropout=cfg["p"], device="cuda",
-                            precision="bf16", simple_pool=cfg["simple"])
+                            precision=cfg.get("prec", "bf16"), simple_pool=cfg["simple"])
+    if cfg.get("groups", 1) > 1:
+        m.grad_groups = cfg["groups"]          # backward finalises the gradient in 1 + groups buckets (the data-parallel layout)
     m._seed_base, m._step = 777, 0
     g = torch.Generator().manual_seed(cfg["xseed"])
     x = (torch.randn(cfg["B"], 80, cfg["T"], generator=g) * 0.11 - 0.1).cuda()
@@ -45,11 +47,13 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     worst = 0.0
     for i in range(n):
-        cfg = dict(B=int(rng.integers(3, 40)), T=int(rng.choice([33, 64, 65, 100, 151, 201, 300, 301, 417])),
+        cfg = dict(B=int(rng.integers(3, 40)), T=int(rng.choice([33, 64, 65, 100, 151, 201, 300, 301, 417, 520, 700])),
                    p=float(rng.choice([0.0, 0.1, 0.3])), head=str(rng.choice(["ce", "arc"])), blocks=int(rng.integers(1, 4)),
                    ncls=int(rng.integers(5, 60)), simple=bool(rng.random() < 0.2), train=bool(rng.random() < 0.8),
                    wseed=int(rng.integers(1 << 30)), xseed=int(rng.integers(1 << 30)),
                    size=str(rng.choice(["s", "s", "m", "l"])), masked=bool(rng.random() < 0.6))
+        cfg["groups"] = int(rng.choice([1, 1, 2, 3]))
+        cfg["prec"] = "fp8" if (cfg["size"] != "s" and rng.random() < 0.3) else "bf16"
         if cfg["size"] != "s":
             cfg["blocks"] = min(cfg["blocks"], 2)
         if cfg["masked"]:
@@ -58,11 +62,12 @@ def main():
         e1, l1, g1 = run(None, cfg)
         er = float((e1 - e0).norm() / e0.norm())
         msg = f"{i:3d} {cfg}  emb rel {er:.2e}"
-        ok = er < 5e-2
+        f8 = cfg.get("prec") == "fp8"          # (TN_GENERIC plans compute in bf16: an fp8 case compares e4m3 forward GEMMs with bf16 ones)
+        ok = er < (1e-1 if f8 else 5e-2)
         if cfg["train"]:
             cos = float((g0 @ g1) / (g0.norm() * g1.norm()))
             msg += f"  dloss {abs(l1 - l0):.2e}  grad cos {cos:.4f}"
-            ok = ok and abs(l1 - l0) < 5e-2 * max(1.0, abs(l0)) and cos > (0.97 if cfg["B"] * cfg["T"] >= 1500 else 0.9)
+            ok = ok and abs(l1 - l0) < 5e-2 * max(1.0, abs(l0)) and cos > ((0.95 if f8 else 0.97) if cfg["B"] * cfg["T"] >= 1500 else 0.9)
         worst = max(worst, er)
         print(("ok  " if ok else "FAIL") + msg, flush=True)
     print("worst emb rel", worst)
