@@ -325,3 +325,20 @@ def test_resume_from_a_checkpoint_written_by_the_reference():
             worst, worst_k = e, k
     print("worst relative parameter / buffer difference after the resumed step", worst, worst_k)
     assert worst < 2e-3, (worst, worst_k)
+
+
+def test_variable_length_training_fast_kernels_track_the_generic_path():
+    """30 optimizer steps on a learnable synthetic task with zero-padded batches + lengths: the masked fast kernels and the
+    generic masked templates drive the loss down the same way (tools/train_compare_masked.py is the long version)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("tcm", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "train_compare_masked.py"))
+    tcm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tcm)
+    fast = tcm.run("s", 3, False, 30)
+    gen = tcm.run("s", 3, True, 30)
+    assert fast[2] and gen[2]
+    assert fast[0][-1] < 0.2 * fast[0][0] and gen[0][-1] < 0.2 * gen[0][0], (fast[0][::5], gen[0][::5])
+    # same data, same dropout stream, bf16 noise only: the curves stay together
+    for k in (5, 10, 20, 29):
+        assert abs(fast[0][k] - gen[0][k]) < 0.15 * max(gen[0][k], 0.05), (k, fast[0][k], gen[0][k])
