@@ -298,14 +298,14 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
 }
 
 template <int DBG = 0, bool F8 = false>
-inline int launch_pgemm_nt_t(const GemmShape& g, const PGemmNtArgs& pa, const PGemmEpiArgs& ea, hipStream_t st, int max_wgs) {
+inline int launch_pgemm_nt_t(const GemmShape& g, const PGemmNtArgs& pa, const PGemmEpiArgs& ea, hipStream_t st, int max_wgs, bool even_rounds = true) {
   if (g.K % (F8 ? 64 : 32) || g.K <= 0 || pa.lda % (F8 ? 16 : 8) || g.N % 64 || g.N > 3072 || ea.ldy % 2 || g.M <= 0) return TN_E_UNSUPPORTED;
   if ((long)g.M * pa.lda >= (1L << 32) || (long)g.N * g.K >= (1L << 32) || (long)g.M * ea.ldy * 2 >= (1L << 32)) return TN_E_UNSUPPORTED;
   const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256, total = tiles_m * tiles_n;
   // persistent workgroups with the same number of tiles each (1200 tiles: 240 x 5 beats 256 x 4.7, the last round of which
   // runs at 69 % occupancy: 201 vs 209 us), a multiple of 8 for the XCD-contiguous order
   int grid = total < max_wgs ? total : max_wgs;
-  if (grid >= 8) {
+  if (grid >= 8 && even_rounds) {
     const int rounds = (total + grid - 1) / grid;
     grid = (((total + rounds - 1) / rounds) + 7) & ~7;
     if (grid > max_wgs) grid = max_wgs & ~7;

@@ -113,6 +113,12 @@ int main(int argc, char** argv) {
     float us = timeit([&](int i) { pa.A = A[i % NSET]; ea.Y = Y[i % NSET]; launch_pgemm_nt(g, pa, ea, 0, wgs); });
     printf("pgemm_nt_kernel (%3d wgs) : %8.2f us  %.3f PFLOP/s\n", wgs, us, flop / us / 1e9);
   }
+  for (int wgs : {256, 248, 232}) {
+    PGemmNtArgs pa{A[0], K};
+    PGemmEpiArgs ea{Y[0], N, bias, stats, nullptr};
+    float us = timeit([&](int i) { pa.A = A[i % NSET]; ea.Y = Y[i % NSET]; launch_pgemm_nt_t<0>(g, pa, ea, 0, wgs, false); });
+    printf("pgemm_nt_kernel (%3d wgs, uneven rounds) : %8.2f us  %.3f PFLOP/s\n", wgs, us, flop / us / 1e9);
+  }
   {
     PGemmNtArgs pa{A[0], K};
     PGemmEpiArgs ea{Y[0], N, bias, stats, nullptr};
