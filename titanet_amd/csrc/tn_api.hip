@@ -218,6 +218,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   // ---- device-resident step state {uint64 step; uint32 word; ...}: cleared once at bind, advanced by tn_plan_step_tick
   p->step_state = b.take(64);
   p->lens = b.take(sizeof(int) * (size_t)batch);
+  p->rowtiles = b.take(sizeof(int) * ((size_t)(M + 255) / 256 + 1));
   if (p->tail_parts > 1) p->se_acc = b.take((size_t)batch * p->tail_parts * H * sizeof(float));      // one block at a time
   // ---- compute-precision weights
   auto wc = [&](size_t n, size_t k) {
@@ -303,6 +304,8 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   }
   // hidden 512 / 1024 (TitaNet-M / -L), bf16: slab kernels for the depthwise convs, pipelined GEMMs (tn_pgemm.h)
   p->wide_wgrad = !p->use_v2 && !p->generic && precision == TN_PREC_BF16 && (H == 512 || H == 1024) && D % 256 == 0 && c.n_mega_blocks > 0;
+  // (dropout > 0: the slab depthwise backward has no variant without it, and the generic one does not mask its dD operand)
+  p->skip_pad_tiles = p->wide_wgrad && p->wide_dw_bwd && (c.kernel == 7 || c.kernel == 11) && !c.simple_pool && c.dropout > 0.f;
   if (p->use_v2) {
     const int hs = (int)(H / 256);
     p->wg2_upl = hs * hs;
@@ -465,6 +468,9 @@ extern "C" int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbu
   hipStream_t st = (hipStream_t)stream;
   p->params = params; p->grads = grads; p->bnbuf = bnbuf; p->nbt = nbt; p->ws = (char*)workspace;
   p->bound_bytes = workspace_bytes;
+  // every byte defined once: variable-length batches leave the rows of padding-only tiles untouched (PGemmNtArgs::rowtiles),
+  // and what those rows hold is multiplied by zero weights later — it must never be a NaN / Inf bit pattern
+  if (p->skip_pad_tiles) TN_CHECK_HIP(hipMemsetAsync(p->ws, 0, p->ws_bytes, st));
   TN_CHECK_HIP(hipMemsetAsync(p->ws + p->step_state, 0, 64, st));
   const tn_model* m = p->model;
   const tn_config& c = m->cfg;
@@ -615,8 +621,10 @@ int gemm_plain_pipe(const tn_plan* p, const GemmShape& g, const void* X, int ldx
   if (act.mode != 0 || act.relu || act.drop_thr) return -1000;
   if (g.K % 32 || g.N % 64 || g.N > 3072 || ldx % 8 || ea.ldy % 2) return -1000;
   if (g.K < 256) return -1000;
-  PGemmNtArgs pa{(const bf16_t*)X, ldx};
-  PGemmEpiArgs pe{(bf16_t*)ea.Y, ea.ldy, ea.bias, ea.stats, ea.colscale, p->masked ? (float)(p->M - p->n_valid) : 0.f};
+  const bool listed = p->masked && p->n_rowtiles > 0;
+  PGemmNtArgs pa{(const bf16_t*)X, ldx, listed ? (const int*)(p->ws + p->rowtiles) : nullptr, listed ? p->n_rowtiles : 0};
+  // (statistics: the padding rows INSIDE the computed tiles give y == bias; the skipped tiles add nothing)
+  PGemmEpiArgs pe{(bf16_t*)ea.Y, ea.ldy, ea.bias, ea.stats, ea.colscale, p->masked ? (float)(p->active_rows - p->n_valid) : 0.f};
   return launch_pgemm_nt(g, pa, pe, st);
 }
 
@@ -751,8 +759,9 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
             // the pipelined LDS-DMA GEMM on the 64-k e4m3 MFMA (tn_pgemm.h, F8): 1.25 PFLOP/s at 76800 x 1024 x 1024 vs 0.96
             rc = -1000;
             if (!p->generic && H % 64 == 0 && H >= 256 && (!p->masked || q_clean)) {
-              PGemmNtArgs pa8{(const bf16_t*)q8, H};
-              PGemmEpiArgs pe8{(bf16_t*)e8.Y, e8.ldy, e8.bias, e8.stats, e8.colscale, p->masked ? (float)(p->M - p->n_valid) : 0.f};
+              const bool listed = p->masked && p->n_rowtiles > 0;
+              PGemmNtArgs pa8{(const bf16_t*)q8, H, listed ? (const int*)(p->ws + p->rowtiles) : nullptr, listed ? p->n_rowtiles : 0};
+              PGemmEpiArgs pe8{(bf16_t*)e8.Y, e8.ldy, e8.bias, e8.stats, e8.colscale, p->masked ? (float)(p->active_rows - p->n_valid) : 0.f};
               rc = launch_pgemm_nt_f8(g8, pa8, pe8, st);
             }
             if (rc == -1000) rc = launch_gemm_fp8<EpiStore>(g8, q8, e8, st);
@@ -983,6 +992,32 @@ static int plan_set_lengths(tn_plan* p, const int64_t* lengths_host, int trainin
     const int n = std::min(512, p->B - b0);
     memcpy(c.v, p->lens_host.data() + b0, sizeof(int) * (size_t)n);
     hipLaunchKernelGGL(lens_write_kernel, dim3(1), dim3(256), 0, st, c, n, (int*)(p->ws + p->lens) + b0);
+  }
+  p->n_rowtiles = 0;
+  p->active_rows = p->M;
+  if (p->skip_pad_tiles) {
+    // 256-row tiles with at least one valid frame: utterance b covers rows [b T, b T + len_b)
+    const int tiles = (p->M + 255) / 256;
+    std::vector<int> act;
+    act.reserve(tiles);
+    int next = 0;                                  // first tile not yet listed
+    for (int b = 0; b < p->B; ++b) {
+      const long r0 = (long)b * p->T, r1 = r0 + p->lens_host[b] - 1;
+      for (int t = std::max<int>(next, (int)(r0 / 256)); t <= (int)(r1 / 256); ++t) act.push_back(t);
+      next = std::max<int>(next, (int)(r1 / 256) + 1);
+    }
+    if ((int)act.size() < tiles) {               // (nothing to skip otherwise: the kernels then run without a list)
+      p->n_rowtiles = (int)act.size();
+      long rows = 0;
+      for (int t : act) rows += std::min(256, p->M - t * 256);
+      p->active_rows = (int)rows;
+      for (size_t i0 = 0; i0 < act.size(); i0 += 512) {
+        LensChunk c;
+        const int n = (int)std::min<size_t>(512, act.size() - i0);
+        memcpy(c.v, act.data() + i0, sizeof(int) * (size_t)n);
+        hipLaunchKernelGGL(lens_write_kernel, dim3(1), dim3(256), 0, st, c, n, (int*)(p->ws + p->rowtiles) + i0);
+      }
+    }
   }
   return (int)hipGetLastError();
 }

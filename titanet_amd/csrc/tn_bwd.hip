@@ -112,13 +112,15 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     if (rc) return rc;
     DBG("pipe dS", dz, (size_t)M * Cout);
     GemmShape g{M, Cin, Cout, ws + wc.wt};
-    PGemmNtArgs pa{(const bf16_t*)(ws + dz), Cout};
+    const bool listed = p->masked && p->n_rowtiles > 0;
+    const int* rowtiles = listed ? (const int*)(ws + p->rowtiles) : nullptr;
+    PGemmNtArgs pa{(const bf16_t*)(ws + dz), Cout, rowtiles, listed ? p->n_rowtiles : 0};
     PGemmEpiArgs pe{(bf16_t*)(ws + dx_out), Cin, nullptr, nullptr, nullptr};
     rc = launch_pgemm_nt(g, pa, pe, st);
     if (rc) return rc;
     DBG("pipe dX", dx_out, (size_t)M * Cin);
     if (q_plain) {
-      PGemmTnArgs ta{(const bf16_t*)(ws + dz), Cout, Cout, (const bf16_t*)q, Cin, Cin, M, grads + wgrad_off, Cin, 0, 0};
+      PGemmTnArgs ta{(const bf16_t*)(ws + dz), Cout, Cout, (const bf16_t*)q, Cin, Cin, M, grads + wgrad_off, Cin, 0, 0, rowtiles, listed ? p->n_rowtiles : 0};
       ProfScope ps(p, TN_PROF_BWD_WGRAD, st);
       return launch_pgemm_tn(ta, st);
     }

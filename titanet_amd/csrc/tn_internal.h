@@ -158,6 +158,12 @@ struct tn_plan {
   // with the backward zero region; se_acc: [B][parts][hidden] partial sums, reused block after block)
   int tail_parts = 1;
   size_t se_acc = 0, dgate_acc = 0;
+  // variable-length batches on the pipelined GEMMs: the 256-row tiles holding at least one valid frame (int32 list in the
+  // workspace, rewritten with every set of lengths), their count and the rows they cover; skip_pad_tiles: the plan's kernels
+  // all tolerate stale values in rows of skipped tiles (wide bf16 plans on the slab depthwise kernels)
+  size_t rowtiles = 0;
+  int n_rowtiles = 0, active_rows = 0;
+  bool skip_pad_tiles = false;
   std::vector<int> lens_host;
   bool masked = false;                  // the last forward carried lengths
   int n_valid = 0;                      // sum of the lengths (rows that enter the [B*T]-row BatchNorm statistics)

@@ -58,6 +58,11 @@ __device__ __forceinline__ pg_i32x4_t pg_make_srd(const void* base, unsigned byt
 struct PGemmNtArgs {
   const bf16_t* A;   // [M][lda], K contiguous, used as stored
   int lda;
+  // variable-length batches: the 256-row tiles that hold at least one valid frame (ascending tile indices, device memory) or
+  // null = all of them.  Row tiles that are padding only are not computed at all — their output rows keep whatever they held:
+  // every consumer of this path masks or zero-weights padding rows
+  const int* rowtiles;
+  int n_rowtiles;
 };
 struct PGemmEpiArgs {
   bf16_t* Y;               // [M][ldy]
@@ -113,8 +118,10 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
   // ---- DMA side: instruction q of this wave fills LDS rows (q*8 + wave) * RPI + lane / CPR of both tiles
   const int dsub = lane / CPR;
   unsigned offA[NQ], offB[NQ];
+  const int* __restrict__ rowtiles = pa.rowtiles;
   auto dma_setup = [&](int tile) {
-    const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
+    const int mi = tile / tiles_n, nt = tile - mi * tiles_n;
+    const int mt = rowtiles ? tn_sload_i32(rowtiles, mi) : mi;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int p = (q * 8 + wave) * RPI + dsub;                    // LDS row of the tile
@@ -243,7 +250,8 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
     cstage = (cstage + 1) & (NSTAGE - 1);
     if (++ckt == KT) {
       // ---- epilogue of this tile, straight from the accumulators
-      const int mt_ = ctile / tiles_n, nt_ = ctile - mt_ * tiles_n;
+      const int mi_ = ctile / tiles_n, nt_ = ctile - mi_ * tiles_n;
+      const int mt_ = rowtiles ? tn_sload_i32(rowtiles, mi_) : mi_;
       const int ncol = nt_ * 256 + wn * 64 + 2 * fi;               // this lane's channel pair
       const bool cols_ok = nt_ * 256 + wn * 64 < g.N;                 // wave-uniform (N is a multiple of 64)
       const bool full_rows = mt_ * 256 + 256 <= g.M;
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
         if (ea.stats) {
           s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64);
           q0 += __shfl_xor(q0, 32, 64); q1 += __shfl_xor(q1, 32, 64);
-          if (mt_ == 0 && wm == 0 && ea.pad_rows != 0.f) {       // once per column: one wave of the first row tile carries the correction
+          if (mi_ == 0 && wm == 0 && ea.pad_rows != 0.f) {       // once per column: one wave of the first row tile carries the correction
             s0 = fmaf(-ea.pad_rows, bv[0], s0); s1 = fmaf(-ea.pad_rows, bv[1], s1);
             q0 = fmaf(-ea.pad_rows * bv[0], bv[0], q0); q1 = fmaf(-ea.pad_rows * bv[1], bv[1], q1);
           }
@@ -301,7 +309,8 @@ template <int DBG = 0, bool F8 = false>
 inline int launch_pgemm_nt_t(const GemmShape& g, const PGemmNtArgs& pa, const PGemmEpiArgs& ea, hipStream_t st, int max_wgs, bool even_rounds = true) {
   if (g.K % (F8 ? 64 : 32) || g.K <= 0 || pa.lda % (F8 ? 16 : 8) || g.N % 64 || g.N > 3072 || ea.ldy % 2 || g.M <= 0) return TN_E_UNSUPPORTED;
   if ((long)g.M * pa.lda >= (1L << 32) || (long)g.N * g.K >= (1L << 32) || (long)g.M * ea.ldy * 2 >= (1L << 32)) return TN_E_UNSUPPORTED;
-  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256, total = tiles_m * tiles_n;
+  const int tiles_m = pa.rowtiles ? pa.n_rowtiles : (g.M + 255) / 256, tiles_n = (g.N + 255) / 256, total = tiles_m * tiles_n;
+  if (total <= 0) return 0;
   // persistent workgroups with the same number of tiles each (1200 tiles: 240 x 5 beats 256 x 4.7, the last round of which
   // runs at 69 % occupancy: 201 vs 209 us), a multiple of 8 for the XCD-contiguous order
   int grid = total < max_wgs ? total : max_wgs;
@@ -356,6 +365,8 @@ struct PGemmTnArgs {
   int rows;
   float* out; int ldo;              // out[c][k] (+=), c < np, k < nq
   int splits, steps_per_split;      // row ranges: split s covers K steps [s * steps_per_split, ...)
+  const int* rowtiles;              // as PGemmNtArgs::rowtiles: the contraction then runs over the 8 K steps of each listed
+  int n_rowtiles;                   // 256-row tile only (P is zero on every padding row, so nothing is lost)
 };
 
 template <int DUMMY>
@@ -370,7 +381,8 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(PGemmTnArgs a) {
   const int tiles_q = a.nq / 256, units = (a.np / 256) * tiles_q;
   const int unit = v % units, split = v / units;
   const int tp = unit / tiles_q, tq = unit - tp * tiles_q;
-  const int nsteps_all = (a.rows + 31) / 32;
+  const int* __restrict__ rowtiles = a.rowtiles;
+  const int nsteps_all = rowtiles ? a.n_rowtiles * 8 : (a.rows + 31) / 32;
   const int s0 = split * a.steps_per_split;
   int nsteps = nsteps_all - s0;
   nsteps = nsteps < a.steps_per_split ? nsteps : a.steps_per_split;
@@ -379,21 +391,36 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(PGemmTnArgs a) {
   const pg_i32x4_t psrd = pg_make_srd(a.P, (unsigned)((size_t)a.rows * a.ldp * 2));
   const pg_i32x4_t qsrd = pg_make_srd(a.Q, (unsigned)((size_t)a.rows * a.ldq * 2));
   // DMA: instruction q of this wave fills tile rows (q*8 + wave)*2 + (lane >> 5), 16-byte chunk lane & 31 of that row
-  unsigned voffP[2], voffQ[2];
+  unsigned voffP[2], voffQ[2], baseP[2], baseQ[2];
+  // first row of K step s (an index into the compacted list of steps when only the listed row tiles are contracted)
+  auto step_row = [&](int s) { return rowtiles ? tn_sload_i32(rowtiles, s >> 3) * 256 + (s & 7) * 32 : s * 32; };
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int r = (q * 8 + wave) * 2 + (lane >> 5);
     const int chunk = (lane & 31) ^ ((r & 3) << 2);
-    voffP[q] = (unsigned)(((size_t)(s0 * 32 + r) * a.ldp + tp * 256 + chunk * 8) * 2);
-    voffQ[q] = (unsigned)(((size_t)(s0 * 32 + r) * a.ldq + tq * 256 + chunk * 8) * 2);
+    baseP[q] = (unsigned)(((size_t)r * a.ldp + tp * 256 + chunk * 8) * 2);
+    baseQ[q] = (unsigned)(((size_t)r * a.ldq + tq * 256 + chunk * 8) * 2);
+  }
+  {
+    const unsigned row0 = (unsigned)step_row(s0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { voffP[q] = baseP[q] + row0 * (unsigned)a.ldp * 2u; voffQ[q] = baseQ[q] + row0 * (unsigned)a.ldq * 2u; }
   }
   const unsigned stepP = 32u * (unsigned)a.ldp * 2u, stepQ = 32u * (unsigned)a.ldq * 2u;
-  int istage = 0;
+  int istage = 0, sreq = s0;          // K step the next DMA group requests
   auto dma_p = [&](int q) { pg_dma16_buf(voffP[q], psrd, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + istage * STAGE_B + (q * 8 + wave) * 1024))); };
   auto dma_q = [&](int q) { pg_dma16_buf(voffQ[q], qsrd, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + istage * STAGE_B + TILE_B + (q * 8 + wave) * 1024))); };
   auto advance_issue = [&]() {
+    ++sreq;
+    if (rowtiles && (sreq & 7) == 0) {
+      // next listed row tile (past the end of the list: beyond the tensor -> zeros by the bounds check)
+      const unsigned row0 = (sreq >> 3) < a.n_rowtiles ? (unsigned)step_row(sreq) : (unsigned)a.rows + 256u;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) { voffP[q] += stepP; voffQ[q] += stepQ; }      // past the last row: zeros (bounds check)
+      for (int q = 0; q < 2; ++q) { voffP[q] = baseP[q] + row0 * (unsigned)a.ldp * 2u; voffQ[q] = baseQ[q] + row0 * (unsigned)a.ldq * 2u; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { voffP[q] += stepP; voffQ[q] += stepQ; }      // past the last row: zeros (bounds check)
+    }
     istage = (istage + 1) & (NSTAGE - 1);
   };
   // fragments
@@ -459,10 +486,11 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(PGemmTnArgs a) {
 
 inline int launch_pgemm_tn(PGemmTnArgs a, hipStream_t st, int max_wgs = 256) {
   if (a.np % 256 || a.nq % 256 || a.np <= 0 || a.nq <= 0 || a.ldp % 8 || a.ldq % 8 || a.rows <= 0) return TN_E_UNSUPPORTED;
-  if ((long)a.rows * a.ldp * 2 >= (1L << 32) || (long)a.rows * a.ldq * 2 >= (1L << 32)) return TN_E_UNSUPPORTED;
+  if ((long)(a.rows + 512) * a.ldp * 2 >= (1L << 32) || (long)(a.rows + 512) * a.ldq * 2 >= (1L << 32)) return TN_E_UNSUPPORTED;
   const int units = (a.np / 256) * (a.nq / 256);
   if (units > max_wgs) return TN_E_UNSUPPORTED;
-  const int nsteps = (a.rows + 31) / 32;
+  const int nsteps = a.rowtiles ? a.n_rowtiles * 8 : (a.rows + 31) / 32;
+  if (nsteps <= 0) return 0;
   // 4 slabs (512 x 512 weights): every workgroup ends with 65536 atomics, and 64 row splits make that 16.7 M per layer — as
   // long as the K loop itself.  48 splits (192 workgroups): 75.7 vs 85.9 us at 76800 rows (tools/pgemm_tn_harness)
   if (units == 4 && max_wgs == 256) max_wgs = 192;

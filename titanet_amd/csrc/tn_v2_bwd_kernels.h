@@ -826,20 +826,26 @@ __global__ __launch_bounds__(512, 2) void dw_bwd_slab_kernel(DwBwdSlabArgs a) {
         ld_ch<CH>(Ds + (l0 + o + PADR) * V2_C + cl, Dc);
         ld_ch<CH>(Xs + (l0 + o + PADR) * V2_C + cl, Yc);
 #pragma unroll
-        for (int i = 0; i < CH; ++i) { dA[i] = 0.f; gb[i] += Dc[i]; Ac[i] = Yc[i]; }
+        for (int i = 0; i < CH; ++i) { dA[i] = 0.f; Ac[i] = Yc[i]; }
         act_c<(FL & 7), CH>(Ac, sc, sh, dkey, dthr, (uint32_t)gr, a.C, cb + cl);
         bool pad = false;
+        int Lb = a.T;                                // valid frames of this row's utterance
         if (len) {
-          pad = t >= tn_sload_i32(len, gr / a.T);
+          Lb = tn_sload_i32(len, gr / a.T);
+          pad = t >= Lb;
         }
         if (pad) {
+          // (dD of a padding row is zero where it was computed; row tiles that are padding only are skipped by the pipelined
+          //  data-gradient GEMM and hold stale values: never read them as data)
 #pragma unroll
-          for (int i = 0; i < CH; ++i) Ac[i] = 0.f;
+          for (int i = 0; i < CH; ++i) { Ac[i] = 0.f; Dc[i] = 0.f; }
         }
 #pragma unroll
+        for (int i = 0; i < CH; ++i) gb[i] += Dc[i];
+#pragma unroll
         for (int k = 0; k < KD; ++k) {
-          const int tb = t - k + PADR;               // frame of dD[gr - k + PADR]: inside this utterance?
-          if (tb >= 0 && tb < a.T) {
+          const int tb = t - k + PADR;               // frame of dD[gr - k + PADR]: inside this utterance (and a valid frame)?
+          if (tb >= 0 && tb < Lb) {
             float v[CH];
             ld_ch<CH>(Ds + (l0 + o + KD - 1 - k) * V2_C + cl, v);
 #pragma unroll

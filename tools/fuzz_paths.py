@@ -47,7 +47,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     worst = 0.0
     for i in range(n):
-        cfg = dict(B=int(rng.integers(3, 40)), T=int(rng.choice([33, 64, 65, 100, 151, 201, 300, 301, 417, 520, 700])),
+        cfg = dict(B=int(rng.integers(6, 40)), T=int(rng.choice([33, 64, 65, 100, 151, 201, 300, 301, 417, 520, 700])),
                    p=float(rng.choice([0.0, 0.1, 0.3])), head=str(rng.choice(["ce", "arc"])), blocks=int(rng.integers(1, 4)),
                    ncls=int(rng.integers(5, 60)), simple=bool(rng.random() < 0.2), train=bool(rng.random() < 0.8),
                    wseed=int(rng.integers(1 << 30)), xseed=int(rng.integers(1 << 30)),
