@@ -508,14 +508,12 @@ __global__ __launch_bounds__(512) void combine_bwd1_kernel(const AT* __restrict_
     for (int t0 = t_lo + tg; t0 < t_hi; t0 += TG * U) {
       float d[U][8], y[U][8], sv[U][8];
 #pragma unroll
-      for (int q = 0; q < U; ++q) {
-        const int t = t0 + q * TG;
-        if (t < t_hi) {
-          const size_t o = ((size_t)b * T + t) * C + c0;
-          load8(dOUT + o, d[q]);
-          load8(Y3 + o, y[q]);
-          load8(S + o, sv[q]);
-        }
+      for (int q = 0; q < U; ++q) {                  // (branch-free loads, see combine_bwd2_kernel)
+        const int t = min(t0 + q * TG, t_hi - 1);
+        const size_t o = ((size_t)b * T + t) * C + c0;
+        load8(dOUT + o, d[q]);
+        load8(Y3 + o, y[q]);
+        load8(S + o, sv[q]);
       }
 #pragma unroll
       for (int q = 0; q < U; ++q) {
@@ -642,31 +640,30 @@ __global__ __launch_bounds__(512) void combine_bwd2_kernel(const AT* __restrict_
     constexpr int U = 4;
     for (int t0 = t_lo + tg; t0 < t_hi; t0 += TG * U) {
       float d[U][8], y[U][8];
+      // (branch-free loads: rows past the end are clamped to the last one and weighted zero — predicated loads compile to one
+      //  exec-masked block with its own wait per row)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int t = t0 + u * TG;
-        if (t < t_hi) {
-          const size_t o = ((size_t)b * T + t) * C + c0;
-          load8(dZ + o, d[u]);
-          load8(Y3 + o, y[u]);
-        }
+        const int t = min(t0 + u * TG, t_hi - 1);
+        const size_t o = ((size_t)b * T + t) * C + c0;
+        load8(dZ + o, d[u]);
+        load8(Y3 + o, y[u]);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int t = t0 + u * TG;
-        if (t < t_hi) {
-          const uint32_t row = (uint32_t)b * T + t;
-          float m[8];
-          act8_grad_mask(y[u], m, sc3 + c0, sh3 + c0, act3, row, C, c0);
+        const bool live = t < t_hi;
+        const uint32_t row = (uint32_t)b * T + min(t, t_hi - 1);
+        float m[8];
+        act8_grad_mask(y[u], m, sc3 + c0, sh3 + c0, act3, row, C, c0);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float v = (d[u][i] * g8[i] + dm8[i]) * m[i];
-            d[u][i] = v;
-            s1[i] += v;
-            s2[i] += v * (y[u][i] - m8[i]) * r8[i];
-          }
-          store8(dYbn + (size_t)row * C + c0, d[u]);
+        for (int i = 0; i < 8; ++i) {
+          const float v = live ? (d[u][i] * g8[i] + dm8[i]) * m[i] : 0.f;
+          d[u][i] = v;
+          s1[i] += v;
+          s2[i] += v * (y[u][i] - m8[i]) * r8[i];
         }
+        if (live) store8(dYbn + (size_t)row * C + c0, d[u]);
       }
     }
     {
