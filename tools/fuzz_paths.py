@@ -42,10 +42,10 @@ def run(mask, cfg):
     return emb.float().cpu(), 0.0, None
 
 
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    worst = 0.0
+def main(n=None, seed=None):
+    n = n if n is not None else (int(sys.argv[1]) if len(sys.argv) > 1 else 24)
+    rng = np.random.default_rng(seed if seed is not None else (int(sys.argv[2]) if len(sys.argv) > 2 else 0))
+    worst, failed = 0.0, []
     for i in range(n):
         cfg = dict(B=int(rng.integers(6, 40)), T=int(rng.choice([33, 64, 65, 100, 151, 201, 300, 301, 417, 520, 700])),
                    p=float(rng.choice([0.0, 0.1, 0.3])), head=str(rng.choice(["ce", "arc"])), blocks=int(rng.integers(1, 4)),
@@ -70,7 +70,10 @@ def main():
             ok = ok and abs(l1 - l0) < 5e-2 * max(1.0, abs(l0)) and cos > ((0.95 if f8 else 0.97) if cfg["B"] * cfg["T"] >= 1500 else 0.9)
         worst = max(worst, er)
         print(("ok  " if ok else "FAIL") + msg, flush=True)
+        if not ok:
+            failed.append(msg)
     print("worst emb rel", worst)
+    return failed
 
 
 if __name__ == "__main__":
