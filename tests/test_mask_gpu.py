@@ -119,3 +119,24 @@ def test_bad_lengths_are_rejected():
         m(x.cuda(), lengths=torch.tensor([0, 5, 5, 5]))
     with pytest.raises(ValueError):
         m(x.cuda(), lengths=torch.tensor([5, 5, 5, x.shape[2] + 1]))
+
+
+def test_more_than_512_utterances_per_batch():
+    """The valid-frame counts travel to the device as kernel arguments in chunks of 512 (lens_write_kernel): a padded batch of 600
+    utterances gives utterances on both sides of the chunk boundary the embedding they have on their own."""
+    from titanet_amd import TitaNet
+    torch.manual_seed(3)
+    m = TitaNet.get_titanet(n_mega_blocks=1, model_size="s", device="cuda", precision="bf16").eval()
+    B, T = 600, 96
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(B, 80, T, generator=g) * 0.11 - 0.1)
+    lengths = torch.randint(20, T + 1, (B,), generator=g)
+    lengths[0] = T
+    for b in range(B):
+        x[b, :, lengths[b]:] = 0
+    x = x.cuda()
+    with torch.no_grad():
+        full = m(x, lengths=lengths).clone()
+        for b in (3, 511, 512, 513, 599):
+            alone = m(x[b:b + 1, :, :int(lengths[b])].contiguous())
+            assert rel_err(full[b:b + 1].cpu().numpy(), alone.cpu().numpy()) < 2e-2, (b, int(lengths[b]))
