@@ -497,6 +497,33 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(const AT* __restrict__
   const int CV = C / 8;
   const int r_begin = blockIdx.x * rows_per_block;
   const int r_end = min(M, r_begin + rows_per_block);
+  const uint32_t okey = key_add ? drop_key + *key_add : drop_key;
+  if (NT % CV == 0) {
+    // a thread keeps ONE 8-channel vector: its four BatchNorm constants live in registers (read from LDS per element they cost
+    // 85 % bank-conflict cycles and a third of the wave time in LDS waits, profiles/r03_m10_sq_counters.json), no index division
+    const int c0 = (tid % CV) * 8, rstep = NT / CV;
+    float kS[8], hS[8], k3[8], h3[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { kS[q] = scS[c0 + q]; hS[q] = shS[c0 + q]; k3[q] = sc3[c0 + q]; h3[q] = sh3[c0 + q]; }
+    for (int row = r_begin + tid / CV; row < r_end; row += rstep) {
+      const int b = row / T;
+      float s[8], y[8], g[8], o[8];
+      load8(S + (size_t)row * C + c0, s);
+      load8(Y3 + (size_t)row * C + c0, y);
+      load8(gate + (size_t)b * C + c0, g);
+      act8(y, k3, h3, act3, (uint32_t)row, C, c0);
+      const bool pad = MK && !tn_row_valid(act3.rm, (uint32_t)row);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = pad ? 0.f : fmaxf(s[q] * kS[q] + hS[q] + g[q] * y[q], 0.f);
+      if (drop_thr) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] *= inv_keep;
+        tn_drop8(o, ((uint32_t)row * (uint32_t)C + (uint32_t)c0) >> 3, okey, drop_thr);
+      }
+      store8(OUT + (size_t)row * C + c0, o);
+    }
+    return;
+  }
   for (int i = tid; i < (r_end - r_begin) * CV; i += NT) {
     const int row = r_begin + i / CV, c0 = (i % CV) * 8;
     const int b = row / T;
@@ -511,7 +538,7 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(const AT* __restrict__
     if (drop_thr) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) o[q] *= inv_keep;
-      tn_drop8(o, ((uint32_t)row * (uint32_t)C + (uint32_t)c0) >> 3, key_add ? drop_key + *key_add : drop_key, drop_thr);
+      tn_drop8(o, ((uint32_t)row * (uint32_t)C + (uint32_t)c0) >> 3, okey, drop_thr);
     }
     store8(OUT + (size_t)row * C + c0, o);
   }
