@@ -634,9 +634,11 @@ __global__ __launch_bounds__(512) void combine_bwd2_kernel(const AT* __restrict_
     for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
     // the thread's 8 channels are fixed: their constants live in registers (they were 32 scalar LDS reads per row), and 4
     // rows of both streams are in flight per thread (one workgroup per utterance: one row at a time is a round trip per row)
-    float g8[8], dm8[8], m8[8], r8[8];
+    float g8[8], dm8[8], m8[8], r8[8], k38[8], h38[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { g8[i] = gS[c0 + i]; dm8[i] = dmT[c0 + i]; m8[i] = m3[c0 + i]; r8[i] = r3[c0 + i]; }
+    for (int i = 0; i < 8; ++i) {
+      g8[i] = gS[c0 + i]; dm8[i] = dmT[c0 + i]; m8[i] = m3[c0 + i]; r8[i] = r3[c0 + i]; k38[i] = sc3[c0 + i]; h38[i] = sh3[c0 + i];
+    }
     constexpr int U = 4;
     for (int t0 = t_lo + tg; t0 < t_hi; t0 += TG * U) {
       float d[U][8], y[U][8];
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(512) void combine_bwd2_kernel(const AT* __restrict_
         const bool live = t < t_hi;
         const uint32_t row = (uint32_t)b * T + min(t, t_hi - 1);
         float m[8];
-        act8_grad_mask(y[u], m, sc3 + c0, sh3 + c0, act3, row, C, c0);
+        act8_grad_mask(y[u], m, k38, h38, act3, row, C, c0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float v = live ? (d[u][i] * g8[i] + dm8[i]) * m[i] : 0.f;

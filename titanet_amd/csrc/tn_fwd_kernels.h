@@ -416,6 +416,9 @@ __global__ __launch_bounds__(512) void se_squeeze_fc_kernel(const AT* __restrict
     // row, 116 us for the 157 MB of a TitaNet-L tensor).  Branch-free: rows past the end are CLAMPED to the last one and
     // added with weight zero — predicated loads compiled to one exec-masked block (with its own wait) per row, 2 TB/s
     constexpr int U = 6;
+    float kr[8], hr[8];                          // the thread's BatchNorm constants in registers (LDS reads per element: bank conflicts)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { kr[i] = act.mode != 0 ? sc[vc * 8 + i] : 1.f; hr[i] = act.mode != 0 ? sh[vc * 8 + i] : 0.f; }
     for (int t0 = t_lo + tg; t0 < t_hi; t0 += TG * U) {
       float v[U][8];
 #pragma unroll
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(512) void se_squeeze_fc_kernel(const AT* __restrict
       for (int u = 0; u < U; ++u) {
         const int t = t0 + u * TG;
         const uint32_t row = (uint32_t)b * T + min(t, t_hi - 1);
-        act8(v[u], sc + vc * 8, sh + vc * 8, act, row, C, vc * 8);
+        act8(v[u], kr, hr, act, row, C, vc * 8);
 #pragma unroll
         for (int i = 0; i < 8; ++i) s[i] += (t < t_hi) ? v[u][i] : 0.f;
       }
