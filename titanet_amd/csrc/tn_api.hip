@@ -318,7 +318,8 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     p->wg2_asp_units = (p->wg2_epi_slabs > 0 && p->use_v2 && H == 256 && A == 128 && !c.simple_pool) ? 2 * (int)(D / 256) : 0;
     p->wg2_layers += p->wg2_asp_units;
     p->wg2_grid = 256;
-    p->wg2_desc = b.take((size_t)p->wg2_layers * 256);   // >= sizeof(WgradV2Desc) each (checked at upload)
+    p->wg2_desc = b.take((size_t)2 * p->wg2_layers * 256);   // two tables, >= sizeof(WgradV2Desc) per unit (checked at upload)
+    p->se_gu = b.take((size_t)batch * 2 * 256 * sizeof(float));
     p->wg2_out = b.take((size_t)p->wg2_layers * 32);
     p->dw_table = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * 32);
   }
@@ -730,7 +731,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
                           params + sb.bpw, (bf16_t*)(ws + bw.Y[j]), statp(sb.bn), M, T, 0,
                           bw.wpw[j].sw ? (const uint4*)(ws + bw.wpw[j].sw) : nullptr,
                           (p->save_q && training) ? (bf16_t*)(ws + bw.Q[j]) : nullptr};
-          rc = launch_sub_fwd_v5<3, true>(va, 256, st);
+          rc = launch_sub_fwd_v5<3, true, 32>(va, 256, st);
           if (rc == 0) pad_fixup(statp(sb.bn), params + sb.bpw, H);
           if (rc == -1000) rc = gemm_store<AT, ProdDw>(g, pa, ea, c.kernel, st);
         } else if (p->split_dw && p->save_q) {

@@ -131,6 +131,11 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   // (a row mask on an otherwise plain operand is moot here: its partner dS is zero on the padding rows)
   auto is_plain = [](const BnAct& a) { return a.mode == 0 && !a.relu && !a.drop_thr; };
   const bool v2_bwd = sizeof(AT) == 2 && use_v2;
+  // round 4: the mega-block tail backward in ONE pass (combine_bwd1_v3 finishes the SE backward per utterance; the last
+  // sub-block's fused data-gradient kernel rebuilds its incoming gradient on load and stores the BatchNorm-backward'd dS for
+  // the weight-gradient launch): fixed-length training batches of the headline shape
+  const bool fuse_tail = v2_bwd && batched_wgrad && H == V2_C && Hr == 16 && c.kernel == 3 && nsub >= 2 && !p->masked &&
+                         p->tail_parts == 1 && p->se_gu != 0;
   const int nb = c.n_mega_blocks;
   const int per_blk = nsub + 1;
   int rc_fin = 0;
@@ -178,7 +183,8 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         }
         {
           ProfScope ps(p, TN_PROF_BWD_WGRAD, st);
-          hipLaunchKernelGGL(kern, dim3(p->wg2_grid), dim3(V2_NT), smem, st, (const WgradV2Desc*)(ws + p->wg2_desc) + first, count, M, T,
+          hipLaunchKernelGGL(kern, dim3(p->wg2_grid), dim3(V2_NT), smem, st,
+                             (const WgradV2Desc*)(ws + p->wg2_desc) + (fuse_tail ? p->wg2_layers : 0) + first, count, M, T,
                              chunks, upw, (int*)(ws + p->wg2_count) + first, seed, 1.f / (float)(p->masked ? std::max(p->n_valid, 1) : M));
         }
         hipLaunchKernelGGL(wgrad_v2_reduce_kernel, dim3(32, count), dim3(256), 0, st, (const WgradV2Out*)(ws + p->wg2_out) + first,
@@ -381,6 +387,20 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       }
       int rc1 = -1000;
       float* dgate_out = (float*)(ws + ((v2_bwd && Hr == 16) ? bw.dgate : bw.dpre2));
+      if (fuse_tail) {
+        CombineBwd1V3Args c3;
+        memset(&c3, 0, sizeof(c3));
+        CombineBwd1V2Args& c1 = c3.a1;
+        c1.dOUT = (const bf16_t*)(ws + p->dA[cur]); c1.gate = (const float*)(ws + bw.g); c1.Y3 = (const bf16_t*)(ws + bw.Y[nsub - 1]);
+        c1.act3 = act3; c1.S = (const bf16_t*)(ws + bw.S); c1.actS = acts; c1.dZ = (bf16_t*)(ws + bw.dZk);
+        c1.bsumsS = bsum(mb.bnskip); c1.T = T; c1.parts = 1; c1.inv_keep = inv_keep; c1.drop_thr = othr; c1.drop_key = okey;
+        c1.key_add = (const uint32_t*)(ws + p->step_state) + 2;
+        c3.hid = (const float*)(ws + bw.h); c3.W1 = params + mb.se_w1; c3.W2 = params + mb.se_w2;
+        c3.dpre2 = (float*)(ws + bw.dpre2); c3.dpre1 = (float*)(ws + bw.dpre1); c3.gu = (float*)(ws + p->se_gu);
+        c3.bsums3 = bsum(mb.sub[nsub - 1].bn);
+        const int rc = launch_combine_bwd1_v3(c3, B, st);
+        if (rc) return rc == -1000 ? TN_E_UNSUPPORTED : rc;
+      } else {
       if (sizeof(AT) == 2 && v2_bwd && H == V2_C) {
         CombineBwd1V2Args c1;
         memset(&c1, 0, sizeof(c1));
@@ -425,6 +445,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
                            (const float*)(ws + bw.g), (const float*)(ws + bw.h), split ? (const float*)dgate_acc : (const float*)(ws + bw.dpre2),
                            (float*)(ws + bw.dpre2), (float*)(ws + bw.dpre1),
                            params + mb.se_w1, params + mb.se_w2, T, H, Hr, (AT*)(ws + bw.dY[nsub - 1]), bsum(mb.sub[nsub - 1].bn));
+      }
       }
     }
     DBG("block dOUT", p->dA[cur], (size_t)M * H); DBG("combine dZk", bw.dZk, (size_t)M * H); DBG("combine dY3", bw.dY[nsub - 1], (size_t)M * H);
@@ -482,6 +503,12 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         fa.Wswz = bw.wpw[j].swt ? (const uint4*)(ws + bw.wpw[j].swt) : nullptr;
         fa.X = (const bf16_t*)sin; fa.actX = asin; fa.wdw = params + sb.wdw; fa.M = M; fa.T = T;
         fa.gacc = (float*)(ws + p->dw_gacc) + (size_t)(i * nsub + j) * TN_NREP * (c.kernel + 1) * H;
+        if (fuse_tail && j == nsub - 1) {
+          // the incoming gradient is rebuilt from the tail's dZ; dS goes where dY[j] would have been (the weight-gradient unit
+          // of this layer reads it as a plain operand: second descriptor table)
+          fa.dZ = (const bf16_t*)(ws + bw.dZk); fa.gu = (const float*)(ws + p->se_gu); fa.act3 = act3;
+          fa.dS_out = (bf16_t*)(ws + bw.dY[j]);
+        }
         if (j > 0) {
           fa.ADD = nullptr; fa.OUT = (bf16_t*)(ws + bw.dY[j - 1]); fa.bsumsX = bsum(mb.sub[j - 1].bn);
         } else {
@@ -696,6 +723,17 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
       if (d.actX.drop_thr || d.wdw) return TN_E_STATE;      // the launch has no dropout-hashing / depthwise-recompute variant
     if (sizeof(WgradV2Desc) > 256 || sizeof(WgradV2Out) > 32) return TN_E_STATE;
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_desc, wd.data(), wd.size() * sizeof(WgradV2Desc), hipMemcpyHostToDevice, st));
+    // second table: the fused-tail flow of backward_impl — the last sub-block's gradient buffer then holds the
+    // BatchNorm-backward'd dS itself (stored by dgrad_dw_v6<.., Z3>): a plain P operand
+    if (hs == 1 && nsub >= 2) {
+      std::vector<WgradV2Desc> wd2 = wd;
+      for (int i = 0; i < c.n_mega_blocks; ++i) {
+        WgradV2Desc& d = wd2[(size_t)i * (nsub + 1) + 1 + (nsub - 1)];
+        d.Y = nullptr; d.fstats = nullptr; d.bsums = nullptr;
+      }
+      TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_desc + (size_t)p->wg2_layers * sizeof(WgradV2Desc), wd2.data(),
+                                  wd2.size() * sizeof(WgradV2Desc), hipMemcpyHostToDevice, st));
+    }
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_out, wo.data(), wo.size() * sizeof(WgradV2Out), hipMemcpyHostToDevice, st));
     std::vector<DwGradOut> dg;
     for (int i = 0; i < c.n_mega_blocks; ++i)

@@ -223,6 +223,9 @@ __global__ __launch_bounds__(V2_NT, 2) void wgrad_batched_v2_kernel(const WgradV
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vc = tid & 31, rq = tid >> 5, c0 = vc * 8;
   const int wa = wave >> 2, wb = wave & 3;
+  // (partition by units, not bytes: a unit whose P operand is a stored tensor reads two tensors per chunk instead of three,
+  //  but a workgroup's time per chunk does not shrink with it — weighting the ranges by bytes made the launch 30 % slower,
+  //  round 4 — so every chunk counts the same)
   const int total_units = n_layers * chunks_per_layer;
   int unit = blockIdx.x * units_per_wg;
   const int unit_end = min(total_units, unit + units_per_wg);
@@ -462,6 +465,188 @@ inline int launch_combine_bwd1_v2(const CombineBwd1V2Args& a, int B, hipStream_t
   const dim3 grid(B * a.parts), blk(512);
   if (fl3 == 7 && a.drop_thr) hipLaunchKernelGGL((combine_bwd1_v2_kernel<7, true>), grid, blk, 0, st, a);
   else if (fl3 == 3 && !a.drop_thr) hipLaunchKernelGGL((combine_bwd1_v2_kernel<3, false>), grid, blk, 0, st, a);
+  else return -1000;
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// combine_bwd1_v3 (round 4): pass 1 of the mega-block tail backward that makes pass 2 unnecessary.
+//
+// Pass 2 (combine_bwd2_v2) existed to materialise  dY3bn[b,t,c] = (dZ[b,t,c] g[b,c] + dmean[b,c] / T) m3[b,t,c]  (m3 = d act3 /
+// d bn3: ReLU sign, dropout keep, 1/(1-p)) and to take its BatchNorm-backward sums: 3 tensor passes per mega block.  But dY3bn
+// is a function of dZ (written here), Y3 (read by every consumer anyway) and two numbers per (utterance, channel), and its
+// sums over the rows are linear in four per-(utterance, channel) sums that THIS pass can take while it holds dZ and Y3:
+//   B1 = sum_t m z,  B2 = sum_t m z y,  B3 = sum_t m,  B4 = sum_t m y      (m = [act3(y) > 0], y raw)
+//   dgate = sc3 B2 + sh3 B1;   sum_t dY3bn = ga B1 + ub B3;   sum_t dY3bn y = ga B2 + ub B4     (ga = g/(1-p), ub = dmean/T/(1-p))
+// So the workgroup of an utterance finishes the SE backward (reference src/modules.py:182-189) itself, publishes ga / ub
+// ([B][2][256] floats) and adds the utterance's share to the BatchNorm-backward sums of sub-block 3; the sub-block's fused
+// data-gradient kernel (dgrad_dw_v6<.., Z3>) rebuilds dY3bn on load from dZ, Y3, ga, ub.  One workgroup per utterance.
+// ------------------------------------------------------------------------------------------
+struct CombineBwd1V3Args {
+  CombineBwd1V2Args a1;      // (dgate unused, parts == 1)
+  const float* hid;          // [B][16] SE hidden layer (forward)
+  const float* W1;           // [16][256]
+  const float* W2;           // [256][16]
+  float* dpre2; float* dpre1;
+  float* gu;                 // [B][2][256]: ga, ub
+  float* bsums3;
+};
+template <int FL3, bool DROP>
+__global__ __launch_bounds__(512) void combine_bwd1_v3_kernel(CombineBwd1V3Args aa) {
+  constexpr int HR = 16;
+  const CombineBwd1V2Args& a = aa.a1;
+  __shared__ float cst[8 * V2_C];        // sc3, sh3, scS, shS, meanS, rstdS, mean3*rstd3, rstd3
+  __shared__ float part[8][6][V2_C];     // per wave: B1..B4, skip sums
+  __shared__ float p2[V2_C], p1[HR];
+  const int tid = threadIdx.x, vc = tid & 31, tg = tid >> 5, c0 = vc * 8;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  if (tid < V2_C) {
+    float s = 1.f, h = 0.f, ss, hs, ms, rs, m3 = 0.f, r3 = 1.f;
+    if (FL3 & 1) { bn_scale_shift(a.act3, V2_C, tid, s, h); bn_mean_rstd(a.act3, V2_C, tid, m3, r3); }
+    bn_scale_shift(a.actS, V2_C, tid, ss, hs);
+    bn_mean_rstd(a.actS, V2_C, tid, ms, rs);
+    cst[tid] = s; cst[V2_C + tid] = h; cst[2 * V2_C + tid] = ss; cst[3 * V2_C + tid] = hs; cst[4 * V2_C + tid] = ms; cst[5 * V2_C + tid] = rs;
+    cst[6 * V2_C + tid] = m3 * r3; cst[7 * V2_C + tid] = r3;
+  }
+  __syncthreads();
+  float k3[8], h3[8], kS[8], hS[8], m8[8], r8[8], g8[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    k3[i] = cst[c0 + i]; h3[i] = cst[V2_C + c0 + i]; kS[i] = cst[2 * V2_C + c0 + i]; hS[i] = cst[3 * V2_C + c0 + i];
+    m8[i] = cst[4 * V2_C + c0 + i]; r8[i] = cst[5 * V2_C + c0 + i]; g8[i] = a.gate[(size_t)b * V2_C + c0 + i];
+  }
+  const uint32_t dkey3 = tn_act_key(a.act3), dthr3 = a.act3.drop_thr;
+  const uint32_t okey = a.key_add ? a.drop_key + *a.key_add : a.drop_key;
+  // operands of the SE backward at the end (they do not depend on the row loop): requested now, so that the serial tail of
+  // the workgroup — every workgroup reaches it at the same time — does not wait for three dependent global round trips
+  float w2r[2][4], hidr[2], w1r[HR];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int j = wave + 8 * jj;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w2r[jj][k] = aa.W2[(size_t)(lane + 64 * k) * HR + j];
+    hidr[jj] = aa.hid[(size_t)b * HR + j];
+  }
+#pragma unroll
+  for (int j = 0; j < HR; ++j) w1r[j] = aa.W1[(size_t)j * V2_C + (tid & 255)];
+  float b1[8], b2[8], b3[8], b4[8], s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { b1[i] = 0.f; b2[i] = 0.f; b3[i] = 0.f; b4[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
+  constexpr int U = 4;
+  for (int tb = tg; tb < a.T; tb += 16 * U) {
+    uint4 rd[U], ry[U], rs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = tb + 16 * u;
+      if (t < a.T) {
+        const size_t o = ((size_t)b * a.T + t) * V2_C + c0;
+        rd[u] = *reinterpret_cast<const uint4*>(a.dOUT + o);
+        ry[u] = *reinterpret_cast<const uint4*>(a.Y3 + o);
+        rs[u] = *reinterpret_cast<const uint4*>(a.S + o);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = tb + 16 * u;
+      if (t < a.T) {
+        const uint32_t row = (uint32_t)b * a.T + t;
+        float d[8], y[8], ya[8], sv[8], m[8];
+        unpack8(rd[u], d);
+        unpack8(ry[u], y);
+        unpack8(rs[u], sv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ya[i] = y[i];
+        act8_t<FL3>(ya, k3, h3, dkey3, dthr3, row, c0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m[i] = (fmaf(sv[i], kS[i], fmaf(g8[i], ya[i], hS[i])) > 0.f) ? a.inv_keep : 0.f;
+        if (DROP) tn_drop8(m, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, okey, a.drop_thr);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float z = d[i] * m[i];
+          d[i] = z;
+          s1[i] += z;
+          s2[i] = fmaf(z, (sv[i] - m8[i]) * r8[i], s2[i]);
+          const bool on3 = ya[i] > 0.f;              // ReLU passed and the element was kept (sc3 / sh3 carry 1/(1-p) > 0)
+          const float zm = on3 ? z : 0.f, ym = on3 ? y[i] : 0.f;
+          b1[i] += zm;
+          b2[i] = fmaf(zm, y[i], b2[i]);
+          b3[i] += on3 ? 1.f : 0.f;
+          b4[i] += ym;
+        }
+        store8(a.dZ + (size_t)row * V2_C + c0, d);
+      }
+    }
+  }
+  // the two row groups of a wave (lanes l, l ^ 32) first, then the 8 waves through LDS
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    b1[i] += __shfl_xor(b1[i], 32, 64); b2[i] += __shfl_xor(b2[i], 32, 64); b3[i] += __shfl_xor(b3[i], 32, 64);
+    b4[i] += __shfl_xor(b4[i], 32, 64); s1[i] += __shfl_xor(s1[i], 32, 64); s2[i] += __shfl_xor(s2[i], 32, 64);
+  }
+  if (lane < 32) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      part[wave][0][c0 + i] = b1[i]; part[wave][1][c0 + i] = b2[i]; part[wave][2][c0 + i] = b3[i];
+      part[wave][3][c0 + i] = b4[i]; part[wave][4][c0 + i] = s1[i]; part[wave][5][c0 + i] = s2[i];
+    }
+  }
+  __syncthreads();
+  const int rep = blockIdx.x % TN_NREP;
+  float B1 = 0.f, B2 = 0.f, B3 = 0.f, B4 = 0.f, g = 0.f;
+  if (tid < V2_C) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { B1 += part[k][0][tid]; B2 += part[k][1][tid]; B3 += part[k][2][tid]; B4 += part[k][3][tid]; }
+    g = a.gate[(size_t)b * V2_C + tid];
+    const float dgate = fmaf(cst[tid], B2, cst[V2_C + tid] * B1);
+    const float d2 = dgate * g * (1.f - g);
+    p2[tid] = d2;
+    aa.dpre2[(size_t)b * V2_C + tid] = d2;
+  } else {
+    const int c = tid - V2_C;
+    float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v1 += part[k][4][c]; v2 += part[k][5][c]; }
+    atomic_add_f32(&a.bsumsS[(size_t)(rep * 2 + 0) * V2_C + c], v1);
+    atomic_add_f32(&a.bsumsS[(size_t)(rep * 2 + 1) * V2_C + c], v2);
+  }
+  __syncthreads();
+  // p1[j] = relu'(hid[j]) * sum_c W2[c][j] p2[c]  (2 outputs per wave)
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int j = wave + 8 * jj;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s = fmaf(w2r[jj][k], p2[lane + 64 * k], s);
+    s = wave_sum(s);
+    if (lane == 0) {
+      s = (hidr[jj] > 0.f) ? s : 0.f;
+      p1[j] = s;
+      aa.dpre1[(size_t)b * HR + j] = s;
+    }
+  }
+  __syncthreads();
+  if (tid < V2_C) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < HR; ++j) s = fmaf(w1r[j], p1[j], s);
+    const float on = (FL3 & 4) ? a.act3.inv_keep : 1.f;
+    const float ga = g * on, ub = s / (float)a.T * on;
+    aa.gu[((size_t)b * 2 + 0) * V2_C + tid] = ga;
+    aa.gu[((size_t)b * 2 + 1) * V2_C + tid] = ub;
+    const float sv = fmaf(ga, B1, ub * B3), sy = fmaf(ga, B2, ub * B4);
+    atomic_add_f32(&aa.bsums3[(size_t)(rep * 2 + 0) * V2_C + tid], sv);
+    atomic_add_f32(&aa.bsums3[(size_t)(rep * 2 + 1) * V2_C + tid], cst[7 * V2_C + tid] * sy - cst[6 * V2_C + tid] * sv);
+  }
+}
+// -1000: no specialisation for this flag combination
+inline int launch_combine_bwd1_v3(const CombineBwd1V3Args& aa, int B, hipStream_t st) {
+  const CombineBwd1V2Args& a = aa.a1;
+  const int fl3 = (a.act3.mode != 0 ? 1 : 0) | (a.act3.relu ? 2 : 0) | (a.act3.drop_thr ? 4 : 0);
+  if (a.act3.rm.len || a.parts != 1) return -1000;
+  const dim3 grid(B), blk(512);
+  if (fl3 == 7 && a.drop_thr) hipLaunchKernelGGL((combine_bwd1_v3_kernel<7, true>), grid, blk, 0, st, aa);
+  else if (fl3 == 3 && !a.drop_thr) hipLaunchKernelGGL((combine_bwd1_v3_kernel<3, false>), grid, blk, 0, st, aa);
   else return -1000;
   return (int)hipGetLastError();
 }
@@ -1077,19 +1262,29 @@ struct DgradDwArgs {
   float* gacc;                                         // [TN_NREP][KD + 1][256]
   float* bsumsX;                                       // or null
   int M, T, ntiles;
+  // Z3 variants (the LAST sub-block of a mega block, round 4): dZ holds the gradient wrt the block's pre-activation sum (what
+  // combine_bwd1_v3 wrote), and the gradient wrt this sub-block's BatchNorm output is rebuilt on load,
+  //   dYbn = (dZ * ga[b][c] + ub[b][c]) * [act3(Y) > 0],
+  // instead of being read from a tensor a second tail pass would have had to write (3 tensor passes per mega block less).
+  const float* gu;                                     // [B][2][256]: ga, ub (combine_bwd1_v3), or null
+  BnAct act3;                                          // activation of this sub-block's output (BatchNorm, ReLU, dropout)
+  bf16_t* dS_out;                                      // the BatchNorm-backward'd gradient is also stored (rows x 256): the
+                                                       // weight-gradient launch then reads it as a plain operand
 };
 
 // MK (variable-length batch, a.bn.rm.len): dS = 0 on padding rows (their dD then adds nothing to the valid rows next to them),
 // padding rows of X read as zeros (no tap-weight gradient through them), the data gradient is written as zero there.
-template <int FL, bool MK = false>
+template <int FL, bool MK = false, bool Z3 = false>
 __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
+  static_assert(!(Z3 && MK), "the rebuilt-gradient variant has no variable-length form");
   constexpr int KD = 3, NT = V2_NT;
   constexpr bool HAS_MASK = (FL & 7) != 0, HAS_ADD = (FL & 8) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* Pt = reinterpret_cast<bf16_t*>(smem);          // [32][264] BN-backward'd dY rows (MFMA B operand)
   bf16_t* Dt = Pt + V6_R * V2_AP;                         // [32][264] dD rows
   bf16_t* Xs = Dt + V6_R * V2_AP;                         // [32][256] raw X rows
-  float* cst = reinterpret_cast<float*>(Xs + V6_R * V2_C);   // k0,k1,k2, sc,sh,mean*rstd,rstd, wd[3] : [10][256]
+  float* cst = reinterpret_cast<float*>(Xs + V6_R * V2_C);   // k0,k1,k2, sc,sh,mean*rstd,rstd, wd[3] : [10][256] (+ sc3, sh3 with Z3)
+  float* gus = cst + 12 * V2_C;                               // Z3: ga, ub of the tile's two utterances [2][2][256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int vc = tid & 31, rq = tid >> 5, c0 = vc * 8;   // transform layout: 8 channels x rows rq, rq + 16
   const int c4 = lane * 4;                               // stencil layout: 4 channels per lane, one wave per strip of 4 rows
@@ -1103,7 +1298,24 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
     cst[3 * V2_C + tid] = s; cst[4 * V2_C + tid] = h; cst[5 * V2_C + tid] = mean * rstd; cst[6 * V2_C + tid] = rstd;
 #pragma unroll
     for (int k = 0; k < KD; ++k) cst[(7 + k) * V2_C + tid] = a.wdw[(size_t)tid * KD + k];
+    if (Z3) {
+      float s3 = 1.f, h3 = 0.f;
+      bn_scale_shift(a.act3, V2_C, tid, s3, h3);
+      cst[10 * V2_C + tid] = s3; cst[11 * V2_C + tid] = h3;
+    }
   }
+  const uint32_t dkey3 = Z3 ? tn_act_key(a.act3) : 0u, dthr3 = Z3 ? a.act3.drop_thr : 0u;
+  // Z3: ga / ub of the (at most two) utterances a tile touches travel global -> register (one 8-byte load per thread, issued
+  // with the tile prefetch) -> LDS (written behind the previous tile's stencil, read by this tile's transform)
+  uint2 pg = make_uint2(0, 0);
+  auto prefetch_g = [&](int tile) {
+    const int g0t = tile * V6_OUT - 1;
+    const int nbat = a.M / a.T;
+    int bb = (g0t < 0 ? 0 : g0t) / a.T + (tid >> 8);
+    bb = bb < nbat ? bb : nbat - 1;
+    pg = *reinterpret_cast<const uint2*>(a.gu + (size_t)bb * 2 * V2_C + (tid & 255) * 2);
+  };
+  auto publish_g = [&]() { *reinterpret_cast<uint2*>(gus + (tid >> 8) * 2 * V2_C + (tid & 255) * 2) = pg; };
   bf16x8_t wf[16];
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) wf[ks] = __builtin_bit_cast(bf16x8_t, a.Wswz[((size_t)wave * 16 + ks) * 64 + lane]);
@@ -1118,6 +1330,7 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
     px[q] = ok ? *reinterpret_cast<const uint4*>(a.X + o) : make_uint4(0, 0, 0, 0);
   };
   int tile = blockIdx.x;
+  if (Z3 && tile < a.ntiles) { prefetch_g(tile); publish_g(); }
   if (tile < a.ntiles) { prefetch_q(tile, 0); prefetch_q(tile, 1); }
   __syncthreads();
   float sc[4], sh[4], wd[KD][4];
@@ -1138,7 +1351,9 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
     const int g0 = tile * V6_OUT - 1;          // global row of tile row 0
     TileMask tm = {0, 0, 0};
     if (MK) tm = tn_tile_mask(a.bn.rm.len, a.T, a.M, g0);
+    const int e0 = Z3 ? ((g0 < 0 ? 0 : g0) / a.T + 1) * a.T : 0;     // first row of the tile's second utterance
     __syncthreads();   // (1) the previous tile's stencil is done with Dt / Xs, its MFMAs with Pt
+    if (Z3 && tile + (int)gridDim.x < a.ntiles) prefetch_g(tile + gridDim.x);      // (published behind this tile's stencil)
     // ---- BN backward on load -> Pt;  raw X rows -> Xs
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -1146,6 +1361,28 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
       float z[8], y[8];
       unpack8(pz[q], z);
       unpack8(py[q], y);
+      if (Z3) {
+        // dYbn = (dZ ga + ub) [act3(y) > 0]: the gradient wrt this sub-block's BatchNorm output, rebuilt from the tail's dZ
+        float m[8];
+        {
+          float c3[8], h3v[8];
+          *reinterpret_cast<float4*>(c3) = *reinterpret_cast<const float4*>(cst + 10 * V2_C + c0);
+          *reinterpret_cast<float4*>(c3 + 4) = *reinterpret_cast<const float4*>(cst + 10 * V2_C + c0 + 4);
+          *reinterpret_cast<float4*>(h3v) = *reinterpret_cast<const float4*>(cst + 11 * V2_C + c0);
+          *reinterpret_cast<float4*>(h3v + 4) = *reinterpret_cast<const float4*>(cst + 11 * V2_C + c0 + 4);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) m[i] = (fmaf(y[i], c3[i], h3v[i]) > 0.f) ? 1.f : 0.f;
+        }
+        if (FL & 4) tn_drop8(m, ((uint32_t)gr * (uint32_t)V2_C + (uint32_t)c0) >> 3, dkey3, dthr3);
+        const float* gsel = gus + (gr >= e0 ? 2 * V2_C : 0) + c0;
+        float gav[8], ubv[8];
+        *reinterpret_cast<float4*>(gav) = *reinterpret_cast<const float4*>(gsel);
+        *reinterpret_cast<float4*>(gav + 4) = *reinterpret_cast<const float4*>(gsel + 4);
+        *reinterpret_cast<float4*>(ubv) = *reinterpret_cast<const float4*>(gsel + V2_C);
+        *reinterpret_cast<float4*>(ubv + 4) = *reinterpret_cast<const float4*>(gsel + V2_C + 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) z[i] = fmaf(z[i], gav[i], ubv[i]) * m[i];
+      }
       {
         // k0, k1, k2 from LDS (the registers go to the stencil window): unconditional 16-byte reads, then a select
         float k0v[8], k1v[8], k2v[8];
@@ -1160,10 +1397,11 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float v = fmaf(k0v[i], z[i], fmaf(k1v[i], y[i], k2v[i]));
-          z[i] = ok ? (valid ? v : 0.f) : z[i];
+          z[i] = ok ? (valid ? v : 0.f) : (Z3 ? 0.f : z[i]);
         }
       }
       store8(Pt + r * V2_AP + c0, z);
+      if (Z3 && a.dS_out && r >= 1 && r <= V6_OUT && gr < a.M) store8(a.dS_out + (size_t)gr * V2_C + c0, z);
       *reinterpret_cast<uint4*>(Xs + r * V2_C + c0) = px[q];
       if (tile + (int)gridDim.x < a.ntiles) prefetch_q(tile + gridDim.x, q);
     }
@@ -1313,6 +1551,7 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
         }
       }
     }
+    if (Z3 && tile + (int)gridDim.x < a.ntiles) publish_g();     // nobody reads gus between barrier (2) and the next barrier (1)
   }
   // s2 was accumulated against the RAW x:  sum dA * xhat = rstd * sum dA*x - mean*rstd * sum dA
 #pragma unroll
@@ -1343,6 +1582,12 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
 template <int FL>
 inline int launch_dgrad_dw_v6_t(DgradDwArgs a, int grid, size_t smem, hipStream_t st) {
   auto kern = a.bn.rm.len ? dgrad_dw_v6_kernel<FL, true> : dgrad_dw_v6_kernel<FL, false>;
+  if constexpr (FL == 7 || FL == 3) {
+    if (a.gu) {
+      if (a.bn.rm.len) return -1000;
+      kern = dgrad_dw_v6_kernel<FL, false, true>;
+    }
+  } else if (a.gu) return -1000;
   TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
   return (int)hipGetLastError();
@@ -1354,8 +1599,10 @@ inline int launch_dgrad_dw_v6(DgradDwArgs a, int max_wgs, hipStream_t st) {
   const int grid = a.ntiles < max_wgs ? a.ntiles : max_wgs;
   const size_t tiles = (size_t)(2 * V6_R * V2_AP + V6_R * V2_C) * sizeof(bf16_t);
   const size_t red = (size_t)8 * 6 * V2_C * sizeof(float);
-  const size_t smem = (tiles > red ? tiles : red) + (size_t)10 * V2_C * sizeof(float);
+  const size_t smem = (tiles > red ? tiles : red) + (size_t)(a.gu ? 12 + 4 : 10) * V2_C * sizeof(float);
   const int fl = (a.actX.mode != 0 ? 1 : 0) | (a.actX.relu ? 2 : 0) | (a.actX.drop_thr ? 4 : 0) | (a.ADD ? 8 : 0);
+  // (Z3: the output activation carries dropout exactly when the input activation does — one model-wide rate)
+  if (a.gu && ((a.act3.drop_thr != 0) != (a.actX.drop_thr != 0) || a.act3.mode == 0 || !a.act3.relu)) return -1000;
   switch (fl) {
     case 7: return launch_dgrad_dw_v6_t<7>(a, grid, smem, st);
     case 3: return launch_dgrad_dw_v6_t<3>(a, grid, smem, st);

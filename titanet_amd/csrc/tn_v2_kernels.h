@@ -563,14 +563,14 @@ inline int launch_se_squeeze_v2(const SeSqueezeV2Args& a, int B, hipStream_t st)
 // MK (variable-length batch, a.act.rm.len): the producers read padding rows as zeros and WRITE the depthwise output of padding
 // rows as zeros (operand tile and kept copy), so the GEMM gives y == bias there: the host takes those rows out of the
 // statistics again (stats_pad_fixup_kernel) and the weight gradients see a zero operand row.
-template <int KD, bool DW, int FL, bool MK = false>
+template <int KD, bool DW, int FL, bool MK = false, int R = V2_R>
 __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
   constexpr int PADR = DW ? (KD - 1) / 2 : 0;
-  constexpr int OUTR = DW ? V2_R - (KD - 1) : V2_R;
+  constexpr int OUTR = DW ? R - (KD - 1) : R;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);     // [64][264] output staging (consumers)
-  bf16_t* As0 = Cs + V2_R * V2_AP;                  // [2][64][264] MFMA B operand, double buffered
-  bf16_t* Xa = As0 + 2 * V2_R * V2_AP;              // [64][256] activated input rows (producers)
+  bf16_t* As0 = Cs + R * V2_AP;                  // [2][64][264] MFMA B operand, double buffered
+  bf16_t* Xa = As0 + 2 * R * V2_AP;              // [64][256] activated input rows (producers)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool producer = wave < 4;
   const int ltid = tid & 255;                        // thread index inside the team
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
   // workgroup barriers), so that the register allocator sees max(producer, consumer) live values, not their sum.
   if (producer) {
     // ---- producer: raw rows of the next tile (8 rows per thread) -> activated rows -> stencil -> operand tile
-    uint4 pf[8];
+    uint4 pf[R / 8];
     auto prefetch_q = [&](int tile, int q) {
       const int gr = tile * OUTR - PADR + rq + 8 * q;
       if (tile < a.ntiles && gr >= 0 && gr < a.M) pf[q] = *reinterpret_cast<const uint4*>(a.X + (size_t)gr * V2_C + c0);
@@ -623,15 +623,15 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
     };
     auto prefetch = [&](int tile) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) prefetch_q(tile, q);
+      for (int q = 0; q < R / 8; ++q) prefetch_q(tile, q);
     };
     TileMask tm = {0, 0, 0};
     auto produce_act = [&](int tile, bf16_t* As) {
       const int raw0 = tile * OUTR - PADR;
-      const bool interior = raw0 >= 0 && raw0 + V2_R <= a.M;
+      const bool interior = raw0 >= 0 && raw0 + R <= a.M;
       if (MK) tm = tn_tile_mask(a.act.rm.len, a.T, a.M, raw0);         // (produce_stencil of the same tile reuses it)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < R / 8; ++q) {
         const int r = rq + 8 * q, gr = raw0 + r;
         float v[8];
         unpack8(pf[q], v);
@@ -652,14 +652,14 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
     auto produce_stencil = [&](int tile, bf16_t* As) {
       const int out0 = tile * OUTR, raw0 = out0 - PADR;
       // (masked: the fast path also needs every row of the tile to be a valid frame)
-      const bool one_utt = raw0 >= 0 && raw0 + V2_R <= a.M && (raw0 % a.T) + V2_R <= a.T && (!MK || raw0 + V2_R <= tm.lim0);
+      const bool one_utt = raw0 >= 0 && raw0 + R <= a.M && (raw0 % a.T) + R <= a.T && (!MK || raw0 + R <= tm.lim0);
 #pragma unroll
-      for (int grp = 0; grp < 2; ++grp) {
+      for (int grp = 0; grp < R / 32; ++grp) {
         const int o0 = grp * 32 + rq * 4;
         float win[KD + 3][8];
 #pragma unroll
         for (int j = 0; j < KD + 3; ++j) {
-          if (o0 + j < V2_R) load8(Xa + (o0 + j) * V2_C + c0, win[j]);
+          if (o0 + j < R) load8(Xa + (o0 + j) * V2_C + c0, win[j]);
           else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) win[j][i] = 0.f;
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
     int buf = 0;
     for (int tile = first; tile < a.ntiles; tile += stride) {
       const int nxt = tile + stride;
-      bf16_t* Anxt = As0 + (buf ^ 1) * V2_R * V2_AP;
+      bf16_t* Anxt = As0 + (buf ^ 1) * R * V2_AP;
       if (nxt < a.ntiles) produce_act(nxt, Anxt);
       __syncthreads();
       if (DW && nxt < a.ntiles) produce_stencil(nxt, Anxt);
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
     __syncthreads();      // (pipeline fill: producers' stencil)
     int buf = 0;
     for (int tile = first; tile < a.ntiles; tile += stride) {
-      const bf16_t* As = As0 + buf * V2_R * V2_AP;
+      const bf16_t* As = As0 + buf * R * V2_AP;
       {
         f32x16_t acc[2][2];    // [channel block][row block]
 #pragma unroll
@@ -756,11 +756,13 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
           const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(brow + ks * 16);
-          const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(brow + 32 * V2_AP + ks * 16);
           acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], b0, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], b1, acc[0][1], 0, 0, 0);
           acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][ks], b0, acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][ks], b1, acc[1][1], 0, 0, 0);
+          if (R == 64) {
+            const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(brow + 32 * V2_AP + ks * 16);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], b1, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][ks], b1, acc[1][1], 0, 0, 0);
+          }
         }
 #pragma unroll
         for (int cbk = 0; cbk < 2; ++cbk)
@@ -771,14 +773,14 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
             w0.x = f2bf_pk(acc[cbk][0][4 * g], acc[cbk][0][4 * g + 1]); w0.y = f2bf_pk(acc[cbk][0][4 * g + 2], acc[cbk][0][4 * g + 3]);
             w1.x = f2bf_pk(acc[cbk][1][4 * g], acc[cbk][1][4 * g + 1]); w1.y = f2bf_pk(acc[cbk][1][4 * g + 2], acc[cbk][1][4 * g + 3]);
             *reinterpret_cast<uint2*>(Cs + (lane & 31) * V2_AP + co) = w0;
-            *reinterpret_cast<uint2*>(Cs + (32 + (lane & 31)) * V2_AP + co) = w1;
+            if (R == 64) *reinterpret_cast<uint2*>(Cs + (32 + (lane & 31)) * V2_AP + co) = w1;
           }
       }
       __syncthreads();
       {
         const int out0 = tile * OUTR;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < R / 8; ++q) {
           const int o = rq + 8 * q, gr = out0 + o;
           if (o < OUTR && gr < a.M) {
             const uint4 raw = *reinterpret_cast<const uint4*>(Cs + o * V2_AP + c0);
@@ -814,24 +816,26 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
   }
 }
 
-template <int KD, bool DW, int FL>
+template <int KD, bool DW, int FL, int R>
 inline int launch_sub_fwd_v5_t(SubFwdV2Args a, int grid, size_t smem, hipStream_t st) {
-  auto kern = a.act.rm.len ? sub_fwd_v5_kernel<KD, DW, FL, true> : sub_fwd_v5_kernel<KD, DW, FL, false>;
+  auto kern = a.act.rm.len ? sub_fwd_v5_kernel<KD, DW, FL, true, R> : sub_fwd_v5_kernel<KD, DW, FL, false, R>;
   TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
   return (int)hipGetLastError();
 }
-template <int KD, bool DW>
+// R: raw rows per tile (64, or 32: twice the tiles per workgroup — a shorter pipeline fill / drain per launch)
+template <int KD, bool DW, int R = V2_R>
 inline int launch_sub_fwd_v5(SubFwdV2Args a, int resident_wgs, hipStream_t st) {
-  constexpr int OUTR = DW ? V2_R - (KD - 1) : V2_R;
+  constexpr int OUTR = DW ? R - (KD - 1) : R;
   a.ntiles = (a.M + OUTR - 1) / OUTR;
   const int grid = a.ntiles < resident_wgs ? a.ntiles : resident_wgs;
-  const size_t smem = (size_t)(3 * V2_R * V2_AP + V2_R * V2_C) * sizeof(bf16_t);
+  const size_t tiles = (size_t)(3 * R * V2_AP + R * V2_C) * sizeof(bf16_t), red = (size_t)8 * 2 * V2_C * sizeof(float);
+  const size_t smem = tiles > red ? tiles : red;
   const int fl = (a.act.mode != 0 ? 1 : 0) | (a.act.relu ? 2 : 0) | (a.act.drop_thr ? 4 : 0);
   switch (fl) {
-    case 0: return launch_sub_fwd_v5_t<KD, DW, 0>(a, grid, smem, st);
-    case 3: return launch_sub_fwd_v5_t<KD, DW, 3>(a, grid, smem, st);
-    case 7: return launch_sub_fwd_v5_t<KD, DW, 7>(a, grid, smem, st);
+    case 0: return launch_sub_fwd_v5_t<KD, DW, 0, R>(a, grid, smem, st);
+    case 3: return launch_sub_fwd_v5_t<KD, DW, 3, R>(a, grid, smem, st);
+    case 7: return launch_sub_fwd_v5_t<KD, DW, 7, R>(a, grid, smem, st);
     default: return -1000;      // no specialisation for this activation (the caller runs the generic GEMM)
   }
 }
