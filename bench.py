@@ -41,13 +41,23 @@ ALG_BYTES_PER_UTT_BF16 = 70.66e6   # 7,065,600 elements x 5 pa
 
 PROF_CLASSES = {1: "fwd_subblock_gemm", 2: "bwd_pointwise_wgrad", 3: "bwd_skip_dgrad", 4: "bwd_subblock_dgrad_depthwise"}
 # kernel behind each class on the headline shape (for the PMC traffic lookup)
-PROF_KERNELS = {1: "sub_fwd_v5_kernel<3, true, 7>", 2: "wgrad_batched_v2_kernel<3, false>", 3: "dgrad_v2_kernel<64>",
-                4: "dgrad_dw_v6_kernel<7>"}
+PROF_KERNELS = {1: "sub_fwd_v5_kernel<3, true, 7", 2: "wgrad_batched_v2_kernel<3, false>", 3: "dgrad_v2_kernel<64>",
+                4: "dgrad_dw_v6_kernel<7"}       # (name prefixes: every instance of the class's main flag set)
 
 
 def _pmc_file():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
     return files[-1] if files else None
+
+
+def _kernel_digest():
+    """Digest of the kernel sources the library is built from (titanet_amd/csrc/build.py): a PMC summary only describes
+    the kernels it was taken with."""
+    try:
+        from titanet_amd.csrc.build import _digest
+        return _digest()[:16]
+    except Exception:
+        return None
 
 
 def _pmc_bytes(d):
@@ -66,9 +76,13 @@ def pmc_traffic(cls):
     try:
         data = json.load(open(path))
         meta = data.get("_meta", {})
+        # stale counters are worse than none: the file names the kernel-source digest it was taken at (tools/pmc_summary.py)
+        if meta.get("kernel_digest") != _kernel_digest():
+            return None, None, os.path.relpath(path, ROOT) + " (STALE: taken at kernel digest %s, this build is %s)" % (
+                meta.get("kernel_digest"), _kernel_digest())
         steps = float(meta.get("steps", 0))
-        k = data.get(PROF_KERNELS[cls])
-        per_launch = int(_pmc_bytes(k)) if k else None
+        ks = [v for n, v in data.items() if n != "_meta" and n.startswith(PROF_KERNELS[cls])]
+        per_launch = int(sum(_pmc_bytes(v) * v.get("launches", 0) for v in ks) / max(sum(v.get("launches", 0) for v in ks), 1)) if ks else None
         per_step = None
         if steps > 0:
             per_step = int(sum(_pmc_bytes(v) * v.get("launches", 0) for n, v in data.items() if n != "_meta") / steps)
@@ -85,8 +99,9 @@ def kernel_own_bytes(cls, rows, hidden, esz):
         1: 3 * t,                          # read input rows once, write raw output once + the kept depthwise output (for wgrad)
         2: 3 * t + hidden * hidden * 4,    # read dYbn, Y (BN backward on load), the kept depthwise output; write dW
         3: 3 * t,                          # read dYbn, Y; write dD
-        4: 4 * t * 32 // 30,               # fused data gradient + depthwise backward: read dYbn, Y, previous raw output; write
-                                           # dYbn(prev); 32-row tiles yield 30 rows (the overlap is re-read)
+        4: (4 * t * 32 // 30) + t // 3,    # fused data gradient + depthwise backward: read dYbn, Y, previous raw output; write
+                                           # dYbn(prev); 32-row tiles yield 30 rows (the overlap is re-read); one launch in three
+                                           # (the last sub-block of a mega block) also stores the BatchNorm-backward'd dS
     }[cls]
 
 
@@ -225,9 +240,16 @@ def other_configs(dev):
         r = {"workload": f"TitaNet-{size.upper()}/{nb} fwd+bwd+Adam, {head} head, batch {B}, 80x{T}, {prec}", "ms_per_step": round(dt * 1e3, 3),
              "utt_per_s": round(ups, 1), "mfma_util": round(FLOPS_PER_UTT[size] * ups / MFMA_PEAK_BF16, 4),
              "params_finite": bool(torch.isfinite(m.flat_parameters()).all())}
-        if size == "l":
+        if size == "l" and prec == "fp8":
+            # BASELINE.md 3 / SURVEY.md 8(d): with e4m3 pointwise operands (5 PFLOP/s dense) L is HBM-bound again: 84.48 MB per
+            # utterance at 8 TB/s = 94.7 k utterances/s
+            nbytes = ELEMS_PER_FRAME["l"] * 300 * 10.0
+            r.update({"bound": "hbm", "frac": round(nbytes * ups / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_MB_per_utt": round(nbytes / 1e6, 2),
+                      "mfma_util_fp8_peak": round(FLOPS_PER_UTT[size] * ups / (2 * MFMA_PEAK_BF16), 4),
+                      "note": "8(d): HBM-bound under fp8 (95 k utt/s roof); forward AND backward pointwise GEMMs on the f8f6f4 MFMA where the fp8 plan provides them, the rest in bf16"})
+        elif size == "l":
             r.update({"bound": "mfma", "frac": r["mfma_util"], "peak_TFLOPs": MFMA_PEAK_BF16 / 1e12,
-                      "note": "8(d): L is MFMA-bound in bf16; the fp8 plan runs the forward pointwise GEMMs on the f8f6f4 MFMA, the rest in bf16"})
+                      "note": "8(d): L is MFMA-bound in bf16"})
         else:
             nbytes = {"s": ALG_BYTES_PER_UTT_BF16, "m": ELEMS_PER_FRAME["m"] * 300 * 10.0}[size]
             r.update({"bound": "hbm", "frac": round(nbytes * ups / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_MB_per_utt": round(nbytes / 1e6, 2)})
@@ -324,6 +346,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo for single-GPU smoke tests)")
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--grad-groups", type=int, default=2, help="gradient buckets of mega blocks for the overlapped all-reduce (N > 1)")
+    ap.add_argument("--median-steps", type=int, default=100, help="extra steps timed one by one with HIP events after the timed region (median step time; 0 = skip)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -430,6 +453,19 @@ def main():
         rank_ms = [float(t.item()) for t in allr]
     loss_value = float(lv.item())
     params_finite = bool(torch.isfinite(model.flat_parameters()).all())
+    # SURVEY.md 8(d) protocol beside the driver's flags: >= 100 further steps, each bracketed by its own HIP events on the
+    # launch stream -> median / spread of the step time (one GPU; the headline `value` stays the wall-clock mean of --steps)
+    step_events = None
+    if world == 1 and args.median_steps > 0:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.median_steps)]
+        for e0, e1 in evs:
+            e0.record()
+            trainer.step(x, y)
+            e1.record()
+        torch.cuda.synchronize()
+        ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        step_events = {"steps": len(ts), "warmup_before": args.warmup + 4 + args.steps, "median_ms": round(ts[len(ts) // 2], 3),
+                       "p10_ms": round(ts[len(ts) // 10], 3), "p90_ms": round(ts[(len(ts) * 9) // 10], 3), "mean_ms": round(sum(ts) / len(ts), 3)}
 
     if rank == 0:
         esz = 2 if args.precision == "bf16" else 4
@@ -468,6 +504,8 @@ def main():
                        "global_batch": args.batch * world, "frames": T, "parallelism": f"dp{world}", "dropout": 0.1,
                        "loss": loss_value, "params_finite": params_finite, "rccl_ranks": rccl_ranks, "backend": args.backend if world > 1 else None,
                        "grad_groups": args.grad_groups if world > 1 else 1,
+                       "grad_groups_note": ("N > 1 runs the weight-gradient launch per gradient bucket (overlapped all-reduce): the same rank "
+                                            "program costs ~0.1 ms/step more than the single-bucket N = 1 program (DESIGN.md 5)") if world > 1 else None,
                        "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)}},
             "roofline": {
                 "bound": "hbm", "scope": "whole step: SURVEY.md 8(d) algorithmic bytes / step time (per GPU)",
@@ -486,7 +524,8 @@ def main():
                     "own_bytes_per_launch": own, "achieved_own_GBps": round(own / avg_s / 1e9, 1),
                     "attributed_8d_bytes_per_launch": attributed, "frac_attributed": round(attributed / avg_s / 1e9 / HBM_PEAK_GBS, 4),
                     "traffic_per_launch": k_traffic},
-                "class_ms_per_step": {PROF_CLASSES[k]: round(v[0], 3) for k, v in cls_ms.items()}},
+                "class_ms_per_step": {PROF_CLASSES[k]: round(v[0], 3) for k, v in cls_ms.items()},
+                "step_time_events": step_events},
         }
         del trainer, model
         torch.cuda.empty_cache()

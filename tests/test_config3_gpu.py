@@ -156,3 +156,26 @@ def test_front_end_fused_into_the_prolog_operand():
         a = m(mel.batch(w.cuda())).cpu().numpy()
         b = m(mel.batch(w.cuda(), into=m)).cpu().numpy()
     assert rel_err(b, a) < 1e-6, rel_err(b, a)
+
+
+def test_prefetching_a_packed_batch_invalidates_a_pending_backward():
+    """MelSpectrogram.batch(into=model) overwrites the plan's prolog operand, which backward re-reads for the prolog weight
+    gradient: a batch prefetched between forward and backward must make that backward raise, not use the wrong input."""
+    from titanet_amd import LOSSES, TitaNet
+    from titanet_amd.transforms import MelSpectrogram
+    B = 4
+    m = TitaNet.get_titanet(n_mega_blocks=1, model_size="s", loss_function=LOSSES["ce"](192, 10, device="cuda"), dropout=0.0,
+                            device="cuda", precision="bf16").train()
+    mel = MelSpectrogram(SR, n_fft=512, win_length=400, hop_length=HOP, n_mels=80)
+    w = (torch.randn(B, 32000, generator=torch.Generator().manual_seed(2)) * 0.05).cuda()
+    y = torch.arange(B).cuda()
+    _, _, lv = m(mel.batch(w, into=m), speakers=y)
+    nxt = mel.batch(w * 0.5, into=m)                      # same shape, same mode: the same plan
+    with pytest.raises(RuntimeError, match="saved activations"):
+        lv.backward()
+    _, _, lv2 = m(nxt, speakers=y)                        # the prefetched batch itself is consumed normally
+    lv2.backward()
+    assert torch.isfinite(m.flat_gradients()).all()
+    # a batch of one utterance in training mode: the intended error, not an AttributeError on the packed handle
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        m(mel.batch(w[:1], into=m), speakers=y[:1])

@@ -168,3 +168,28 @@ def test_yaml_driven_data_parallel_training(tmp_path):
     assert res[0][3] == 3, res[0][3]            # tail bucket + 2 groups of mega blocks
     d = torch.load(ck, weights_only=True)
     assert d["epoch"] == 4 and d["dropout_stream"]["step"] == 4
+
+
+def test_bench_spawn_path_two_ranks_same_device():
+    """`python bench.py --gpus 2` as the driver's 8-GPU box will first run it (bench.py's own mp.spawn, port pick,
+    init_process_group, the collective probe, the per-rank spread gather), here with both ranks on cuda:0 over gloo: ONE JSON
+    line with n_gpus 2, rccl_ranks 2, the rank spread and the whole-job value."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo", "--steps", "2",
+                          "--warmup", "1", "--batch", "64", "--no-cpu-baseline", "--no-other-configs", "--no-ceiling"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    cfg = d["config"]
+    assert d["n_gpus"] == 2 and cfg["rccl_ranks"] == 2 and cfg["global_batch"] == 128 and cfg["parallelism"] == "dp2"
+    assert cfg["grad_groups"] == 2 and cfg["grad_groups_note"] and cfg["params_finite"]
+    assert 0 < cfg["rank_ms_per_step"]["min"] <= cfg["rank_ms_per_step"]["max"]
+    assert abs(d["value"] - 128 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3 and d["scaling"] == "weak"

@@ -44,3 +44,29 @@ def test_verification_eer_parity():
     want = metrics.get_test_metrics(o_scores, labels, prefix="test")
     assert abs(got["test/eer"] - want["test/eer"]) < 1e-6
     assert abs(got["test/mindcf"] - want["test/mindcf"]) < 1e-6
+
+
+def test_verification_with_the_mean_pool_decoder_and_ragged_utterances():
+    """Decoder(simple_pool=True) has no padding-mask forward: verification_test embeds one utterance per forward then (as the
+    reference does) instead of raising on utterances of different lengths."""
+    case = CASES["tiny_simple_pool"]
+    m = build(case, None).eval()
+    g = torch.Generator().manual_seed(5)
+    specs = [torch.randn(case["cfg"]["n_mels"], int(torch.randint(20, 50, (1,), generator=g)), generator=g) * 0.05 - 0.1 for _ in range(6)]
+    spk = [0, 0, 1, 1, 2, 2]
+    got, scores, labels = metrics.verification_test(m, specs, spk, batch_size=4)
+    assert len(scores) == 36 and np.isfinite(scores).all()
+    with torch.no_grad():
+        alone = torch.cat([m(s.unsqueeze(0).cuda()) for s in specs]).cpu().numpy()
+    alone /= np.linalg.norm(alone, axis=1, keepdims=True)
+    assert np.abs(scores.reshape(6, 6) - alone @ alone.T).max() < 1e-5
+
+
+def test_verification_keeps_the_plan_cache_small():
+    """utterances sorted by length, frames padded to multiples of 128: a sweep over many lengths creates a handful of plans"""
+    case = CASES["tiny_k3"]
+    m = build(case, None).eval()
+    g = torch.Generator().manual_seed(6)
+    specs = [torch.randn(case["cfg"]["n_mels"], 20 + 7 * i, generator=g) * 0.05 - 0.1 for i in range(24)]      # 20 .. 181 frames
+    metrics.verification_test(m, specs, list(range(24)), batch_size=8)
+    assert len(m._plans) <= 3, len(m._plans)

@@ -30,6 +30,8 @@ def test_gradients_at_trained_weights_vs_float64_oracle(hidden, kernel, precisio
     case = dict(cfg=dict(n_mels=80, n_mega_blocks=2, hidden=hidden, enc_out=1536, emb=192, kernel=kernel, attn_hidden=128),
                 batch=64, frames=120, n_classes=NCLS, seed=31)
     m32 = build(case, "ce", precision="fp32", dropout=P).train()
+    m32._seed_base, m32._step = 20240917, 0           # the dropout stream of the training run: not whatever torch.initial_seed()
+                                                      # happens to be after the tests that ran before this one
     tr = Trainer(m32, lr=1e-3)
     first = last = None
     for step in range(250):

@@ -853,7 +853,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   }
   BnAct acte = make_act(p, m->epi_bn, M, training, 1, 0.f, seed, 0);
   // the attention GEMMs (1536 <-> 128) do not depend on the hidden width: the wide models run them on the same kernels
-  const bool attn_v2 = sizeof(AT) == 2 && !p->generic && D % 256 == 0 && A == 128 && ((use_v2 && H == 256) || (H >= 512 && !use_v2 && p->wide_dw_bwd));
+  const bool attn_v2 = sizeof(AT) == 2 && !p->generic && D % 256 == 0 && A == 128 && (size_t)M * D * 2 < ((size_t)1 << 31) && ((use_v2 && H == 256) || (H >= 512 && !use_v2 && p->wide_dw_bwd));
   if (c.simple_pool) {
     // ---- simple pool (reference src/models.py:497-502): mean over time, then Linear(D, 2D) in f32
     hipLaunchKernelGGL(mean_pool_fwd_kernel<AT>, dim3(B, (D + 511) / 512), dim3(256), 0, st, (const AT*)(ws + p->E), acte, T, D,

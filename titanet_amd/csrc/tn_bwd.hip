@@ -257,7 +257,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   }
   // ================= attentive statistics pooling =================
   BnAct acte = make_act(p, m->epi_bn, M, training, 1, 0.f, seed, 0);
-  const bool attn_v2 = sizeof(AT) == 2 && !p->generic && D % 256 == 0 && A == 128 && ((use_v2 && H == 256) || (H >= 512 && !use_v2 && p->wide_dw_bwd));
+  const bool attn_v2 = sizeof(AT) == 2 && !p->generic && D % 256 == 0 && A == 128 && (size_t)M * D * 2 < ((size_t)1 << 31) && ((use_v2 && H == 256) || (H >= 512 && !use_v2 && p->wide_dw_bwd));
   if (c.simple_pool) {
     // ================= simple pool: Linear(D, 2D) over B rows, then the mean over time =================
     const float* dpool = (const float*)(ws + p->dpooled);

@@ -46,12 +46,21 @@ __global__ __launch_bounds__(V2_NT, 2) void wide_out_v2_kernel(WideOutArgs a) {
 
   bf16x8_t wf[KS], wfn[KS];
   float biasn[16];
+  // fragment-order weights through buffer loads: one per-lane offset register, the (slab, wave, k-step) part is scalar (flat
+  // addressing kept 16 per-lane 64-bit addresses alive next to 128 fragment registers: the <256, 0> instance spilled)
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+  const __amdgpu_buffer_rsrc_t srdW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.Wswz), 0, a.Wswz ? a.N * K * (int)sizeof(bf16_t) : 0, 0x00020000);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   auto fetch_w = [&](int slab) {
     const int co = slab * V2_C + wave * 32 + (lane & 31);
+    if (a.Wswz) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      wfn[ks] = a.Wswz ? __builtin_bit_cast(bf16x8_t, a.Wswz[((size_t)(slab * 8 + wave) * KS + ks) * 64 + lane])
-                       : *reinterpret_cast<const bf16x8_t*>(a.W + (size_t)co * K + ks * 16 + half * 8);
+      for (int ks = 0; ks < KS; ++ks)
+        wfn[ks] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(srdW, lane * 16, ((slab * 8 + wave_u) * KS + ks) * 1024, 0));
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) wfn[ks] = *reinterpret_cast<const bf16x8_t*>(a.W + (size_t)co * K + ks * 16 + half * 8);
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -253,18 +262,29 @@ __global__ __launch_bounds__(V2_NT, 2) void wide_in_v2_kernel(WideInArgs a) {
       par[c] = s; par[a.KW + c] = h;
     }
   }
-  // weight chunk kc -> LDS (each thread moves 8 x 16 bytes)
-  auto w_load = [&](int kc, uint4 (&wr)[8]) {
+  // weight chunk kc -> LDS in 8 pieces of 16 bytes per thread.  The NEXT chunk travels two pieces per tile step (loads issued
+  // at the top of the step, stored behind its MFMAs): the 8-piece register prefetch of round 2 (32 VGPRs next to 80
+  // accumulator + 64 fragment registers) lived in scratch — hipcc parked every piece there with a wait right behind its load,
+  // so each chunk began with an exposed L2 round trip and the activation prefetch was drained with it (round 4).
+  // Buffer loads with ONE per-lane offset register per stream and a scalar offset per (chunk, tile, piece): with flat
+  // addresses hipcc hoisted the 20 + 8 per-lane 64-bit addresses of the unrolled steps out of the chunk loop and spilled them.
+  // Rows at or beyond r_end read as zeros (num_records).
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+  const __amdgpu_buffer_rsrc_t srdW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W), 0, NO * a.KW * (int)sizeof(bf16_t), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.A), 0, (int)((size_t)r_end * a.KW * sizeof(bf16_t)), 0x00020000);
+  const int voffW = ((tid >> 5) * a.KW + (tid & 31) * 8) * (int)sizeof(bf16_t);
+  const int voffA = (rq * a.KW + c0) * (int)sizeof(bf16_t);
+  auto w_load2 = [&](int kc, int q0, uint4 (&wr)[2]) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int v = tid + q * V2_NT, r = v >> 5, cv = v & 31;
-      wr[q] = *reinterpret_cast<const uint4*>(a.W + (size_t)r * a.KW + kc * V2_C + cv * 8);
+    for (int q = 0; q < 2; ++q) {
+      const u32x4_t r = __builtin_amdgcn_raw_buffer_load_b128(srdW, voffW, ((q0 + q) * 16 * a.KW + kc * V2_C) * (int)sizeof(bf16_t), 0);
+      wr[q] = make_uint4(r[0], r[1], r[2], r[3]);
     }
   };
-  auto w_store = [&](const uint4 (&wr)[8]) {
+  auto w_store2 = [&](int q0, const uint4 (&wr)[2]) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int v = tid + q * V2_NT, r = v >> 5, cv = v & 31;
+    for (int q = 0; q < 2; ++q) {
+      const int v = tid + (q0 + q) * V2_NT, r = v >> 5, cv = v & 31;
       *reinterpret_cast<uint4*>(Wl + r * V2_AP + cv * 8) = wr[q];
     }
   };
@@ -277,46 +297,46 @@ __global__ __launch_bounds__(V2_NT, 2) void wide_in_v2_kernel(WideInArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     __syncthreads();
-    {
-      uint4 wr[8];
-      w_load(0, wr);
-      w_store(wr);
+#pragma unroll
+    for (int q0 = 0; q0 < 8; q0 += 2) {
+      uint4 wr[2];
+      w_load2(0, q0, wr);
+      w_store2(q0, wr);
     }
     uint4 pa[4];
     auto a_fetch = [&](int kc, int t) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int o = t * V2_R + rq + 16 * q;
-        pa[q] = o < grow ? *reinterpret_cast<const uint4*>(a.A + (size_t)(g0 + o) * a.KW + kc * V2_C + c0) : make_uint4(0, 0, 0, 0);
+        const u32x4_t r = __builtin_amdgcn_raw_buffer_load_b128(srdA, voffA, ((g0 + t * V2_R + 16 * q) * a.KW + kc * V2_C) * (int)sizeof(bf16_t), 0);
+        pa[q] = make_uint4(r[0], r[1], r[2], r[3]);
       }
     };
     a_fetch(0, 0);
-    __syncthreads();
     for (int kc = 0; kc < nchunks; ++kc) {
+      __syncthreads();                              // Wl holds chunk kc (the pieces stored during the previous chunk's steps)
       bf16x8_t wf[16];
       {
         const bf16_t* wrow = Wl + (cb * 32 + (lane & 31)) * V2_AP + half * 8;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) wf[ks] = *reinterpret_cast<const bf16x8_t*>(wrow + ks * 16);
       }
-      float sc[8], sh[8];
-      if (MODE == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { sc[i] = par[kc * V2_C + c0 + i]; sh[i] = par[a.KW + kc * V2_C + c0 + i]; }
-      }
-      uint4 wr[8];
       const bool more_w = kc + 1 < nchunks;
-      if (more_w) w_load(kc + 1, wr);               // lands in LDS after this chunk's fragments were read (barrier below)
 #pragma unroll
       for (int t = 0; t < GT; ++t) {
         if (t < ntile) {
+          uint4 wp[2];
+          if (t < 4 && more_w) w_load2(kc + 1, 2 * t, wp);
           __syncthreads();                          // previous MFMA done with As (and, for t == 0, every wave holds its wf)
-          if (t == 0 && more_w) w_store(wr);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float v[8];
             unpack8(pa[q], v);
             if (MODE == 0) {
+              float sc[8], sh[8];
+              *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(par + kc * V2_C + c0);
+              *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(par + kc * V2_C + c0 + 4);
+              *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(par + a.KW + kc * V2_C + c0);
+              *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(par + a.KW + kc * V2_C + c0 + 4);
 #pragma unroll
               for (int i = 0; i < 8; ++i) v[i] = fmaxf(fmaf(v[i], sc[i], sh[i]), 0.f);
             }
@@ -332,6 +352,15 @@ __global__ __launch_bounds__(V2_NT, 2) void wide_in_v2_kernel(WideInArgs a) {
             const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(brow + ks * 16);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b, acc[t], 0, 0, 0);
           }
+          if (t < 4 && more_w) w_store2(2 * t, wp);
+        }
+      }
+      // row groups of fewer than 4 tiles: the pieces no tile step moved
+      if (more_w && ntile < 4) {
+        for (int t = ntile; t < 4; ++t) {
+          uint4 wp[2];
+          w_load2(kc + 1, 2 * t, wp);
+          w_store2(2 * t, wp);
         }
       }
     }
@@ -400,6 +429,7 @@ __global__ __launch_bounds__(V2_NT, 2) void wide_in_v2_kernel(WideInArgs a) {
 
 template <int MODE>
 inline int launch_wide_in_v2(WideInArgs a, int max_wgs, hipStream_t st) {
+  if ((size_t)a.M * a.KW * sizeof(bf16_t) >= ((size_t)1 << 31)) return -1000;      // 32-bit buffer offsets
   int grid = (a.M + V2_R - 1) / V2_R;
   if (grid > max_wgs) grid = max_wgs;
   a.rows_per_wg = (a.M + grid - 1) / grid;

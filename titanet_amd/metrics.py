@@ -84,14 +84,30 @@ def verification_test(model, spectrograms, speakers, mindcf_p_target=1e-2, mindc
     model.eval()
     dev = model.flat_parameters().device
     specs = [(s[0] if s.dim() == 3 else s) for s in spectrograms]
-    embs = []
-    for lo in range(0, len(specs), batch_size):
-        chunk = specs[lo:lo + batch_size]
-        lens = torch.tensor([int(s.shape[-1]) for s in chunk], dtype=torch.int64)
-        x = torch.zeros(len(chunk), chunk[0].shape[0], int(lens.max()), dtype=torch.float32, device=dev)
-        for i, s in enumerate(chunk):
-            x[i, :, :s.shape[-1]] = s.to(device=dev, dtype=torch.float32)
-        embs.append(model(x, lengths=lens) if len(set(lens.tolist())) > 1 else model(x))
+    n_utt = len(specs)
+    emb_of = [None] * n_utt
+    if getattr(getattr(model, "_cfg", None), "simple_pool", False):
+        # the mean-pool decoder has no padding-mask form (tn_forward_masked refuses it): one utterance per forward, as the
+        # reference does
+        for i, s in enumerate(specs):
+            emb_of[i] = model(s.to(device=dev, dtype=torch.float32).unsqueeze(0))
+    else:
+        # utterances sorted by length, `batch_size` per forward, the frame axis padded to a multiple of 128: few distinct
+        # (batch, frames) shapes, so the evaluation does not churn through the module's plan cache (MAX_PLANS) and evict the
+        # training plans; the padding mask makes the extra frames invisible
+        order = sorted(range(n_utt), key=lambda i: int(specs[i].shape[-1]))
+        for lo in range(0, n_utt, batch_size):
+            idx = order[lo:lo + batch_size]
+            chunk = [specs[i] for i in idx]
+            lens = torch.tensor([int(s.shape[-1]) for s in chunk], dtype=torch.int64)
+            T_pad = (int(lens.max()) + 127) // 128 * 128
+            x = torch.zeros(len(chunk), chunk[0].shape[0], T_pad, dtype=torch.float32, device=dev)
+            for i, s in enumerate(chunk):
+                x[i, :, :s.shape[-1]] = s.to(device=dev, dtype=torch.float32)
+            e = model(x, lengths=lens) if int(lens.min()) < T_pad else model(x)
+            for k, i in enumerate(idx):
+                emb_of[i] = e[k:k + 1]
+    embs = emb_of
     model.train(was_training)
     e = torch.cat(embs, dim=0)
     e = e / e.norm(dim=1, keepdim=True).clamp(min=1e-8)       # F.cosine_similarity eps

@@ -384,7 +384,7 @@ class TitaNet(nn.Module):
                 x = x.contiguous().float()
         B, _, T = spectrograms.shape
         if self.training and B < 2:
-            raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(spectrograms.shape)}")
         plan = self._get_plan(B, T)
         if packed is not None and (packed.plan is not plan or plan.handle is None or packed.generation != plan.generation):
             raise RuntimeError("titanet_amd: this PackedSpectrograms batch was written for another plan (the model changed mode, "

@@ -142,7 +142,9 @@ class Trainer:
               "tn_adam_step")
 
     def step(self, spectrograms, speakers, lengths=None):
-        if self.use_graph and lengths is None:
+        # (the captured step copies a float32 tensor into its static input: a batch the mel front end packed into the plan
+        #  — PackedSpectrograms — and ragged batches take the eager path)
+        if self.use_graph and lengths is None and isinstance(spectrograms, torch.Tensor):
             return self._graph_step(spectrograms, speakers)
         out = self.forward_backward(spectrograms, speakers, lengths=lengths)
         grads = self.model.flat_gradients()

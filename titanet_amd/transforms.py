@@ -163,7 +163,11 @@ class MelSpectrogram:
             check(self._lib.tn_mel_forward_batch_packed(self._mel(), vp(w.data_ptr()), B, A, vp(ln_d.data_ptr()), vp(rt_d.data_ptr()),
                                                         vp(fm.data_ptr() if fm is not None else 0), vp(tm.data_ptr() if tm is not None else 0),
                                                         T, vp(dst), vp(0), vp(stream)), "tn_mel_forward_batch_packed")
-            return PackedSpectrograms(plan, plan.generation, B, self.n_mels, T, torch.tensor(frames, dtype=torch.int64), self.device)
+            # the write replaced the plan's prolog operand, which a pending backward of an earlier forward on this plan would
+            # re-read for the prolog weight gradient: a new generation makes that backward raise instead of using this batch
+            plan.generation += 1
+            return PackedSpectrograms(plan, plan.generation, B, self.n_mels, T, torch.tensor(frames, dtype=torch.int64),
+                                      into.flat_parameters().device)
         check(self._lib.tn_mel_forward_batch(self._mel(), vp(w.data_ptr()), B, A, vp(ln_d.data_ptr()), vp(rt_d.data_ptr()),
                                              vp(fm.data_ptr() if fm is not None else 0), vp(tm.data_ptr() if tm is not None else 0),
                                              T, vp(out.data_ptr()), vp(stream)), "tn_mel_forward_batch")

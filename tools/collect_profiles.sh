@@ -7,11 +7,11 @@ TAG=${1:-r01_v3}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -o ${TAG} -- \
-    python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > gpurun_out/${TAG}_bench_profiled.json 2> gpurun_out/${TAG}_trace.log
+    python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --median-steps 0 > gpurun_out/${TAG}_bench_profiled.json 2> gpurun_out/${TAG}_trace.log
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_fetch -o f -- \
-    python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-ceiling --no-other-configs > /dev/null 2> gpurun_out/${TAG}_fetch.log
+    python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-ceiling --no-other-configs --median-steps 0 > /dev/null 2> gpurun_out/${TAG}_fetch.log
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_write -o w -- \
-    python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-ceiling --no-other-configs > /dev/null 2> gpurun_out/${TAG}_write.log
+    python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-ceiling --no-other-configs --median-steps 0 > /dev/null 2> gpurun_out/${TAG}_write.log
 python tools/pmc_summary.py gpurun_out/${TAG}_pmc_traffic.json --steps 9 gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write | head -20
 find gpurun_out/${TAG}_trace -name "*kernel_stats.csv" | head -2
 # un-profiled run last (this is the line the round reports)

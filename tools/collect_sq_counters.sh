@@ -4,11 +4,11 @@ set -u
 TAG=${1:-r01_sq}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS --output-format csv -d gpurun_out/${TAG}_a -o a -- \
-    python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-other-configs > /dev/null 2> gpurun_out/${TAG}_a.log
+    python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-other-configs --median-steps 0 > /dev/null 2> gpurun_out/${TAG}_a.log
 timeout 600 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d gpurun_out/${TAG}_b -o b -- \
-    python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-other-configs > /dev/null 2> gpurun_out/${TAG}_b.log
+    python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-other-configs --median-steps 0 > /dev/null 2> gpurun_out/${TAG}_b.log
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM --output-format csv -d gpurun_out/${TAG}_c -o c -- \
-    python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-other-configs > /dev/null 2> gpurun_out/${TAG}_c.log
+    python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-other-configs --median-steps 0 > /dev/null 2> gpurun_out/${TAG}_c.log
 python tools/pmc_summary.py gpurun_out/${TAG}_counters.json gpurun_out/${TAG}_a gpurun_out/${TAG}_b gpurun_out/${TAG}_c > /dev/null
 rm -rf gpurun_out/${TAG}_a gpurun_out/${TAG}_b gpurun_out/${TAG}_c
 python - <<PY

@@ -2,7 +2,8 @@
 Usage: python tools/pmc_summary.py out.json [--steps N] DIR1 DIR2 ...
 --steps: training steps the profiled command ran (bench.py: warmup + 4 class-probe steps + steps), stored as _meta.steps so
 that bench.py can turn per-launch averages x launches into HBM bytes per step."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 argv = sys.argv[1:]
 steps = 0
@@ -23,8 +24,14 @@ for d in argv[1:]:
             out.setdefault(k, {})[c] = v / n[(k, c)]
             out[k]["launches"] = n[(k, c)]
 total = sum((2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 * v["launches"] for v in out.values())
+try:
+    from titanet_amd.csrc.build import _digest
+    kd = _digest()[:16]
+except Exception:
+    kd = None
 out["_meta"] = {"steps": steps, "unit": "KiB per launch (FETCH_SIZE to be doubled on gfx950)",
-                "bytes_per_step": total / steps if steps else None}
+                "bytes_per_step": total / steps if steps else None,
+                "kernel_digest": kd}      # bench.py prints this file's traffic only for the kernels it was taken with
 json.dump(out, open(argv[0], "w"), indent=1)
 if steps:
     print("HBM bytes per step (2*FETCH + WRITE): %.2f GB" % (total / steps / 1e9))
