@@ -139,6 +139,25 @@ def stream_ceiling(dev, rows=256 * 300, hidden=256, sets=10, reps=40):
     return out
 
 
+def effective_cores():
+    """Host cores this process may actually use: the visible count capped by the container's CPU quota (cgroup v2 cpu.max /
+    v1 cfs_quota).  The GPU boxes show 256 cores under a 16-core quota: thread pools sized by os.cpu_count() burn the quota in
+    a few ms of spinning and the whole process is frozen for the rest of the 100 ms accounting period."""
+    n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(budget_s=24.0):
     """The reference's CPU path timed on this box's host cores: the reference's module graph
     (nn.Conv1d / nn.BatchNorm1d / ... leaf modules, F.pad per conv, the margin loss's per-row loop) rebuilt in
@@ -149,7 +168,7 @@ def cpu_baseline(budget_s=24.0):
     (the GPU workload; 64 on hosts with < 32 cores) train fwd+bwd with CE on all cores, one iteration.  Bounded: each batch-8
     leg stops after ~budget_s / 8 seconds."""
     from oracle.eager_modules import EagerTitaNet
-    ncpu = os.cpu_count() or 1
+    ncpu = effective_cores()
     g = torch.Generator().manual_seed(42)
 
     def leg(batch, mode, loss, threads, max_s, max_it, warm=True):
@@ -186,7 +205,8 @@ def cpu_baseline(budget_s=24.0):
             leg(256 if ncpu >= 32 else 64, "train", "ce", min(ncpu, 64), 0.0, 1, warm=False)]
     best = max((lg for lg in legs if lg["mode"] == "train" and lg["loss"] == "ce"), key=lambda lg: lg["utt_per_s"])
     torch.set_num_threads(min(ncpu, 8))
-    return {"value": best["utt_per_s"], "unit": "utterances/s", "cores": best["threads"], "kind": "port", "host_cores": ncpu,
+    return {"value": best["utt_per_s"], "unit": "utterances/s", "cores": best["threads"], "kind": "port", "host_cores": os.cpu_count(),
+            "usable_cores": ncpu,
             "sample": f"best train fwd+bwd (CE) leg: batch {best['batch']}, {best['iterations']} iterations, {best['threads']} threads; "
                       "eager nn.Module graph of the reference (oracle/eager_modules.py), fp32, TitaNet-S/17, 80x300",
             "legs": legs}
@@ -209,7 +229,7 @@ def _timed_steps(fn, warm, steps):
     return (time.perf_counter() - t0) / steps
 
 
-def other_configs(dev):
+def other_configs(dev, only=None):
     """BASELINE.json configs[2..4] as bounded legs OUTSIDE the headline's timed region (rank 0, one GPU): ms per step,
     utterances/s, the governing roofline of SURVEY.md 8(d) and the MFMA utilisation FLOPs x utt/s / 2.5 PFLOP/s (bf16 dense)."""
     import random
@@ -220,6 +240,8 @@ def other_configs(dev):
     n_classes = 251
 
     def leg(name, fn):
+        if only and name not in only:
+            return
         try:
             out[name] = fn()
         except Exception as e:      # a leg must never take the headline line down with it
@@ -341,6 +363,7 @@ def main():
     ap.add_argument("--loss", default="ce", choices=["ce", "arc"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the bounded legs of BASELINE configs[2..4]")
+    ap.add_argument("--only-config", action="append", default=None, help="run only this other_configs leg (repeatable), e.g. m10_ragged_mel_specaug_masked")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the streaming-ceiling microbenchmark (PMC passes: keeps foreign kernels out of the counters)")
     ap.add_argument("--prof-class", type=int, default=0, help="kernel class timed with HIP events in the timed region (0 = the dominant one)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo for single-GPU smoke tests)")
@@ -351,6 +374,7 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU execution path for the product)")
+    torch.set_num_threads(min(effective_cores(), 8))       # host-side torch ops: never a pool of one thread per VISIBLE core
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # launched as a plain `python bench.py --gpus N`: start the N ranks here (one process per GPU, RCCL)
         ndev = torch.cuda.device_count()
@@ -530,7 +554,7 @@ def main():
         del trainer, model
         torch.cuda.empty_cache()
         if world == 1 and not args.no_other_configs:
-            out["other_configs"] = other_configs(dev)
+            out["other_configs"] = other_configs(dev, args.only_config)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -170,6 +170,15 @@ int tn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
  * from the same counter.  A capture of { tn_plan_step_tick; tn_forward(seed fixed); tn_backward; tn_adam_step_plan } on
  * one stream is then replayable as a single hipGraph with no per-step host arguments (titanet_amd/trainer.py). */
 int tn_plan_step_tick(tn_plan* p, void* stream);
+
+/* ---- stream progress visible to the host WITHOUT a runtime call (new; the reference's training loop synchronises every
+ * step through `loss.item()`, reference src/learn.py:110) -------------------------------------------------------------------
+ * Enqueues a one-thread kernel that stores `value` (system scope, release) to `host_flag`, a 4-byte word of PINNED host
+ * memory: everything enqueued on `stream` before the call has completed when the host reads `value` there.  The trainer
+ * bounds the steps in flight with it and the mel front end recycles its pinned staging slots with it: waiting on HIP
+ * events from a host that is several steps ahead of the GPU (hipEventQuery / hipEventSynchronize) left the GPU idle for
+ * 50-80 ms at a time in the middle of a step (BASELINE configs[3] leg, round 4), polling a plain word does not. */
+int tn_mark_host(uint32_t* host_flag, uint32_t value, void* stream);
 int tn_plan_step_set(tn_plan* p, int64_t step, void* stream);   /* step 0 = word 0 (the ungraphed convention) */
 int tn_adam_step_plan(tn_plan* p, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                       float beta1, float beta2, float eps, float weight_decay, float grad_mult, void* stream);

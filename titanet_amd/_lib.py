@@ -19,6 +19,7 @@ EXPORTS = [
     "tn_profile_read", "tn_profile_sample", "tn_mel_create", "tn_mel_destroy", "tn_mel_num_frames", "tn_mel_forward", "tn_mel_forward_batch", "tn_plan_step_tick",
     "tn_plan_step_set", "tn_adam_step_plan", "tn_plan_set_lr", "tn_head_save_floats", "tn_head_forward", "tn_head_backward",
     "tn_forward_masked", "tn_forward_prepacked", "tn_plan_prolog_input", "tn_mel_forward_batch_packed", "tn_plan_set_grad_groups", "tn_plan_num_grad_buckets", "tn_plan_grad_bucket", "tn_plan_wait_grad_bucket",
+    "tn_mark_host",
 ]
 
 
@@ -75,6 +76,7 @@ def load():
     lib.tn_backward.argtypes = [vp, f32, vp, vp, vp, vp]
     lib.tn_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]
     lib.tn_plan_step_tick.argtypes = [vp, vp]
+    lib.tn_mark_host.argtypes = [vp, C.c_uint32, vp]
     lib.tn_plan_step_set.argtypes = [vp, i64, vp]
     lib.tn_adam_step_plan.argtypes = [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp]
     lib.tn_plan_set_lr.argtypes = [vp, f32, vp]
@@ -115,3 +117,36 @@ def check(rc, what):
     if rc != 0:
         names = {-1: "TN_E_BADARG", -2: "TN_E_UNSUPPORTED", -3: "TN_E_NOTBOUND", -4: "TN_E_STATE"}
         raise TitaNetLibraryError(f"{what} failed: {names.get(rc, 'hipError_t ' + str(rc))}")
+
+
+class HostMarks:
+    """Stream progress the host can poll without a runtime call (``tn_mark_host``): ``n`` 4-byte words of pinned memory.
+    ``mark(i, stream)`` enqueues a store of a fresh sequence number to word ``i`` behind everything on ``stream``;
+    ``pending(i)`` tells whether that store has not landed yet; ``wait(i)`` polls it with short sleeps.  No busy-waiting: the
+    GPU boxes run this process under a CPU quota, and a host thread that spins (on this word or on hipEventQuery) is frozen
+    by the scheduler for the rest of the accounting period — 60-85 ms at a time, in the middle of a launch sequence, with the
+    GPU running dry behind it (round 4: the configs[3] leg measured 18-25 ms per step for 14.2 ms of kernels)."""
+
+    def __init__(self, n):
+        import torch
+        self._t = torch.zeros(n, dtype=torch.int32).pin_memory()
+        self._np = self._t.numpy()              # shares the pinned memory: element reads are plain loads
+        self._want = [0] * n
+        self._seq = 0
+        self._lib = load()
+
+    def mark(self, i, stream):
+        self._seq = (self._seq + 1) & 0x3FFFFFFF
+        self._want[i] = self._seq
+        check(self._lib.tn_mark_host(C.c_void_p(self._t.data_ptr() + 4 * i), C.c_uint32(self._seq), C.c_void_p(stream)), "tn_mark_host")
+
+    def pending(self, i):
+        return self._want[i] != 0 and int(self._np[i]) != self._want[i]
+
+    def wait(self, i):
+        want = self._want[i]
+        if want:
+            import time
+            a = self._np
+            while int(a[i]) != want:
+                time.sleep(2e-4)

@@ -1133,6 +1133,15 @@ __global__ void step_tick_kernel(uint64_t* st, uint64_t set_to, int do_set) {
   st[0] = s;
   reinterpret_cast<uint32_t*>(st)[2] = s ? tn_mix32((uint32_t)s * 0x9E3779B9u + (uint32_t)(s >> 32) + 0x85ebca6bu) : 0u;
 }
+__global__ void mark_host_kernel(uint32_t* flag, uint32_t value) {
+  __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+extern "C" int tn_mark_host(uint32_t* host_flag, uint32_t value, void* stream) {
+  if (!host_flag) return TN_E_BADARG;
+  hipLaunchKernelGGL(mark_host_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, host_flag, value);
+  return (int)hipGetLastError();
+}
+
 extern "C" int tn_plan_step_tick(tn_plan* p, void* stream) {
   if (!p || !p->bound) return TN_E_STATE;
   hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (uint64_t*)(p->ws + p->step_state), (uint64_t)0, 0);

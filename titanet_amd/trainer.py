@@ -95,8 +95,14 @@ class Trainer:
     """``step(spectrograms, speakers)`` == one iteration of reference src/learn.py:88-135."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, n_buckets=2, group=None,
-                 use_graph=False, graph_warmup=2):
+                 use_graph=False, graph_warmup=2, max_steps_in_flight=0):
         self.model = model
+        # A step is 400-600 kernel launches and the host enqueues one in ~1.2 ms: left alone it runs a few steps ahead of the
+        # GPU until the HIP runtime's own back-pressure blocks it (a sleeping wait: harmless, the GPU stays fed).  Optional
+        # bound on the steps in flight (0 = the runtime's): polls a word of pinned memory the stream stores to at the end of
+        # every step (tn_mark_host), sleeping between polls — never spinning, see _lib.HostMarks.
+        self.max_steps_in_flight = max(0, int(max_steps_in_flight))
+        self._marks, self._mark_i = None, 0
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.reducer = FlatAllReducer(n_buckets, group)
         self.step_count = 0
@@ -141,7 +147,26 @@ class Trainer:
                                   self.eps, self.weight_decay, self.step_count, 1.0 / self.reducer.world, vp(stream)),
               "tn_adam_step")
 
+    def _throttle(self):
+        if self.max_steps_in_flight and self._marks is not None:
+            self._marks.wait(self._mark_i % self.max_steps_in_flight)       # the step `max_steps_in_flight` steps ago has finished
+
+    def _mark_step(self, device):
+        if not self.max_steps_in_flight:
+            return
+        if self._marks is None:
+            from ._lib import HostMarks
+            self._marks = HostMarks(self.max_steps_in_flight)
+        self._marks.mark(self._mark_i % self.max_steps_in_flight, torch.cuda.current_stream(device).cuda_stream)
+        self._mark_i += 1
+
     def step(self, spectrograms, speakers, lengths=None):
+        self._throttle()
+        out = self._step(spectrograms, speakers, lengths)
+        self._mark_step(out[0].device)
+        return out
+
+    def _step(self, spectrograms, speakers, lengths=None):
         # (the captured step copies a float32 tensor into its static input: a batch the mel front end packed into the plan
         #  — PackedSpectrograms — and ragged batches take the eager path)
         if self.use_graph and lengths is None and isinstance(spectrograms, torch.Tensor):

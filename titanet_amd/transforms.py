@@ -42,11 +42,11 @@ class MelSpectrogram:
         self.device = torch.device(device)
         self._lib = _lib.load()
         self._handle = None
-        self._ring, self._ring_i = [None] * 4, 0
+        self._ring, self._ring_i, self._marks = [None] * 32, 0, None
 
     def _upload(self, parts):
         """Small per-batch host arrays (lengths, rates, masks) -> device tensors through ONE asynchronous copy from a pinned
-        staging slot (a ring of 4, each guarded by an event).  ``tensor.to(device)`` from pageable memory blocks the calling
+        staging slot (a ring of 32, each guarded by a host-visible completion word).  ``tensor.to(device)`` from pageable memory blocks the calling
         thread until the stream has drained — one sleep / wake-up round trip per array and step, which on a busy host cost more
         than the whole network step (configs[3] leg: 26 -> 30-70 ms).  ``parts``: (source tensor, dtype, shape) — the source
         is converted and zero-padded to ``shape`` INSIDE the pinned slot (no temporaries: host allocations were the next stall)."""
@@ -58,26 +58,36 @@ class MelSpectrogram:
         k = self._ring_i % len(self._ring)
         self._ring_i += 1
         slot = self._ring[k]
+        if self._marks is None:
+            from ._lib import HostMarks
+            self._marks = HostMarks(len(self._ring))
         if slot is None or slot[0].numel() < total:
             cap = max(4096, 1 << (total - 1).bit_length())
-            slot = self._ring[k] = (torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=self.device),
-                                    torch.cuda.Event())
+            self._marks.wait(k)
+            slot = self._ring[k] = (torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=self.device))
         else:
-            while not slot[2].query():                 # the copy that last used this slot (4 batches ago) has run; spin (a
-                pass                                   # blocking wait sleeps, and waking up costs milliseconds on a busy host)
-        host, dev, ev = slot
+            # the copy that last used this slot (32 batches ago) has run: a word of pinned memory the stream stored to behind it
+            # (tn_mark_host).  With 32 slots the wait never happens in practice (the HIP runtime's own back-pressure stops the
+            # host a few steps ahead of the GPU), and it sleeps instead of spinning: see _lib.HostMarks
+            self._marks.wait(k)
+        host, dev = slot
         out = []
         for (src, dt, shape), o in zip(parts, offs):
             n = math.prod(shape) * torch.empty(0, dtype=dt).element_size()
-            view = host[o:o + n].view(dt).view(shape)
-            if tuple(src.shape) == tuple(shape):
-                view.copy_(src)
+            # numpy, not torch, for the host-side copies: a torch CPU op over more than 32 k elements (the time masks) wakes
+            # the intra-op thread pool — one thread per VISIBLE core (256 on the GPU boxes), all spinning for a few ms after the
+            # op — which burns through the container's CPU quota (16 cores) and gets the whole process frozen for the rest of the
+            # 100 ms accounting period, mid launch sequence (round 4: 60-85 ms GPU-idle gaps on the configs[3] leg)
+            view = host[o:o + n].view(dt).view(shape).numpy()
+            src_np = src.detach().cpu().numpy() if isinstance(src, torch.Tensor) else src
+            if tuple(src_np.shape) == tuple(shape):
+                view[...] = src_np
             else:                                      # time masks narrower than the padded batch: zero beyond them
-                view.zero_()
-                view[:, :src.shape[1]].copy_(src)
+                view[...] = 0
+                view[:, :src_np.shape[1]] = src_np
             out.append(dev[o:o + n].view(dt).view(shape))
         dev[:total].copy_(host[:total], non_blocking=True)
-        ev.record(torch.cuda.current_stream(self.device))
+        self._marks.mark(k, torch.cuda.current_stream(self.device).cuda_stream)
         return out
 
     def _mel(self):
