@@ -319,10 +319,10 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     p->wg2_layers += p->wg2_asp_units;
     p->wg2_grid = 256;
     p->wg2_desc = b.take((size_t)2 * p->wg2_layers * 256);   // two tables, >= sizeof(WgradV2Desc) per unit (checked at upload)
-    p->se_gu = b.take((size_t)batch * 2 * 256 * sizeof(float));
     p->wg2_out = b.take((size_t)p->wg2_layers * 32);
     p->dw_table = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * 32);
   }
+  if (precision == TN_PREC_BF16) p->se_gu = b.take((size_t)batch * 2 * H * sizeof(float));      // fused mega-block tail backward
   p->cast_table = b.take(sizeof(CastDesc) * (8 + (size_t)c.n_mega_blocks * (c.n_sub_blocks + 1)));
   p->swz_table = b.take(sizeof(SwzDesc) * (2 * (size_t)c.n_mega_blocks * (c.n_sub_blocks + 1) + 8));
   p->bn_table = b.take(sizeof(BnUpdateDesc) * m->n_bn);

@@ -104,11 +104,14 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   // dS^T * Q straight into the gradient buffer), layer by layer
   const bool pipe = sizeof(AT) == 2 && !use_v2 && p->wide_wgrad && training && H % 256 == 0 && D % 256 == 0;
   const bool batched_wgrad = sizeof(AT) == 2 && use_v2 && training && p->wg2_layers > 0;
+  // act_out (fused tail, the last sub-block of a mega block): dz already holds dS (bn_bwd_apply_z3_kernel rebuilt the layer's
+  // incoming gradient from the tail's dZ before the skip path's in-place pass overwrote that)
   auto pipe_layer = [&](size_t dz, size_t y, const BnRef& bn, int Cout, const WcRef& wc, int Cin, size_t dx_out, const void* q, bool q_plain,
-                        const BnAct& qact, int64_t wgrad_off) -> int {
+                        const BnAct& qact, int64_t wgrad_off, const BnAct* act_out = nullptr) -> int {
     DBG("pipe dZ in", dz, (size_t)M * Cout); DBG("pipe Y", y, (size_t)M * Cout);
     DBGF("pipe bsums", ws + p->bsums[bn.id], TN_NREP * 2 * Cout); DBGF("pipe fstats", ws + p->stats[bn.id], TN_NREP * 2 * Cout);
-    int rc = launch_bn_bwd_apply((bf16_t*)(ws + dz), (const bf16_t*)(ws + y), make_bnbwd(p, bn, M, training), M, Cout, st);
+    int rc = 0;
+    if (!act_out) rc = launch_bn_bwd_apply((bf16_t*)(ws + dz), (const bf16_t*)(ws + y), make_bnbwd(p, bn, M, training), M, Cout, st);
     if (rc) return rc;
     DBG("pipe dS", dz, (size_t)M * Cout);
     GemmShape g{M, Cin, Cout, ws + wc.wt};
@@ -136,6 +139,9 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   // the weight-gradient launch): fixed-length training batches of the headline shape
   const bool fuse_tail = v2_bwd && batched_wgrad && H == V2_C && Hr == 16 && c.kernel == 3 && nsub >= 2 && !p->masked &&
                          p->tail_parts == 1 && p->se_gu != 0;
+  // ... and of the wide models on the pipelined path: the rebuild sits in the streaming pass that makes the stored dS operand
+  const bool fuse_tail_wide = pipe && (H == 512 || H == 1024) && Hr * 16 == H && nsub >= 2 && !p->masked && p->tail_parts == 1 &&
+                              p->se_gu != 0 && !getenv("TN_DBG_NO_FUSE_WIDE");
   const int nb = c.n_mega_blocks;
   const int per_blk = nsub + 1;
   int rc_fin = 0;
@@ -387,7 +393,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       }
       int rc1 = -1000;
       float* dgate_out = (float*)(ws + ((v2_bwd && Hr == 16) ? bw.dgate : bw.dpre2));
-      if (fuse_tail) {
+      if (fuse_tail || fuse_tail_wide) {
         CombineBwd1V3Args c3;
         memset(&c3, 0, sizeof(c3));
         CombineBwd1V2Args& c1 = c3.a1;
@@ -398,8 +404,15 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         c3.hid = (const float*)(ws + bw.h); c3.W1 = params + mb.se_w1; c3.W2 = params + mb.se_w2;
         c3.dpre2 = (float*)(ws + bw.dpre2); c3.dpre1 = (float*)(ws + bw.dpre1); c3.gu = (float*)(ws + p->se_gu);
         c3.bsums3 = bsum(mb.sub[nsub - 1].bn);
-        const int rc = launch_combine_bwd1_v3(c3, B, st);
+        int rc = launch_combine_bwd1_v3(c3, B, H, st);
         if (rc) return rc == -1000 ? TN_E_UNSUPPORTED : rc;
+        if (fuse_tail_wide) {
+          // dS of the last sub-block NOW: the skip connection's BatchNorm-backward pass below works in place on dZk
+          rc = launch_bn_bwd_apply_z3((const bf16_t*)(ws + bw.dZk), (const bf16_t*)(ws + bw.Y[nsub - 1]),
+                                      make_bnbwd(p, mb.sub[nsub - 1].bn, M, training), act3, (const float*)(ws + p->se_gu),
+                                      (bf16_t*)(ws + bw.dY[nsub - 1]), M, H, T, st);
+          if (rc) return rc;
+        }
       } else {
       if (sizeof(AT) == 2 && v2_bwd && H == V2_C) {
         CombineBwd1V2Args c1;
@@ -524,7 +537,9 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         continue;
       }
       if (pipe) {
-        int rc = pipe_layer(bw.dY[j], bw.Y[j], sb.bn, H, bw.wpw[j], H, p->dD, ws + bw.Q[j], true, identity_act(), sb.wpw);
+        const bool z3 = fuse_tail_wide && j == nsub - 1;
+        int rc = pipe_layer(bw.dY[j], bw.Y[j], sb.bn, H, bw.wpw[j], H, p->dD, ws + bw.Q[j], true, identity_act(), sb.wpw,
+                            z3 ? &act3 : nullptr);
         if (rc) return rc;
       } else {
         GemmShape g{M, H, H, wt(bw.wpw[j])};

@@ -491,56 +491,63 @@ struct CombineBwd1V3Args {
   float* gu;                 // [B][2][256]: ga, ub
   float* bsums3;
 };
-template <int FL3, bool DROP>
+// CH = hidden width (256: TitaNet-S; 512 / 1024: the wide models, whose last sub-block rebuilds the gradient in
+// bn_bwd_apply_z3_kernel).  512 threads = (CH / 8 channel vectors) x TG row groups; dynamic LDS: 8 CH constants + [NS][6][CH] partial sums.
+template <int FL3, bool DROP, int CH>
 __global__ __launch_bounds__(512) void combine_bwd1_v3_kernel(CombineBwd1V3Args aa) {
-  constexpr int HR = 16;
+  constexpr int HR = CH / 16, CV = CH / 8, TG = 512 / CV, NS = CH == 256 ? 8 : TG, PT = (CH + 511) / 512;
   const CombineBwd1V2Args& a = aa.a1;
-  __shared__ float cst[8 * V2_C];        // sc3, sh3, scS, shS, meanS, rstdS, mean3*rstd3, rstd3
-  __shared__ float part[8][6][V2_C];     // per wave: B1..B4, skip sums
-  __shared__ float p2[V2_C], p1[HR];
-  const int tid = threadIdx.x, vc = tid & 31, tg = tid >> 5, c0 = vc * 8;
+  extern __shared__ __attribute__((aligned(16))) float cb3_smem[];
+  float* cst = cb3_smem;                 // sc3, sh3, scS, shS, meanS, rstdS, mean3*rstd3, rstd3 : [8][CH]
+  float* part = cst + 8 * CH;            // [NS][6][CH]: B1..B4, skip sums
+  float* p2 = part + NS * 6 * CH;        // [CH]
+  float* p1 = p2 + CH;                   // [HR]
+  const int tid = threadIdx.x, vc = tid % CV, tg = tid / CV, c0 = vc * 8;
   const int lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
-  if (tid < V2_C) {
+  for (int c = tid; c < CH; c += 512) {
     float s = 1.f, h = 0.f, ss, hs, ms, rs, m3 = 0.f, r3 = 1.f;
-    if (FL3 & 1) { bn_scale_shift(a.act3, V2_C, tid, s, h); bn_mean_rstd(a.act3, V2_C, tid, m3, r3); }
-    bn_scale_shift(a.actS, V2_C, tid, ss, hs);
-    bn_mean_rstd(a.actS, V2_C, tid, ms, rs);
-    cst[tid] = s; cst[V2_C + tid] = h; cst[2 * V2_C + tid] = ss; cst[3 * V2_C + tid] = hs; cst[4 * V2_C + tid] = ms; cst[5 * V2_C + tid] = rs;
-    cst[6 * V2_C + tid] = m3 * r3; cst[7 * V2_C + tid] = r3;
+    if (FL3 & 1) { bn_scale_shift(a.act3, CH, c, s, h); bn_mean_rstd(a.act3, CH, c, m3, r3); }
+    bn_scale_shift(a.actS, CH, c, ss, hs);
+    bn_mean_rstd(a.actS, CH, c, ms, rs);
+    cst[c] = s; cst[CH + c] = h; cst[2 * CH + c] = ss; cst[3 * CH + c] = hs; cst[4 * CH + c] = ms; cst[5 * CH + c] = rs;
+    cst[6 * CH + c] = m3 * r3; cst[7 * CH + c] = r3;
   }
   __syncthreads();
   float k3[8], h3[8], kS[8], hS[8], m8[8], r8[8], g8[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    k3[i] = cst[c0 + i]; h3[i] = cst[V2_C + c0 + i]; kS[i] = cst[2 * V2_C + c0 + i]; hS[i] = cst[3 * V2_C + c0 + i];
-    m8[i] = cst[4 * V2_C + c0 + i]; r8[i] = cst[5 * V2_C + c0 + i]; g8[i] = a.gate[(size_t)b * V2_C + c0 + i];
+    k3[i] = cst[c0 + i]; h3[i] = cst[CH + c0 + i]; kS[i] = cst[2 * CH + c0 + i]; hS[i] = cst[3 * CH + c0 + i];
+    m8[i] = cst[4 * CH + c0 + i]; r8[i] = cst[5 * CH + c0 + i]; g8[i] = a.gate[(size_t)b * CH + c0 + i];
   }
   const uint32_t dkey3 = tn_act_key(a.act3), dthr3 = a.act3.drop_thr;
   const uint32_t okey = a.key_add ? a.drop_key + *a.key_add : a.drop_key;
-  // operands of the SE backward at the end (they do not depend on the row loop): requested now, so that the serial tail of
-  // the workgroup — every workgroup reaches it at the same time — does not wait for three dependent global round trips
-  float w2r[2][4], hidr[2], w1r[HR];
+  // operands of the SE backward at the end (they do not depend on the row loop): requested now (hidden 256), so that the
+  // serial tail of the workgroup — every workgroup reaches it at the same time — does not wait for dependent global round trips
+  constexpr bool PRE = CH == 256;
+  float w2r[PRE ? 2 : 1][4], hidr[2], w1r[PRE ? HR : 1];
+  if (PRE) {
 #pragma unroll
-  for (int jj = 0; jj < 2; ++jj) {
-    const int j = wave + 8 * jj;
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = wave + 8 * jj;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) w2r[jj][k] = aa.W2[(size_t)(lane + 64 * k) * HR + j];
-    hidr[jj] = aa.hid[(size_t)b * HR + j];
+      for (int k = 0; k < 4; ++k) w2r[PRE ? jj : 0][k] = aa.W2[(size_t)(lane + 64 * k) * HR + j];
+      hidr[jj] = aa.hid[(size_t)b * HR + j];
+    }
+#pragma unroll
+    for (int j = 0; j < (PRE ? HR : 1); ++j) w1r[j] = aa.W1[(size_t)j * CH + (tid & 255)];
   }
-#pragma unroll
-  for (int j = 0; j < HR; ++j) w1r[j] = aa.W1[(size_t)j * V2_C + (tid & 255)];
   float b1[8], b2[8], b3[8], b4[8], s1[8], s2[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { b1[i] = 0.f; b2[i] = 0.f; b3[i] = 0.f; b4[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
   constexpr int U = 4;
-  for (int tb = tg; tb < a.T; tb += 16 * U) {
+  for (int tb = tg; tb < a.T; tb += TG * U) {
     uint4 rd[U], ry[U], rs[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int t = tb + 16 * u;
+      const int t = tb + TG * u;
       if (t < a.T) {
-        const size_t o = ((size_t)b * a.T + t) * V2_C + c0;
+        const size_t o = ((size_t)b * a.T + t) * CH + c0;
         rd[u] = *reinterpret_cast<const uint4*>(a.dOUT + o);
         ry[u] = *reinterpret_cast<const uint4*>(a.Y3 + o);
         rs[u] = *reinterpret_cast<const uint4*>(a.S + o);
@@ -548,7 +555,7 @@ __global__ __launch_bounds__(512) void combine_bwd1_v3_kernel(CombineBwd1V3Args 
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int t = tb + 16 * u;
+      const int t = tb + TG * u;
       if (t < a.T) {
         const uint32_t row = (uint32_t)b * a.T + t;
         float d[8], y[8], ya[8], sv[8], m[8];
@@ -557,10 +564,18 @@ __global__ __launch_bounds__(512) void combine_bwd1_v3_kernel(CombineBwd1V3Args 
         unpack8(rs[u], sv);
 #pragma unroll
         for (int i = 0; i < 8; ++i) ya[i] = y[i];
-        act8_t<FL3>(ya, k3, h3, dkey3, dthr3, row, c0);
+        if (FL3 & 1) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ya[i] = fmaf(ya[i], k3[i], h3[i]);
+        }
+        if (FL3 & 2) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ya[i] = fmaxf(ya[i], 0.f);
+        }
+        if (FL3 & 4) tn_drop8(ya, (row * (uint32_t)CH + (uint32_t)c0) >> 3, dkey3, dthr3);
 #pragma unroll
         for (int i = 0; i < 8; ++i) m[i] = (fmaf(sv[i], kS[i], fmaf(g8[i], ya[i], hS[i])) > 0.f) ? a.inv_keep : 0.f;
-        if (DROP) tn_drop8(m, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, okey, a.drop_thr);
+        if (DROP) tn_drop8(m, (row * (uint32_t)CH + (uint32_t)c0) >> 3, okey, a.drop_thr);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float z = d[i] * m[i];
@@ -574,81 +589,186 @@ __global__ __launch_bounds__(512) void combine_bwd1_v3_kernel(CombineBwd1V3Args 
           b3[i] += on3 ? 1.f : 0.f;
           b4[i] += ym;
         }
-        store8(a.dZ + (size_t)row * V2_C + c0, d);
+        store8(a.dZ + (size_t)row * CH + c0, d);
       }
     }
   }
-  // the two row groups of a wave (lanes l, l ^ 32) first, then the 8 waves through LDS
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    b1[i] += __shfl_xor(b1[i], 32, 64); b2[i] += __shfl_xor(b2[i], 32, 64); b3[i] += __shfl_xor(b3[i], 32, 64);
-    b4[i] += __shfl_xor(b4[i], 32, 64); s1[i] += __shfl_xor(s1[i], 32, 64); s2[i] += __shfl_xor(s2[i], 32, 64);
-  }
-  if (lane < 32) {
+  // hidden 256: the two row groups of a wave (lanes l, l ^ 32) first; then the row groups through LDS
+  if (CH == 256) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      part[wave][0][c0 + i] = b1[i]; part[wave][1][c0 + i] = b2[i]; part[wave][2][c0 + i] = b3[i];
-      part[wave][3][c0 + i] = b4[i]; part[wave][4][c0 + i] = s1[i]; part[wave][5][c0 + i] = s2[i];
+      b1[i] += __shfl_xor(b1[i], 32, 64); b2[i] += __shfl_xor(b2[i], 32, 64); b3[i] += __shfl_xor(b3[i], 32, 64);
+      b4[i] += __shfl_xor(b4[i], 32, 64); s1[i] += __shfl_xor(s1[i], 32, 64); s2[i] += __shfl_xor(s2[i], 32, 64);
+    }
+  }
+  if (CH != 256 || lane < 32) {
+    float* mine = part + (size_t)(CH == 256 ? wave : tg) * 6 * CH + c0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      mine[i] = b1[i]; mine[CH + i] = b2[i]; mine[2 * CH + i] = b3[i];
+      mine[3 * CH + i] = b4[i]; mine[4 * CH + i] = s1[i]; mine[5 * CH + i] = s2[i];
     }
   }
   __syncthreads();
   const int rep = blockIdx.x % TN_NREP;
-  float B1 = 0.f, B2 = 0.f, B3 = 0.f, B4 = 0.f, g = 0.f;
-  if (tid < V2_C) {
+  float B[PT][4], gg[PT];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { B1 += part[k][0][tid]; B2 += part[k][1][tid]; B3 += part[k][2][tid]; B4 += part[k][3][tid]; }
-    g = a.gate[(size_t)b * V2_C + tid];
-    const float dgate = fmaf(cst[tid], B2, cst[V2_C + tid] * B1);
-    const float d2 = dgate * g * (1.f - g);
-    p2[tid] = d2;
-    aa.dpre2[(size_t)b * V2_C + tid] = d2;
-  } else {
-    const int c = tid - V2_C;
-    float v1 = 0.f, v2 = 0.f;
+  for (int q = 0; q < PT; ++q) {
+    const int c = tid + 512 * q;
+    B[q][0] = B[q][1] = B[q][2] = B[q][3] = 0.f; gg[q] = 0.f;
+    if (c < CH) {
+      float v1 = 0.f, v2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { v1 += part[k][4][c]; v2 += part[k][5][c]; }
-    atomic_add_f32(&a.bsumsS[(size_t)(rep * 2 + 0) * V2_C + c], v1);
-    atomic_add_f32(&a.bsumsS[(size_t)(rep * 2 + 1) * V2_C + c], v2);
+      for (int k = 0; k < NS; ++k) {
+        const float* pk = part + (size_t)k * 6 * CH + c;
+        B[q][0] += pk[0]; B[q][1] += pk[CH]; B[q][2] += pk[2 * CH]; B[q][3] += pk[3 * CH]; v1 += pk[4 * CH]; v2 += pk[5 * CH];
+      }
+      atomic_add_f32(&a.bsumsS[(size_t)(rep * 2 + 0) * CH + c], v1);
+      atomic_add_f32(&a.bsumsS[(size_t)(rep * 2 + 1) * CH + c], v2);
+      const float g = a.gate[(size_t)b * CH + c];
+      gg[q] = g;
+      const float dgate = fmaf(cst[c], B[q][1], cst[CH + c] * B[q][0]);
+      const float d2 = dgate * g * (1.f - g);
+      p2[c] = d2;
+      aa.dpre2[(size_t)b * CH + c] = d2;
+    }
   }
   __syncthreads();
-  // p1[j] = relu'(hid[j]) * sum_c W2[c][j] p2[c]  (2 outputs per wave)
+  // p1[j] = relu'(hid[j]) * sum_c W2[c][j] p2[c]  (HR / 8 outputs per wave)
 #pragma unroll
-  for (int jj = 0; jj < 2; ++jj) {
+  for (int jj = 0; jj < HR / 8; ++jj) {
     const int j = wave + 8 * jj;
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s = fmaf(w2r[jj][k], p2[lane + 64 * k], s);
+    for (int k = 0; k < CH / 64; ++k) s = fmaf(PRE ? w2r[PRE ? jj : 0][PRE ? k : 0] : aa.W2[(size_t)(lane + 64 * k) * HR + j], p2[lane + 64 * k], s);
     s = wave_sum(s);
     if (lane == 0) {
-      s = (hidr[jj] > 0.f) ? s : 0.f;
+      s = ((PRE ? hidr[PRE ? jj : 0] : aa.hid[(size_t)b * HR + j]) > 0.f) ? s : 0.f;
       p1[j] = s;
       aa.dpre1[(size_t)b * HR + j] = s;
     }
   }
   __syncthreads();
-  if (tid < V2_C) {
-    float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < HR; ++j) s = fmaf(w1r[j], p1[j], s);
-    const float on = (FL3 & 4) ? a.act3.inv_keep : 1.f;
-    const float ga = g * on, ub = s / (float)a.T * on;
-    aa.gu[((size_t)b * 2 + 0) * V2_C + tid] = ga;
-    aa.gu[((size_t)b * 2 + 1) * V2_C + tid] = ub;
-    const float sv = fmaf(ga, B1, ub * B3), sy = fmaf(ga, B2, ub * B4);
-    atomic_add_f32(&aa.bsums3[(size_t)(rep * 2 + 0) * V2_C + tid], sv);
-    atomic_add_f32(&aa.bsums3[(size_t)(rep * 2 + 1) * V2_C + tid], cst[7 * V2_C + tid] * sy - cst[6 * V2_C + tid] * sv);
+  for (int q = 0; q < PT; ++q) {
+    const int c = tid + 512 * q;
+    if (c < CH) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < HR; ++j) s = fmaf(PRE ? w1r[PRE ? j : 0] : aa.W1[(size_t)j * CH + c], p1[j], s);
+      const float on = (FL3 & 4) ? a.act3.inv_keep : 1.f;
+      const float ga = gg[q] * on, ub = s / (float)a.T * on;
+      aa.gu[((size_t)b * 2 + 0) * CH + c] = ga;
+      aa.gu[((size_t)b * 2 + 1) * CH + c] = ub;
+      const float sv = fmaf(ga, B[q][0], ub * B[q][2]), sy = fmaf(ga, B[q][1], ub * B[q][3]);
+      atomic_add_f32(&aa.bsums3[(size_t)(rep * 2 + 0) * CH + c], sv);
+      atomic_add_f32(&aa.bsums3[(size_t)(rep * 2 + 1) * CH + c], cst[7 * CH + c] * sy - cst[6 * CH + c] * sv);
+    }
   }
 }
 // -1000: no specialisation for this flag combination
-inline int launch_combine_bwd1_v3(const CombineBwd1V3Args& aa, int B, hipStream_t st) {
+template <int CH>
+inline int launch_combine_bwd1_v3_c(const CombineBwd1V3Args& aa, int B, hipStream_t st) {
   const CombineBwd1V2Args& a = aa.a1;
   const int fl3 = (a.act3.mode != 0 ? 1 : 0) | (a.act3.relu ? 2 : 0) | (a.act3.drop_thr ? 4 : 0);
   if (a.act3.rm.len || a.parts != 1) return -1000;
+  constexpr int CV = CH / 8, TG = 512 / CV, NS = CH == 256 ? 8 : TG;
+  const size_t smem = (size_t)(8 * CH + NS * 6 * CH + CH + CH / 16) * sizeof(float);
   const dim3 grid(B), blk(512);
-  if (fl3 == 7 && a.drop_thr) hipLaunchKernelGGL((combine_bwd1_v3_kernel<7, true>), grid, blk, 0, st, aa);
-  else if (fl3 == 3 && !a.drop_thr) hipLaunchKernelGGL((combine_bwd1_v3_kernel<3, false>), grid, blk, 0, st, aa);
-  else return -1000;
+  if (fl3 == 7 && a.drop_thr) {
+    auto kern = combine_bwd1_v3_kernel<7, true, CH>;
+    TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, grid, blk, smem, st, aa);
+  } else if (fl3 == 3 && !a.drop_thr) {
+    auto kern = combine_bwd1_v3_kernel<3, false, CH>;
+    TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, grid, blk, smem, st, aa);
+  } else return -1000;
   return (int)hipGetLastError();
+}
+inline int launch_combine_bwd1_v3(const CombineBwd1V3Args& aa, int B, int C, hipStream_t st) {
+  switch (C) {
+    case 256: return launch_combine_bwd1_v3_c<256>(aa, B, st);
+    case 512: return launch_combine_bwd1_v3_c<512>(aa, B, st);
+    case 1024: return launch_combine_bwd1_v3_c<1024>(aa, B, st);
+    default: return -1000;
+  }
+}
+
+// dS = BatchNorm-backward(dYbn, Y) with dYbn = (dZ ga[b] + ub[b]) [act3(Y) > 0] rebuilt on the fly from the tail's dZ
+// (combine_bwd1_v3): the wide models' form of dgrad_dw_v6<.., Z3> — the streaming pass that makes the stored dS operand of
+// the two pipelined GEMMs reads the tail's gradient directly, and the second tail pass (3 tensor passes per mega block) is gone.
+// One workgroup = (utterance, 64-frame chunk); a thread keeps the constants of its 8 channels — k0 k1 k2, sc3 sh3 and the
+// utterance's ga / ub — in registers and walks the chunk's rows (a flat grid-stride loop re-read ga / ub, 64 bytes of
+// float32 per 16 bytes of gradient, for every vector: 79 us against 47 for the plain pass at hidden 512).
+template <bool DROP3, int CH>
+__global__ __launch_bounds__(256) void bn_bwd_apply_z3_kernel(const bf16_t* __restrict__ dZ, const bf16_t* __restrict__ Y, BnBwd bn, BnAct act3,
+                                                              const float* __restrict__ gu, bf16_t* __restrict__ dS, int T, int chunk) {
+  constexpr int VC = CH / 8, RG = 256 / VC;       // channel vectors per row, row groups per workgroup
+  __shared__ __attribute__((aligned(16))) float pg_k[5 * CH];      // k0, k1, k2, sc3, sh3
+  for (int c = threadIdx.x; c < CH; c += 256) {
+    bn_bwd_coefs(bn, CH, c, pg_k[c], pg_k[CH + c], pg_k[2 * CH + c]);
+    bn_scale_shift(act3, CH, c, pg_k[3 * CH + c], pg_k[4 * CH + c]);
+  }
+  __syncthreads();
+  const uint32_t dkey3 = tn_act_key(act3), dthr3 = act3.drop_thr;
+  const int b = blockIdx.y, vc = threadIdx.x % VC, rg = threadIdx.x / VC, c0 = vc * 8;
+  float k0[8], k1[8], k2[8], s3[8], h3[8], ga[8], ub[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    k0[u] = pg_k[c0 + u]; k1[u] = pg_k[CH + c0 + u]; k2[u] = pg_k[2 * CH + c0 + u]; s3[u] = pg_k[3 * CH + c0 + u]; h3[u] = pg_k[4 * CH + c0 + u];
+  }
+  load8(gu + (size_t)b * 2 * CH + c0, ga);
+  load8(gu + (size_t)b * 2 * CH + CH + c0, ub);
+  const int t0 = blockIdx.x * chunk, t1 = min(T, t0 + chunk);
+  constexpr int U = 4;
+  for (int tb = t0 + rg; tb < t1; tb += RG * U) {
+    uint4 rz[U], ry[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int t = tb + RG * q;
+      if (t < t1) {
+        const size_t o = ((size_t)b * T + t) * CH + c0;
+        rz[q] = *reinterpret_cast<const uint4*>(dZ + o);
+        ry[q] = *reinterpret_cast<const uint4*>(Y + o);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int t = tb + RG * q;
+      if (t < t1) {
+        const uint32_t row = (uint32_t)b * T + t;
+        float z[8], y[8], m[8];
+        unpack8(rz[q], z);
+        unpack8(ry[q], y);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m[u] = (fmaf(y[u], s3[u], h3[u]) > 0.f) ? 1.f : 0.f;
+        if (DROP3) tn_drop8(m, (row * (uint32_t)CH + (uint32_t)c0) >> 3, dkey3, dthr3);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float v = fmaf(z[u], ga[u], ub[u]) * m[u];
+          z[u] = fmaf(k0[u], v, fmaf(k1[u], y[u], k2[u]));
+        }
+        store8(dS + (size_t)row * CH + c0, z);
+      }
+    }
+  }
+}
+template <int CH>
+inline int launch_bn_bwd_apply_z3_c(const bf16_t* dZ, const bf16_t* Y, const BnBwd& bn, const BnAct& act3, const float* gu, bf16_t* dS, int M,
+                                    int T, hipStream_t st) {
+  const int chunk = 64;
+  const dim3 grid((T + chunk - 1) / chunk, M / T);
+  if (act3.drop_thr) hipLaunchKernelGGL((bn_bwd_apply_z3_kernel<true, CH>), grid, dim3(256), 0, st, dZ, Y, bn, act3, gu, dS, T, chunk);
+  else hipLaunchKernelGGL((bn_bwd_apply_z3_kernel<false, CH>), grid, dim3(256), 0, st, dZ, Y, bn, act3, gu, dS, T, chunk);
+  return (int)hipGetLastError();
+}
+inline int launch_bn_bwd_apply_z3(const bf16_t* dZ, const bf16_t* Y, const BnBwd& bn, const BnAct& act3, const float* gu, bf16_t* dS, int M,
+                                  int C, int T, hipStream_t st) {
+  if (bn.rm.len || act3.mode == 0 || !act3.relu || M % T) return TN_E_UNSUPPORTED;
+  if (C == 512) return launch_bn_bwd_apply_z3_c<512>(dZ, Y, bn, act3, gu, dS, M, T, st);
+  if (C == 1024) return launch_bn_bwd_apply_z3_c<1024>(dZ, Y, bn, act3, gu, dS, M, T, st);
+  return TN_E_UNSUPPORTED;
 }
 
 // ------------------------------------------------------------------------------------------
