@@ -323,6 +323,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     p->dw_table = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * 32);
   }
   if (precision == TN_PREC_BF16) p->se_gu = b.take((size_t)batch * 2 * H * sizeof(float));      // fused mega-block tail backward
+  if (p->wide_wgrad) p->tn_table = b.take((size_t)c.n_mega_blocks * (c.n_sub_blocks + 1) * 64);   // >= sizeof(PGemmTnDesc) each
   p->cast_table = b.take(sizeof(CastDesc) * (8 + (size_t)c.n_mega_blocks * (c.n_sub_blocks + 1)));
   p->swz_table = b.take(sizeof(SwzDesc) * (2 * (size_t)c.n_mega_blocks * (c.n_sub_blocks + 1) + 8));
   p->bn_table = b.take(sizeof(BnUpdateDesc) * m->n_bn);

@@ -107,7 +107,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   // act_out (fused tail, the last sub-block of a mega block): dz already holds dS (bn_bwd_apply_z3_kernel rebuilt the layer's
   // incoming gradient from the tail's dZ before the skip path's in-place pass overwrote that)
   auto pipe_layer = [&](size_t dz, size_t y, const BnRef& bn, int Cout, const WcRef& wc, int Cin, size_t dx_out, const void* q, bool q_plain,
-                        const BnAct& qact, int64_t wgrad_off, const BnAct* act_out = nullptr) -> int {
+                        const BnAct& qact, int64_t wgrad_off, const BnAct* act_out = nullptr, bool defer_tn = false) -> int {
     DBG("pipe dZ in", dz, (size_t)M * Cout); DBG("pipe Y", y, (size_t)M * Cout);
     DBGF("pipe bsums", ws + p->bsums[bn.id], TN_NREP * 2 * Cout); DBGF("pipe fstats", ws + p->stats[bn.id], TN_NREP * 2 * Cout);
     int rc = 0;
@@ -122,6 +122,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     rc = launch_pgemm_nt(g, pa, pe, st);
     if (rc) return rc;
     DBG("pipe dX", dx_out, (size_t)M * Cin);
+    if (q_plain && defer_tn) return 0;      // its weight gradient rides in the bucket's batched launch (finalize_bucket)
     if (q_plain) {
       PGemmTnArgs ta{(const bf16_t*)(ws + dz), Cout, Cout, (const bf16_t*)q, Cin, Cin, M, grads + wgrad_off, Cin, 0, 0, rowtiles, listed ? p->n_rowtiles : 0};
       ProfScope ps(p, TN_PROF_BWD_WGRAD, st);
@@ -133,6 +134,13 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   };
   // (a row mask on an otherwise plain operand is moot here: its partner dS is zero on the padding rows)
   auto is_plain = [](const BnAct& a) { return a.mode == 0 && !a.relu && !a.drop_thr; };
+  // wide models: the pointwise weight gradients of the mega blocks in ONE pipelined launch per gradient bucket
+  // (pgemm_tn_batched_kernel: ~2 atomic flushes per workgroup and step instead of one per layer)
+  const bool tn_batched = pipe && p->tn_table != 0;
+  // table layout (plan_upload_bwd_tables): blocks from the last down, per block the skip conv (blocks > 0), then the
+  // sub-blocks from the last down
+  auto tn_entries = [&](int blk) { return nsub + (blk > 0 ? 1 : 0); };
+  auto tn_offset = [&](int blk) { int o = 0; for (int k = c.n_mega_blocks - 1; k > blk; --k) o += tn_entries(k); return o; };
   const bool v2_bwd = sizeof(AT) == 2 && use_v2;
   // round 4: the mega-block tail backward in ONE pass (combine_bwd1_v3 finishes the SE backward per utterance; the last
   // sub-block's fused data-gradient kernel rebuilds its incoming gradient on load and stores the BatchNorm-backward'd dS for
@@ -170,6 +178,14 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     if (v2_bwd && has_blocks)
       hipLaunchKernelGGL(dw_grad_finalize_kernel, dim3((bk.blk_hi - bk.blk_lo + 1) * nsub), dim3(256), 0, st,
                          (const DwGradOut*)(ws + p->dw_table) + (size_t)bk.blk_lo * nsub, c.kernel);
+    if (tn_batched && has_blocks) {
+      const int first = tn_offset(bk.blk_hi), count = tn_offset(bk.blk_lo) + tn_entries(bk.blk_lo) - first;
+      const bool listed = p->masked && p->n_rowtiles > 0;
+      ProfScope ps(p, TN_PROF_BWD_WGRAD, st);
+      const int rc = launch_pgemm_tn_batched((const PGemmTnDesc*)(ws + p->tn_table) + first, count, M, (H / 256) * (H / 256),
+                                             listed ? (const int*)(ws + p->rowtiles) : nullptr, listed ? p->n_rowtiles : 0, st);
+      if (rc) { rc_fin = rc; return; }
+    }
     if (batched_wgrad) {
       const int upb = per_blk * p->wg2_upl;      // weight-gradient units per mega block
       int first = has_blocks ? bk.blk_lo * upb : nb * upb;
@@ -464,7 +480,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     DBG("block dOUT", p->dA[cur], (size_t)M * H); DBG("combine dZk", bw.dZk, (size_t)M * H); DBG("combine dY3", bw.dY[nsub - 1], (size_t)M * H);
     // ---- skip connection: d S = BN-backward(dZ); dXs = dS * W_skip; d W_skip = dS^T X
     if (pipe) {
-      int rc = pipe_layer(bw.dZk, bw.S, mb.bnskip, H, bw.wskip, H, p->dXs, xin, is_plain(actx), actx, mb.wskip);
+      int rc = pipe_layer(bw.dZk, bw.S, mb.bnskip, H, bw.wskip, H, p->dXs, xin, is_plain(actx), actx, mb.wskip, nullptr, tn_batched && i > 0);
       if (rc) return rc;
     } else
     {
@@ -539,7 +555,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       if (pipe) {
         const bool z3 = fuse_tail_wide && j == nsub - 1;
         int rc = pipe_layer(bw.dY[j], bw.Y[j], sb.bn, H, bw.wpw[j], H, p->dD, ws + bw.Q[j], true, identity_act(), sb.wpw,
-                            z3 ? &act3 : nullptr);
+                            z3 ? &act3 : nullptr, tn_batched);
         if (rc) return rc;
       } else {
         GemmShape g{M, H, H, wt(bw.wpw[j])};
@@ -657,6 +673,23 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
   }
   if (!sd.empty())
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->se_table, sd.data(), sd.size() * sizeof(SeGradDesc), hipMemcpyHostToDevice, st));
+  if (p->tn_table) {
+    const tn_config& c = m->cfg;
+    const int nsub = c.n_sub_blocks, H = c.hidden;
+    std::vector<PGemmTnDesc> td;
+    for (int i = c.n_mega_blocks - 1; i >= 0; --i) {
+      const BlockWs& bw = p->blk[i];
+      if (i > 0) td.push_back(PGemmTnDesc{(const bf16_t*)(p->ws + bw.dZk), (const bf16_t*)(p->ws + p->blk[i - 1].OUT),
+                                          p->grads + m->blocks[i].wskip, H, H, H, H / 256});
+      for (int j = nsub - 1; j >= 0; --j)
+        td.push_back(PGemmTnDesc{(const bf16_t*)(p->ws + bw.dY[j]), (const bf16_t*)(p->ws + bw.Q[j]), p->grads + m->blocks[i].sub[j].wpw,
+                                 H, H, H, H / 256});
+    }
+    if (sizeof(PGemmTnDesc) > 64) return TN_E_STATE;
+    if (!td.empty())
+      TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->tn_table, td.data(), td.size() * sizeof(PGemmTnDesc), hipMemcpyHostToDevice, st));
+    TN_CHECK_HIP(hipStreamSynchronize(st));
+  }
   if (p->use_v2 && p->wg2_layers > 0) {
     const tn_config& c = m->cfg;
     const int nsub = c.n_sub_blocks, M = p->M, H = c.hidden, hs = H / 256;

@@ -131,6 +131,8 @@ struct tn_plan {
   size_t wg2_desc, wg2_out, wg2_count, wg2_slabs;   // batched weight-gradient launch (v2); wg2_desc holds TWO tables of
                                                     // wg2_layers descriptors: [0] every unit from (dZ, Y), [1] the fused-tail
                                                     // flow (the last sub-block's unit reads the stored BatchNorm-backward'd dS)
+  size_t tn_table = 0;          // wide models: PGemmTnDesc table of the mega blocks' pointwise layers in backward order (batched
+                                // weight-gradient launch, one per gradient bucket), or 0
   size_t se_gu = 0;             // fused mega-block tail backward (combine_bwd1_v3): ga / ub [B][2][256] floats, one block at a time
   size_t dw_gacc, dw_table;                         // depthwise gradient accumulators [layer][NREP][KD+1][256] + finalize table
   int wg2_layers = 0, wg2_maxparts = 0, wg2_units_per_wg = 0, wg2_grid = 0, wg2_epi_slabs = 0, wg2_asp_units = 0;

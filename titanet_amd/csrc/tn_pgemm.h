@@ -369,24 +369,14 @@ struct PGemmTnArgs {
   int n_rowtiles;                   // 256-row tile only (P is zero on every padding row, so nothing is lost)
 };
 
-template <int DUMMY>
-__global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(PGemmTnArgs a) {
+// one (256 x 256 output slab (tp, tq), K steps [s0, s0 + nsteps)) segment of a workgroup: prologue, ring loop, atomic flush
+__device__ __forceinline__ void pg_tn_segment(const PGemmTnArgs& a, int tp, int tq, int s0, int nsteps, char* smem) {
   constexpr int NSTAGE = 4, TILE_B = 16384, STAGE_B = 2 * TILE_B, GRP = 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(tn_lds_char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wave >> 2, wb = wave & 3;
-  const int G = gridDim.x, v = pg_virtual_id(blockIdx.x, G);
-  const int tiles_q = a.nq / 256, units = (a.np / 256) * tiles_q;
-  const int unit = v % units, split = v / units;
-  const int tp = unit / tiles_q, tq = unit - tp * tiles_q;
   const int* __restrict__ rowtiles = a.rowtiles;
-  const int nsteps_all = rowtiles ? a.n_rowtiles * 8 : (a.rows + 31) / 32;
-  const int s0 = split * a.steps_per_split;
-  int nsteps = nsteps_all - s0;
-  nsteps = nsteps < a.steps_per_split ? nsteps : a.steps_per_split;
-  if (nsteps <= 0) return;                                         // workgroup-uniform
 
   const pg_i32x4_t psrd = pg_make_srd(a.P, (unsigned)((size_t)a.rows * a.ldp * 2));
   const pg_i32x4_t qsrd = pg_make_srd(a.Q, (unsigned)((size_t)a.rows * a.ldq * 2));
@@ -482,6 +472,80 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(PGemmTnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         atomic_add_f32(out + (size_t)(mi * 32 + cd_row(r, lane)) * a.ldo + nj * 32, acc[mi][nj][r]);
+}
+
+template <int DUMMY>
+__global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(PGemmTnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int G = gridDim.x, v = pg_virtual_id(blockIdx.x, G);
+  const int tiles_q = a.nq / 256, units = (a.np / 256) * tiles_q;
+  const int unit = v % units, split = v / units;
+  const int tp = unit / tiles_q, tq = unit - tp * tiles_q;
+  const int nsteps_all = a.rowtiles ? a.n_rowtiles * 8 : (a.rows + 31) / 32;
+  const int s0 = split * a.steps_per_split;
+  int nsteps = nsteps_all - s0;
+  nsteps = nsteps < a.steps_per_split ? nsteps : a.steps_per_split;
+  if (nsteps <= 0) return;                                         // workgroup-uniform
+  pg_tn_segment(a, tp, tq, s0, nsteps, smem);
+}
+
+// ==========================================================================================
+// pgemm_tn_batched_kernel (round 4): the weight gradients of MANY layers of one width in ONE launch at the end of backward
+// (per gradient bucket).  Layer by layer, 256 workgroups each end with 65536 f32 atomics — 12.6 - 16.7 M per layer, which at
+// hidden 512 takes as long as the contraction itself (the atomics resolve memory-side at ~0.2 G/us).  The BatchNorm-backward'd
+// gradients dS and the GEMM operands Q of every layer are kept anyway (one buffer per layer), so the contraction can wait:
+// here a GROUP of U = (H / 256)^2 workgroups (adjacent on one XCD: they share the P / Q slabs through its L2) walks a
+// contiguous range of the (layer, K step) space — unit u of the group accumulates slab u of whatever layer the range is in,
+// and flushes once per layer it touches: ~2 flushes per workgroup and STEP instead of one per layer.
+// ==========================================================================================
+struct PGemmTnDesc {
+  const bf16_t* P; const bf16_t* Q; float* out;
+  int ldp, ldq, ldo, tiles_q;       // tiles_p * tiles_q == U for every descriptor of a launch
+};
+template <int DUMMY>
+__global__ __launch_bounds__(512, 2) void pgemm_tn_batched_kernel(const PGemmTnDesc* __restrict__ descs, int n_descs, int rows, int U,
+                                                                   int steps_per_group, const int* rowtiles, int n_rowtiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int G = gridDim.x, v = pg_virtual_id(blockIdx.x, G);
+  const int group = v / U, unit = v - group * U;
+  const int nsteps = rowtiles ? n_rowtiles * 8 : (rows + 31) / 32;
+  const long total = (long)n_descs * nsteps;
+  long pos = (long)group * steps_per_group;
+  long end = pos + steps_per_group;
+  end = end < total ? end : total;
+  while (pos < end) {
+    const int d = (int)(pos / nsteps), s0 = (int)(pos - (long)d * nsteps);
+    const long left = end - pos;
+    const int n = (int)(left < (long)(nsteps - s0) ? left : (long)(nsteps - s0));
+    PGemmTnArgs a;
+    a.P = descs[d].P; a.Q = descs[d].Q; a.out = descs[d].out;
+    a.ldp = descs[d].ldp; a.ldq = descs[d].ldq; a.ldo = descs[d].ldo;
+    a.rows = rows; a.rowtiles = rowtiles; a.n_rowtiles = n_rowtiles;
+    a.np = 0; a.nq = 0; a.splits = 0; a.steps_per_split = 0;
+    const int tq_n = descs[d].tiles_q;
+    pg_barrier();                       // the previous segment's last fragment reads are done before its ring is refilled
+    pg_tn_segment(a, unit / tq_n, unit % tq_n, s0, n, smem);
+    pos += n;
+  }
+}
+inline int launch_pgemm_tn_batched(const PGemmTnDesc* descs_dev, int n_descs, int rows, int U, const int* rowtiles, int n_rowtiles, hipStream_t st,
+                                   int max_wgs = 256) {
+  if (n_descs <= 0) return 0;
+  if (U <= 0 || U > max_wgs || rows <= 0) return TN_E_UNSUPPORTED;
+  const int nsteps = rowtiles ? n_rowtiles * 8 : (rows + 31) / 32;
+  if (nsteps <= 0) return 0;
+  const long total = (long)n_descs * nsteps;
+  int groups = max_wgs / U;
+  if ((long)groups > total) groups = (int)total;
+  const int spg = (int)((total + groups - 1) / groups);
+  groups = (int)((total + spg - 1) / spg);
+  int grid = groups * U;
+  // (pg_virtual_id keeps a group on one XCD only for grids that are multiples of 8; U is 4 or 16 and groups a power-of-two
+  //  fraction of 256 in practice)
+  auto kern = pgemm_tn_batched_kernel<0>;
+  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 131072, st, descs_dev, n_descs, rows, U, spg, rowtiles, n_rowtiles);
+  return (int)hipGetLastError();
 }
 
 inline int launch_pgemm_tn(PGemmTnArgs a, hipStream_t st, int max_wgs = 256) {
