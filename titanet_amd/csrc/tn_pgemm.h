@@ -94,15 +94,20 @@ struct PGemmEpiArgs {
 // (k bytes [16 h, 16 h + 16) and [32 + 16 h, 48 + 16 h) of the 64-k block, the same for both operands) are ONE 32-byte
 // operand of v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales): 8 MFMAs of 64 k per stage instead of 16 of 16 k, half the
 // DMA bytes and half the matrix-pipe time per unit of K.
-template <int DBG = 0, bool F8 = false>
+// HT: 128-row halves per output tile (2: 256 x 256 tiles; 1: 128 x 256 — twice the tiles, for shapes whose 256-row tile count
+// leaves a fifth of the chip idle in the last round, e.g. 600 tiles at 76800 x 512: 200 workgroups x 3 against 240 x 5)
+template <int DBG = 0, bool F8 = false, int HT = 2>
 __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtArgs pa, PGemmEpiArgs ea, int tiles_n, int total_tiles) {
   constexpr int BK = F8 ? 64 : 32, NSTAGE = 4;
   constexpr int ROWB = 64;                   // bytes of a tile row
   constexpr int CPR = ROWB / 16;             // 16-byte chunks per row
   constexpr int RPI = 64 / CPR;              // rows per DMA instruction (1 KiB)
-  constexpr int NQ = 256 / (8 * RPI);        // DMA instructions per wave, operand and stage
-  constexpr int TILE_B = 256 * ROWB, STAGE_B = 2 * TILE_B;
-  constexpr int GRP = 2 * NQ;                // DMA instructions per wave and K step
+  constexpr int TM = 128 * HT;               // rows of the output tile
+  constexpr int NQ = 256 / (8 * RPI);        // DMA instructions per wave and stage: weight tile
+  constexpr int NQA = TM / (8 * RPI);        // ... A tile
+  constexpr int TILE_A = TM * ROWB, TILE_B = TILE_A, STAGE_B = TILE_A + 256 * ROWB;     // (TILE_B: offset of the weight tile in a stage)
+  constexpr int GRP = NQ + NQA;              // DMA instructions per wave and K step
+  constexpr int STW = 32 * HT - 1;           // one less than the output stores a wave issues per tile
   constexpr int SWS = 2, SWM = CPR - 1;      // swizzle: chunk ^= (row >> SWS) & SWM
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(tn_lds_char*)smem;
@@ -126,16 +131,16 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
     for (int q = 0; q < NQ; ++q) {
       const int p = (q * 8 + wave) * RPI + dsub;                    // LDS row of the tile
       const int chunk = (DBG & 4) ? (lane % CPR) : ((lane % CPR) ^ ((p >> SWS) & SWM));
-      int ra = mt * 256 + p;
+      int ra = mt * TM + p;
       int rb = nt * 256 + (p & ~63) + 2 * (p & 31) + ((p >> 5) & 1);    // weight rows: 2 i + j at LDS row 32 j + i
       ra = ra < g.M ? ra : g.M - 1;            // rows outside the matrix: any valid row (their outputs are never stored)
       rb = rb < g.N ? rb : g.N - 1;
-      offA[q] = ((unsigned)ra * (unsigned)pa.lda) * ESZ + chunk * 16;       // bytes
+      if (q < NQA) offA[q] = ((unsigned)ra * (unsigned)pa.lda) * ESZ + chunk * 16;       // bytes
       offB[q] = ((unsigned)rb * (unsigned)g.K) * ESZ + chunk * 16;
     }
   };
   auto dma_a = [&](int q, int kt, int stage) {
-    tn_dma16(Ab + (size_t)offA[q] + kt * ROWB, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + (q * 8 + wave) * 1024)));
+    if (q < NQA) tn_dma16(Ab + (size_t)offA[q] + kt * ROWB, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + (q * 8 + wave) * 1024)));
   };
   auto dma_b = [&](int q, int kt, int stage) {
     tn_dma16(Wb + (size_t)offB[q] + kt * ROWB, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + TILE_B + (q * 8 + wave) * 1024)));
@@ -147,10 +152,10 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
   for (int ks = 0; ks < 2; ++ks) foff[ks] = fi * ROWB + ((((ks << 1) + fh) ^ ((fi >> SWS) & SWM)) << 4);
   const int abase = wm * 64 * ROWB, bbase = TILE_B + wn * 64 * ROWB;
 
-  f32x16_t acc[2][2][2];
+  f32x16_t acc[HT][2][2];
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < HT; ++h)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -197,14 +202,14 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
     const int kt_req = itile < total_tiles ? ikt : 0;
     {
       const char* st = smem + cstage * STAGE_B;
-      bf16x8_t af[2][4], bf[2][2];
+      bf16x8_t af[2][2 * HT], bf[2][2];
       auto read_frags = [&](int ks, int buf) {
         const char* ap = st + abase + foff[ks];
         const char* bp = st + bbase + foff[ks];
         bf[buf][0] = *reinterpret_cast<const bf16x8_t*>(bp);
         bf[buf][1] = *reinterpret_cast<const bf16x8_t*>(bp + 32 * ROWB);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[buf][i] = *reinterpret_cast<const bf16x8_t*>(ap + ((i >> 1) * 128 + (i & 1) * 32) * ROWB);
+        for (int i = 0; i < 2 * HT; ++i) af[buf][i] = *reinterpret_cast<const bf16x8_t*>(ap + ((i >> 1) * 128 + (i & 1) * 32) * ROWB);
       };
       read_frags(0, 0);
       if constexpr (F8) {
@@ -220,8 +225,9 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
         constexpr int SC1 = 0x7f7f7f7f;          // E8M0 127: block scale 1
         const i32x8_t b0 = join(bf[0][0], bf[1][0]), b1 = join(bf[0][1], bf[1][1]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (!(DBG & 2) && (i & 1) == 0) { dma_a(i >> 1, kt_req, istage); dma_b(i >> 1, kt_req, istage); }     // of the K step three ahead
+        for (int i = 0; i < 2 * HT; ++i) {
+          if (!(DBG & 2) && HT == 1) { dma_a(i, kt_req, istage); dma_b(i, kt_req, istage); }
+          if (!(DBG & 2) && HT == 2 && (i & 1) == 0) { dma_a(i >> 1, kt_req, istage); dma_b(i >> 1, kt_req, istage); }     // of the K step three ahead
           const i32x8_t a8 = join(af[0][i], af[1][i]);
           if (DBG & 1) {
             asm volatile("" ::"v"(a8), "v"(b0), "v"(b1));
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
         if (ks == 0) read_frags(1, 1);
         if (!(DBG & 2)) { dma_a(ks, kt_req, istage); dma_b(ks, kt_req, istage); }     // of the K step three ahead
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2 * HT; ++i) {
           if (DBG & 1) {
             asm volatile("" ::"v"(af[ks][i]), "v"(bf[ks][0]), "v"(bf[ks][1]));
           } else {
@@ -254,15 +260,15 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
       const int mt_ = rowtiles ? tn_sload_i32(rowtiles, mi_) : mi_;
       const int ncol = nt_ * 256 + wn * 64 + 2 * fi;               // this lane's channel pair
       const bool cols_ok = nt_ * 256 + wn * 64 < g.N;                 // wave-uniform (N is a multiple of 64)
-      const bool full_rows = mt_ * 256 + 256 <= g.M;
+      const bool full_rows = mt_ * TM + TM <= g.M;
       float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
       if (cols_ok) {
         const f32x2_t bv = *reinterpret_cast<const f32x2_t*>(cbias + ncol), cv = *reinterpret_cast<const f32x2_t*>(cbias + g.N + ncol);
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < HT; ++h)
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) {
-            const int rblk = mt_ * 256 + h * 128 + wm * 64 + mt * 32;     // first row of the 32-row block
+            const int rblk = mt_ * TM + h * 128 + wm * 64 + mt * 32;     // first row of the 32-row block
             const unsigned sbase = (unsigned)rblk * row_b + (unsigned)(nt_ * 256 + wn * 64) * 2;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
     // this wave's part of the next stage has landed.  The vmcnt queue retires in order: the two groups requested after it
     // may stay in flight, and so may this tile's 64 output stores (+ statistics atomics) while they are YOUNGER than the
     // group waited for: "at most 63 outstanding" then retires the DMA groups that precede them
-    if (fresh < 3) pg_wait<63>();
+    if (fresh < 3) pg_wait<STW>();
     else pg_wait<2 * GRP>();
     ++fresh;
     pg_barrier();           // ... everybody's part; and the stage refilled next is no longer read by anyone
@@ -309,20 +315,42 @@ template <int DBG = 0, bool F8 = false>
 inline int launch_pgemm_nt_t(const GemmShape& g, const PGemmNtArgs& pa, const PGemmEpiArgs& ea, hipStream_t st, int max_wgs, bool even_rounds = true) {
   if (g.K % (F8 ? 64 : 32) || g.K <= 0 || pa.lda % (F8 ? 16 : 8) || g.N % 64 || g.N > 3072 || ea.ldy % 2 || g.M <= 0) return TN_E_UNSUPPORTED;
   if ((long)g.M * pa.lda >= (1L << 32) || (long)g.N * g.K >= (1L << 32) || (long)g.M * ea.ldy * 2 >= (1L << 32)) return TN_E_UNSUPPORTED;
-  const int tiles_m = pa.rowtiles ? pa.n_rowtiles : (g.M + 255) / 256, tiles_n = (g.N + 255) / 256, total = tiles_m * tiles_n;
-  if (total <= 0) return 0;
+  const int tiles_n = (g.N + 255) / 256;
   // persistent workgroups with the same number of tiles each (1200 tiles: 240 x 5 beats 256 x 4.7, the last round of which
   // runs at 69 % occupancy: 201 vs 209 us), a multiple of 8 for the XCD-contiguous order
-  int grid = total < max_wgs ? total : max_wgs;
-  if (grid >= 8 && even_rounds) {
-    const int rounds = (total + grid - 1) / grid;
-    grid = (((total + rounds - 1) / rounds) + 7) & ~7;
-    if (grid > max_wgs) grid = max_wgs & ~7;
+  auto plan_grid = [&](int total) {
+    int grid = total < max_wgs ? total : max_wgs;
+    if (grid >= 8 && even_rounds) {
+      const int rounds = (total + grid - 1) / grid;
+      grid = (((total + rounds - 1) / rounds) + 7) & ~7;
+      if (grid > max_wgs) grid = max_wgs & ~7;
+    }
+    return grid;
+  };
+  const int total2 = (pa.rowtiles ? pa.n_rowtiles : (g.M + 255) / 256) * tiles_n;
+  if (total2 <= 0) return 0;
+  const int grid2 = plan_grid(total2);
+  // 128-row tiles when the 256-row partition would leave more than an eighth of the launch's workgroup-rounds empty
+  // (not with a row-tile list: those are 256-row tiles; not for the e4m3 form)
+  bool half = false;
+  int total = total2, grid = grid2;
+  if (!F8 && !pa.rowtiles && even_rounds && total2 >= max_wgs) {
+    const int rounds2 = (total2 + grid2 - 1) / grid2;
+    const double use2 = (double)total2 / ((double)rounds2 * max_wgs);
+    const int total1 = ((g.M + 127) / 128) * tiles_n, grid1 = plan_grid(total1), rounds1 = (total1 + grid1 - 1) / grid1;
+    const double use1 = (double)total1 / ((double)rounds1 * max_wgs);
+    if (use2 < 0.875 && use1 > use2 + 0.08) { half = true; total = total1; grid = grid1; }
   }
-  const size_t smem = (size_t)131072 + (size_t)2 * g.N * sizeof(float);
-  auto kern = pgemm_nt_kernel<DBG, F8>;
-  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g, pa, ea, tiles_n, total);
+  const size_t smem = (size_t)(half ? 98304 : 131072) + (size_t)2 * g.N * sizeof(float);
+  if (half) {
+    auto kern = pgemm_nt_kernel<DBG, F8, 1>;
+    TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g, pa, ea, tiles_n, total);
+  } else {
+    auto kern = pgemm_nt_kernel<DBG, F8, 2>;
+    TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g, pa, ea, tiles_n, total);
+  }
   return (int)hipGetLastError();
 }
 inline int launch_pgemm_nt(const GemmShape& g, const PGemmNtArgs& pa, const PGemmEpiArgs& ea, hipStream_t st, int max_wgs = 256) {
