@@ -170,6 +170,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   p->model = m;
   p->B = batch; p->T = frames; p->M = batch * frames; p->prec = precision;
   p->fp8 = precision == TN_PREC_FP8;
+  { const char* e = getenv("TN_FP8_BWD_EMU"); p->fp8_bwd_emu = p->fp8 && e && atoi(e) != 0; }
   if (p->fp8) precision = TN_PREC_BF16;      // storage, statistics and the backward pass are the bf16 plan's
   p->prec = precision;
   p->esz = precision == TN_PREC_BF16 ? 2 : 4;

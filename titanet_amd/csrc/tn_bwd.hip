@@ -111,7 +111,8 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     DBG("pipe dZ in", dz, (size_t)M * Cout); DBG("pipe Y", y, (size_t)M * Cout);
     DBGF("pipe bsums", ws + p->bsums[bn.id], TN_NREP * 2 * Cout); DBGF("pipe fstats", ws + p->stats[bn.id], TN_NREP * 2 * Cout);
     int rc = 0;
-    if (!act_out) rc = launch_bn_bwd_apply((bf16_t*)(ws + dz), (const bf16_t*)(ws + y), make_bnbwd(p, bn, M, training), M, Cout, st);
+    if (!act_out) rc = launch_bn_bwd_apply((bf16_t*)(ws + dz), (const bf16_t*)(ws + y), make_bnbwd(p, bn, M, training), M, Cout, st,
+                                            p->fp8_bwd_emu && Cout == H);
     if (rc) return rc;
     DBG("pipe dS", dz, (size_t)M * Cout);
     GemmShape g{M, Cin, Cout, ws + wc.wt};
@@ -149,7 +150,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
                          p->tail_parts == 1 && p->se_gu != 0;
   // ... and of the wide models on the pipelined path: the rebuild sits in the streaming pass that makes the stored dS operand
   const bool fuse_tail_wide = pipe && (H == 512 || H == 1024) && Hr * 16 == H && nsub >= 2 && !p->masked && p->tail_parts == 1 &&
-                              p->se_gu != 0 && !getenv("TN_DBG_NO_FUSE_WIDE");
+                              p->se_gu != 0 && !p->fp8_bwd_emu;      // (the e4m3 experiment rounds dS in the plain pass)
   const int nb = c.n_mega_blocks;
   const int per_blk = nsub + 1;
   int rc_fin = 0;

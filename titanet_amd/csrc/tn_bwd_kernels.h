@@ -1283,8 +1283,13 @@ __global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const float* __restr
 // GEMMs of a layer's backward read as a stored matrix (data gradient: dS * W, weight gradient: dS^T * Q).  One streaming pass
 // (2 reads + 1 write) instead of the transform inside two GEMM producers.
 // ==========================================================================================
+// EMU8 (experiment, TN_FP8_BWD_EMU=1 on an fp8 plan): dS is rounded through e4m3 with one power-of-two scale per ROW — what a
+// data-gradient / weight-gradient GEMM on the f8f6f4 MFMA would read — so that the accuracy of an fp8 backward can be
+// measured against the parity tests before its kernels exist (C = 512 / 1024 only: a row is one or two waves).
+template <bool EMU8>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ dZ, const bf16_t* __restrict__ Y, BnBwd bn, int M, int C) {
   extern __shared__ __attribute__((aligned(16))) float pg_k[];      // k0, k1, k2 : [3][C]
+  __shared__ float wmax[4];
   for (int c = threadIdx.x; c < C; c += 256) bn_bwd_coefs(bn, C, c, pg_k[c], pg_k[C + c], pg_k[2 * C + c]);
   __syncthreads();
   const int VC = C / 8;
@@ -1292,7 +1297,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ 
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
     const int c0 = (int)(i % VC) * 8;
     float z[8], y[8];
-    if (bn.rm.len && !tn_row_valid(bn.rm, (uint32_t)(i / VC))) {     // padding rows carry no gradient
+    if (!EMU8 && bn.rm.len && !tn_row_valid(bn.rm, (uint32_t)(i / VC))) {     // padding rows carry no gradient
 #pragma unroll
       for (int u = 0; u < 8; ++u) z[u] = 0.f;
       store8(dZ + i * 8, z);
@@ -1302,11 +1307,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ 
     load8(Y + i * 8, y);
 #pragma unroll
     for (int u = 0; u < 8; ++u) z[u] = fmaf(pg_k[c0 + u], z[u], fmaf(pg_k[C + c0 + u], y[u], pg_k[2 * C + c0 + u]));
+    if (EMU8) {
+      float m = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m = fmaxf(m, fabsf(z[u]));
+      m = wave_max(m);
+      if (VC == 128) {                      // hidden 1024: a row is two waves
+        const int w = threadIdx.x >> 6;
+        wmax[w] = m;
+        __syncthreads();
+        m = fmaxf(m, wmax[w ^ 1]);
+        __syncthreads();
+      }
+      const float sc = tn_e4m3_row_scale(m);
+      tn_e4m3_roundtrip8(z, sc, 1.f / sc);
+    }
     store8(dZ + i * 8, z);
   }
 }
-inline int launch_bn_bwd_apply(bf16_t* dZ, const bf16_t* Y, const BnBwd& bn, int M, int C, hipStream_t st) {
+inline int launch_bn_bwd_apply(bf16_t* dZ, const bf16_t* Y, const BnBwd& bn, int M, int C, hipStream_t st, bool emu8 = false) {
   if (C % 8 || C > 4096) return TN_E_UNSUPPORTED;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C);
+  if (emu8 && !bn.rm.len && (C == 512 || C == 1024) && ((size_t)M * (C / 8)) % 256 == 0)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C);
   return (int)hipGetLastError();
 }

@@ -283,6 +283,22 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// e4m3 round trip of 8 values that share one power-of-two scale (experiment: what an fp8 operand would carry)
+__device__ __forceinline__ void tn_e4m3_roundtrip8(float v[8], float s, float inv_s) {
+#pragma unroll
+  for (int i = 0; i < 8; i += 4) {
+    uint32_t w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i] * inv_s, v[i + 1] * inv_s, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i + 2] * inv_s, v[i + 3] * inv_s, w, true);
+    v[i] = __builtin_amdgcn_cvt_f32_fp8(w, 0) * s; v[i + 1] = __builtin_amdgcn_cvt_f32_fp8(w, 1) * s;
+    v[i + 2] = __builtin_amdgcn_cvt_f32_fp8(w, 2) * s; v[i + 3] = __builtin_amdgcn_cvt_f32_fp8(w, 3) * s;
+  }
+}
+// the power-of-two scale that maps a row maximum onto the e4m3 range (448 = largest finite e4m3)
+__device__ __forceinline__ float tn_e4m3_row_scale(float amax) {
+  return amax > 0.f ? exp2f(ceilf(log2f(amax * (1.f / 448.f)))) : 1.f;
+}
+
 #define TN_CHECK_HIP(expr)                          \
   do {                                              \
     hipError_t _e = (expr);                         \

@@ -95,6 +95,10 @@ struct tn_plan {
   // workspace layout (byte offsets)
   size_t zero_begin, zero_bytes;        // region cleared at the start of every forward
   bool fp8 = false;                     // TN_PREC_FP8: forward pointwise GEMMs of the sub-blocks on the fp8 matrix cores
+  bool fp8_bwd_emu = false;             // experiment (TN_FP8_BWD_EMU=1 at plan creation, fp8 plans): every BatchNorm-backward'd
+                                        // gradient dS of the pipelined path is rounded through e4m3 (one power-of-two scale per
+                                        // row) before the data- and weight-gradient GEMMs read it: the accuracy an fp8 backward
+                                        // would have, measured before its kernels exist
   size_t q8 = 0, fp8_table = 0;         // e4m3 copy of the current depthwise output [M][H] bytes; weight-cast descriptors
   int n_fp8 = 0;
   bool split_dw = false;                // wide models: depthwise producer as its own streaming kernel (forward)
