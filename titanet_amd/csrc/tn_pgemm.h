@@ -55,6 +55,9 @@ __device__ __forceinline__ pg_i32x4_t pg_make_srd(const void* base, unsigned byt
   return r;
 }
 
+// what an absent bias / column scale reads in the deep-ring variants (N <= 3072; one copy per translation unit)
+static __device__ const float pg_const_zeros[3072] = {};
+
 struct PGemmNtArgs {
   const bf16_t* A;   // [M][lda], K contiguous, used as stored
   int lda;
@@ -96,9 +99,12 @@ struct PGemmEpiArgs {
 // DMA bytes and half the matrix-pipe time per unit of K.
 // HT: 128-row halves per output tile (2: 256 x 256 tiles; 1: 128 x 256 — twice the tiles, for shapes whose 256-row tile count
 // leaves a fifth of the chip idle in the last round, e.g. 600 tiles at 76800 x 512: 200 workgroups x 3 against 240 x 5)
-template <int DBG = 0, bool F8 = false, int HT = 2>
+// NS: ring stages (4, or 5 = all 160 KB of LDS: one more K step in flight.  The operand stream of this kernel runs at
+// (bytes in flight) / (latency): 3 x 32 KB per CU at ~2.5 us under load = the measured ~38 GB/s per CU; bias / column scales
+// then live in registers, fetched per tile by inline-asm loads that retire behind the ring's own waits)
+template <int DBG = 0, bool F8 = false, int HT = 2, int NS = 4>
 __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtArgs pa, PGemmEpiArgs ea, int tiles_n, int total_tiles) {
-  constexpr int BK = F8 ? 64 : 32, NSTAGE = 4;
+  constexpr int BK = F8 ? 64 : 32, NSTAGE = NS, AHEAD = NS - 1;
   constexpr int ROWB = 64;                   // bytes of a tile row
   constexpr int CPR = ROWB / 16;             // 16-byte chunks per row
   constexpr int RPI = 64 / CPR;              // rows per DMA instruction (1 KiB)
@@ -172,31 +178,50 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
   // bias / column scales of all N columns sit in LDS behind the ring (the only compiler-visible loads of the kernel:
   // complete before the first DMA)
   float* cbias = reinterpret_cast<float*>(smem + NSTAGE * STAGE_B);
-  for (int i = tid; i < g.N; i += 512) {
-    cbias[i] = ea.bias ? ea.bias[i] : 0.f;
-    cbias[g.N + i] = ea.colscale ? ea.colscale[i] : 1.f;
+  if (NS == 4) {      // (deeper rings fill the LDS: their bias / scales travel in registers, fetch_bias)
+    for (int i = tid; i < g.N; i += 512) {
+      cbias[i] = ea.bias ? ea.bias[i] : 0.f;
+      cbias[g.N + i] = ea.colscale ? ea.colscale[i] : 1.f;
+    }
+    __syncthreads();
   }
-  __syncthreads();
+  // NS == 5: this lane's bias / scale pair of the NEXT tile to finish, requested one tile ahead (hidden loads: they join the
+  // in-order vmcnt queue in front of a tile's K steps and have retired long before its epilogue reads them)
+  f32x2_t bvn, cvn;
+  auto fetch_bias = [&](int tile) {
+    if (NS == 4) return;      // (NS == 4: bias / scales of all columns sit in LDS behind the ring)
+    // branch-free (an absent bias / scale reads a constant array): a conditional load would leave the compiler free to
+    // re-materialise the default into a register whose load is still in flight
+    tile = tile < total_tiles ? tile : total_tiles - 1;
+    const int mi = tile / tiles_n, nt = tile - mi * tiles_n;
+    int nc = nt * 256 + wn * 64 + 2 * (lane & 31);
+    nc = nc + 1 < g.N ? nc : 0;
+    const float* pb = (ea.bias ? ea.bias : pg_const_zeros) + nc;
+    const float* pc = (ea.colscale ? ea.colscale : pg_const_zeros) + nc;      // (absent: 0 + the 1 added in the epilogue)
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(bvn) : "v"(pb) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(cvn) : "v"(pc) : "memory");
+  };
 
   int itile = v, ikt = 0;       // next K step to request
   int ctile = v, ckt = 0;       // K step being multiplied
   int cstage = 0, istage = 0;
-  int fresh = 3;                // K steps since this wave's last epilogue stores were issued (they sit in the vmcnt queue)
+  int fresh = AHEAD;            // K steps since this wave's last epilogue stores were issued (they sit in the vmcnt queue)
   // the stream never stops requesting: past the last real K step it re-requests step 0 of the last tile into stages nobody
   // reads any more (every wait below then has the same count, and no branch splits the MFMA stream)
   auto advance_issue = [&]() {
     if (itile < total_tiles && ++ikt == KT) { ikt = 0; itile += G; if (itile < total_tiles) dma_setup(itile); }
-    istage = (istage + 1) & (NSTAGE - 1);
+    istage = istage + 1 == NSTAGE ? 0 : istage + 1;
   };
+  fetch_bias(ctile);
   dma_setup(itile < total_tiles ? itile : total_tiles - 1);
 #pragma unroll 1
-  for (int d = 0; d < 3; ++d) {                     // steps 0, 1, 2 in flight
+  for (int d = 0; d < AHEAD; ++d) {                 // steps 0 .. AHEAD - 1 in flight
     const int kt = itile < total_tiles ? ikt : 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { dma_a(q, kt, istage); dma_b(q, kt, istage); }
     advance_issue();
   }
-  pg_wait<2 * GRP>();               // step 0 has landed (steps 1 and 2 stay in flight)
+  pg_wait<(AHEAD - 1) * GRP>();     // step 0 has landed (the later ones stay in flight)
   pg_barrier();
   while (ctile < total_tiles) {
     const int kt_req = itile < total_tiles ? ikt : 0;
@@ -253,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
       }
     }
     advance_issue();
-    cstage = (cstage + 1) & (NSTAGE - 1);
+    cstage = cstage + 1 == NSTAGE ? 0 : cstage + 1;
     if (++ckt == KT) {
       // ---- epilogue of this tile, straight from the accumulators
       const int mi_ = ctile / tiles_n, nt_ = ctile - mi_ * tiles_n;
@@ -263,7 +288,9 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
       const bool full_rows = mt_ * TM + TM <= g.M;
       float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
       if (cols_ok) {
-        const f32x2_t bv = *reinterpret_cast<const f32x2_t*>(cbias + ncol), cv = *reinterpret_cast<const f32x2_t*>(cbias + g.N + ncol);
+        f32x2_t bv, cv;
+        if (NS == 4) { bv = *reinterpret_cast<const f32x2_t*>(cbias + ncol); cv = *reinterpret_cast<const f32x2_t*>(cbias + g.N + ncol); }
+        else { const float one = ea.colscale ? 0.f : 1.f; bv = bvn; cv[0] = cvn[0] + one; cv[1] = cvn[1] + one; }
 #pragma unroll
         for (int h = 0; h < HT; ++h)
 #pragma unroll
@@ -298,13 +325,14 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
       zero_acc();
       ckt = 0;
       ctile += G;
-      fresh = (cols_ok && !(DBG & 8)) ? 0 : 3;
+      fresh = (cols_ok && !(DBG & 8)) ? 0 : AHEAD;
+      fetch_bias(ctile);
     }
     // this wave's part of the next stage has landed.  The vmcnt queue retires in order: the two groups requested after it
     // may stay in flight, and so may this tile's 64 output stores (+ statistics atomics) while they are YOUNGER than the
     // group waited for: "at most 63 outstanding" then retires the DMA groups that precede them
-    if (fresh < 3) pg_wait<STW>();
-    else pg_wait<2 * GRP>();
+    if (fresh < AHEAD) pg_wait<STW>();
+    else pg_wait<(AHEAD - 1) * GRP>();
     ++fresh;
     pg_barrier();           // ... everybody's part; and the stage refilled next is no longer read by anyone
   }
@@ -341,13 +369,20 @@ inline int launch_pgemm_nt_t(const GemmShape& g, const PGemmNtArgs& pa, const PG
     const double use1 = (double)total1 / ((double)rounds1 * max_wgs);
     if (use2 < 0.875 && use1 > use2 + 0.08) { half = true; total = total1; grid = grid1; }
   }
-  const size_t smem = (size_t)(half ? 98304 : 131072) + (size_t)2 * g.N * sizeof(float);
   if (half) {
-    auto kern = pgemm_nt_kernel<DBG, F8, 1>;
+    const size_t smem = (size_t)98304 + (size_t)2 * g.N * sizeof(float);
+    auto kern = pgemm_nt_kernel<DBG, F8, 1, 4>;
+    TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g, pa, ea, tiles_n, total);
+  } else if (g.N <= 3072) {
+    // five 32 KB stages = the whole LDS of a CU: one more K step in flight (L/5: 21.8 -> 21.4 ms; neutral at K = 512)
+    const size_t smem = (size_t)5 * 32768;
+    auto kern = pgemm_nt_kernel<DBG, F8, 2, 5>;
     TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g, pa, ea, tiles_n, total);
   } else {
-    auto kern = pgemm_nt_kernel<DBG, F8, 2>;
+    const size_t smem = (size_t)131072 + (size_t)2 * g.N * sizeof(float);
+    auto kern = pgemm_nt_kernel<DBG, F8, 2, 4>;
     TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g, pa, ea, tiles_n, total);
   }
@@ -398,8 +433,9 @@ struct PGemmTnArgs {
 };
 
 // one (256 x 256 output slab (tp, tq), K steps [s0, s0 + nsteps)) segment of a workgroup: prologue, ring loop, atomic flush
+template <int NSTAGE>
 __device__ __forceinline__ void pg_tn_segment(const PGemmTnArgs& a, int tp, int tq, int s0, int nsteps, char* smem) {
-  constexpr int NSTAGE = 4, TILE_B = 16384, STAGE_B = 2 * TILE_B, GRP = 4;
+  constexpr int AHEAD = NSTAGE - 1, TILE_B = 16384, STAGE_B = 2 * TILE_B, GRP = 4;
   const unsigned lds0 = (unsigned)(uintptr_t)(tn_lds_char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -439,7 +475,7 @@ __device__ __forceinline__ void pg_tn_segment(const PGemmTnArgs& a, int tp, int 
 #pragma unroll
       for (int q = 0; q < 2; ++q) { voffP[q] += stepP; voffQ[q] += stepQ; }      // past the last row: zeros (bounds check)
     }
-    istage = (istage + 1) & (NSTAGE - 1);
+    istage = istage + 1 == NSTAGE ? 0 : istage + 1;
   };
   // fragments
   const int i16 = lane & 15, g1 = (lane >> 4) & 1, half = lane >> 5, rw = (i16 >> 2) & 3;
@@ -459,11 +495,11 @@ __device__ __forceinline__ void pg_tn_segment(const PGemmTnArgs& a, int tp, int 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
 #pragma unroll 1
-  for (int d = 0; d < 3; ++d) {
+  for (int d = 0; d < AHEAD; ++d) {
     dma_p(0); dma_q(0); dma_p(1); dma_q(1);
     advance_issue();
   }
-  pg_wait<2 * GRP>();
+  pg_wait<(AHEAD - 1) * GRP>();
   pg_barrier();
   int cstage = 0;
   for (int s = 0; s < nsteps; ++s) {
@@ -487,8 +523,8 @@ __device__ __forceinline__ void pg_tn_segment(const PGemmTnArgs& a, int tp, int 
       }
     }
     advance_issue();
-    cstage = (cstage + 1) & (NSTAGE - 1);
-    pg_wait<2 * GRP>();
+    cstage = cstage + 1 == NSTAGE ? 0 : cstage + 1;
+    pg_wait<(AHEAD - 1) * GRP>();
     pg_barrier();
   }
   pg_wait<0>();
@@ -514,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(PGemmTnArgs a) {
   int nsteps = nsteps_all - s0;
   nsteps = nsteps < a.steps_per_split ? nsteps : a.steps_per_split;
   if (nsteps <= 0) return;                                         // workgroup-uniform
-  pg_tn_segment(a, tp, tq, s0, nsteps, smem);
+  pg_tn_segment<4>(a, tp, tq, s0, nsteps, smem);
 }
 
 // ==========================================================================================
@@ -552,7 +588,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_batched_kernel(const PGemmTnD
     a.np = 0; a.nq = 0; a.splits = 0; a.steps_per_split = 0;
     const int tq_n = descs[d].tiles_q;
     pg_barrier();                       // the previous segment's last fragment reads are done before its ring is refilled
-    pg_tn_segment(a, unit / tq_n, unit % tq_n, s0, n, smem);
+    pg_tn_segment<5>(a, unit / tq_n, unit % tq_n, s0, n, smem);      // five 32 KB stages: the whole LDS
     pos += n;
   }
 }
@@ -571,8 +607,8 @@ inline int launch_pgemm_tn_batched(const PGemmTnDesc* descs_dev, int n_descs, in
   // (pg_virtual_id keeps a group on one XCD only for grids that are multiples of 8; U is 4 or 16 and groups a power-of-two
   //  fraction of 256 in practice)
   auto kern = pgemm_tn_batched_kernel<0>;
-  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 131072, st, descs_dev, n_descs, rows, U, spg, rowtiles, n_rowtiles);
+  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 163840, st, descs_dev, n_descs, rows, U, spg, rowtiles, n_rowtiles);
   return (int)hipGetLastError();
 }
 
