@@ -214,6 +214,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   }
   p->dw_gacc = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * TN_NREP * (c.kernel + 1) * H * sizeof(float));
   if (p->tail_parts > 1) p->dgate_acc = b.take((size_t)c.n_mega_blocks * batch * H * sizeof(float));
+  if (p->tail_parts > 1 && precision == TN_PREC_BF16) p->se_bacc = b.take((size_t)batch * 4 * H * sizeof(float));
   p->bzero_bytes = ((b.off + 255) & ~(size_t)255) - p->bzero_begin;
   b.off = p->bzero_begin + p->bzero_bytes;
   // ---- device-resident step state {uint64 step; uint32 word; ...}: cleared once at bind, advanced by tn_plan_step_tick

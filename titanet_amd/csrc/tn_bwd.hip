@@ -146,11 +146,13 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   // round 4: the mega-block tail backward in ONE pass (combine_bwd1_v3 finishes the SE backward per utterance; the last
   // sub-block's fused data-gradient kernel rebuilds its incoming gradient on load and stores the BatchNorm-backward'd dS for
   // the weight-gradient launch): fixed-length training batches of the headline shape
-  const bool fuse_tail = v2_bwd && batched_wgrad && H == V2_C && Hr == 16 && c.kernel == 3 && nsub >= 2 && !p->masked &&
-                         p->tail_parts == 1 && p->se_gu != 0;
+  // (variable-length batches included: padding rows carry no gradient, sums over the valid rows; small batches of long
+  //  utterances: several workgroups per utterance + a finishing kernel)
+  const bool tail_ok = nsub >= 2 && p->se_gu != 0 && (p->tail_parts == 1 || p->se_bacc != 0);
+  const bool fuse_tail = v2_bwd && batched_wgrad && H == V2_C && Hr == 16 && c.kernel == 3 && tail_ok;
   // ... and of the wide models on the pipelined path: the rebuild sits in the streaming pass that makes the stored dS operand
-  const bool fuse_tail_wide = pipe && (H == 512 || H == 1024) && Hr * 16 == H && nsub >= 2 && !p->masked && p->tail_parts == 1 &&
-                              p->se_gu != 0 && !p->fp8_bwd_emu;      // (the e4m3 experiment rounds dS in the plain pass)
+  const bool fuse_tail_wide = pipe && (H == 512 || H == 1024) && Hr * 16 == H && tail_ok &&
+                              !p->fp8_bwd_emu;      // (the e4m3 experiment rounds dS in the plain pass)
   const int nb = c.n_mega_blocks;
   const int per_blk = nsub + 1;
   int rc_fin = 0;
@@ -416,8 +418,9 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         CombineBwd1V2Args& c1 = c3.a1;
         c1.dOUT = (const bf16_t*)(ws + p->dA[cur]); c1.gate = (const float*)(ws + bw.g); c1.Y3 = (const bf16_t*)(ws + bw.Y[nsub - 1]);
         c1.act3 = act3; c1.S = (const bf16_t*)(ws + bw.S); c1.actS = acts; c1.dZ = (bf16_t*)(ws + bw.dZk);
-        c1.bsumsS = bsum(mb.bnskip); c1.T = T; c1.parts = 1; c1.inv_keep = inv_keep; c1.drop_thr = othr; c1.drop_key = okey;
+        c1.bsumsS = bsum(mb.bnskip); c1.T = T; c1.parts = p->tail_parts; c1.inv_keep = inv_keep; c1.drop_thr = othr; c1.drop_key = okey;
         c1.key_add = (const uint32_t*)(ws + p->step_state) + 2;
+        c3.len = plan_row_mask(p).len; c3.bacc = p->se_bacc ? (float*)(ws + p->se_bacc) : nullptr;
         c3.hid = (const float*)(ws + bw.h); c3.W1 = params + mb.se_w1; c3.W2 = params + mb.se_w2;
         c3.dpre2 = (float*)(ws + bw.dpre2); c3.dpre1 = (float*)(ws + bw.dpre1); c3.gu = (float*)(ws + p->se_gu);
         c3.bsums3 = bsum(mb.sub[nsub - 1].bn);

@@ -137,6 +137,8 @@ struct tn_plan {
                                                     // flow (the last sub-block's unit reads the stored BatchNorm-backward'd dS)
   size_t tn_table = 0;          // wide models: PGemmTnDesc table of the mega blocks' pointwise layers in backward order (batched
                                 // weight-gradient launch, one per gradient bucket), or 0
+  size_t se_bacc = 0;           // ... its per-utterance partial sums [B][4][hidden] when several workgroups share an utterance
+                                // (tail_parts > 1; inside the region zeroed at the start of every backward)
   size_t se_gu = 0;             // fused mega-block tail backward (combine_bwd1_v3): ga / ub [B][2][256] floats, one block at a time
   size_t dw_gacc, dw_table;                         // depthwise gradient accumulators [layer][NREP][KD+1][256] + finalize table
   int wg2_layers = 0, wg2_maxparts = 0, wg2_units_per_wg = 0, wg2_grid = 0, wg2_epi_slabs = 0, wg2_asp_units = 0;

@@ -483,16 +483,77 @@ inline int launch_combine_bwd1_v2(const CombineBwd1V2Args& a, int B, hipStream_t
 // data-gradient kernel (dgrad_dw_v6<.., Z3>) rebuilds dY3bn on load from dZ, Y3, ga, ub.  One workgroup per utterance.
 // ------------------------------------------------------------------------------------------
 struct CombineBwd1V3Args {
-  CombineBwd1V2Args a1;      // (dgate unused, parts == 1)
-  const float* hid;          // [B][16] SE hidden layer (forward)
-  const float* W1;           // [16][256]
-  const float* W2;           // [256][16]
+  CombineBwd1V2Args a1;      // (dgate unused; parts = workgroups per utterance)
+  const float* hid;          // [B][CH / 16] SE hidden layer (forward)
+  const float* W1;           // [CH / 16][CH]
+  const float* W2;           // [CH][CH / 16]
   float* dpre2; float* dpre1;
-  float* gu;                 // [B][2][256]: ga, ub
+  float* gu;                 // [B][2][CH]: ga, ub
   float* bsums3;
+  const int* len;            // valid frames per utterance (variable-length batch) or null: padding rows carry no gradient,
+                             // the sums run over the valid rows, the SE mean ran over them
+  float* bacc;               // parts > 1: [B][4][CH] accumulators of B1..B4 (zero on entry, left zero by the tail kernel)
 };
+// The per-utterance end of the pass: SE backward from B1..B4 of this thread's channels (B[q]: channel tid + 512 q), ga / ub,
+// the utterance's share of the BatchNorm-backward sums of the last sub-block.  cst: sc3, sh3, .., mean3*rstd3 (6), rstd3 (7).
+template <int FL3, int CH, bool PRE>
+__device__ __forceinline__ void cb3_tail(const CombineBwd1V3Args& aa, int b, int L, const float* cst, float* p2, float* p1,
+                                         float (&B)[(CH + 511) / 512][4], const float (*w2r)[4], const float* hidr, const float* w1r) {
+  constexpr int HR = CH / 16, PT = (CH + 511) / 512;
+  const CombineBwd1V2Args& a = aa.a1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rep = b % TN_NREP;
+  float gg[PT];
+#pragma unroll
+  for (int q = 0; q < PT; ++q) {
+    const int c = tid + 512 * q;
+    gg[q] = 0.f;
+    if (c < CH) {
+      const float g = a.gate[(size_t)b * CH + c];
+      gg[q] = g;
+      const float dgate = fmaf(cst[c], B[q][1], cst[CH + c] * B[q][0]);
+      const float d2 = dgate * g * (1.f - g);
+      p2[c] = d2;
+      aa.dpre2[(size_t)b * CH + c] = d2;
+    }
+  }
+  __syncthreads();
+  // p1[j] = relu'(hid[j]) * sum_c W2[c][j] p2[c]  (HR / 8 outputs per wave)
+#pragma unroll
+  for (int jj = 0; jj < HR / 8; ++jj) {
+    const int j = wave + 8 * jj;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < CH / 64; ++k) s = fmaf(PRE ? w2r[PRE ? jj : 0][PRE ? k : 0] : aa.W2[(size_t)(lane + 64 * k) * HR + j], p2[lane + 64 * k], s);
+    s = wave_sum(s);
+    if (lane == 0) {
+      s = ((PRE ? hidr[PRE ? jj : 0] : aa.hid[(size_t)b * HR + j]) > 0.f) ? s : 0.f;
+      p1[j] = s;
+      aa.dpre1[(size_t)b * HR + j] = s;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < PT; ++q) {
+    const int c = tid + 512 * q;
+    if (c < CH) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < HR; ++j) s = fmaf(PRE ? w1r[PRE ? j : 0] : aa.W1[(size_t)j * CH + c], p1[j], s);
+      const float on = (FL3 & 4) ? a.act3.inv_keep : 1.f;
+      const float ga = gg[q] * on, ub = s / (float)max(L, 1) * on;
+      aa.gu[((size_t)b * 2 + 0) * CH + c] = ga;
+      aa.gu[((size_t)b * 2 + 1) * CH + c] = ub;
+      const float sv = fmaf(ga, B[q][0], ub * B[q][2]), sy = fmaf(ga, B[q][1], ub * B[q][3]);
+      atomic_add_f32(&aa.bsums3[(size_t)(rep * 2 + 0) * CH + c], sv);
+      atomic_add_f32(&aa.bsums3[(size_t)(rep * 2 + 1) * CH + c], cst[7 * CH + c] * sy - cst[6 * CH + c] * sv);
+    }
+  }
+}
 // CH = hidden width (256: TitaNet-S; 512 / 1024: the wide models, whose last sub-block rebuilds the gradient in
 // bn_bwd_apply_z3_kernel).  512 threads = (CH / 8 channel vectors) x TG row groups; dynamic LDS: 8 CH constants + [NS][6][CH] partial sums.
+// a1.parts workgroups per utterance (small batches of long utterances): each takes a range of frames, B1..B4 meet in aa.bacc
+// and combine_bwd1_v3_tail_kernel finishes the utterance; parts == 1: the workgroup does it itself.
 template <int FL3, bool DROP, int CH>
 __global__ __launch_bounds__(512) void combine_bwd1_v3_kernel(CombineBwd1V3Args aa) {
   constexpr int HR = CH / 16, CV = CH / 8, TG = 512 / CV, NS = CH == 256 ? 8 : TG, PT = (CH + 511) / 512;
@@ -504,7 +565,10 @@ __global__ __launch_bounds__(512) void combine_bwd1_v3_kernel(CombineBwd1V3Args 
   float* p1 = p2 + CH;                   // [HR]
   const int tid = threadIdx.x, vc = tid % CV, tg = tid / CV, c0 = vc * 8;
   const int lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x;
+  const int parts = a.parts, b = blockIdx.x / parts, prt = blockIdx.x - b * parts;
+  const int L = aa.len ? aa.len[b] : a.T;
+  const int per = (a.T + parts - 1) / parts;
+  const int t_lo = prt * per, t_end = min(a.T, t_lo + per), t_hi = min(L, t_end);
   for (int c = tid; c < CH; c += 512) {
     float s = 1.f, h = 0.f, ss, hs, ms, rs, m3 = 0.f, r3 = 1.f;
     if (FL3 & 1) { bn_scale_shift(a.act3, CH, c, s, h); bn_mean_rstd(a.act3, CH, c, m3, r3); }
@@ -541,12 +605,12 @@ __global__ __launch_bounds__(512) void combine_bwd1_v3_kernel(CombineBwd1V3Args 
 #pragma unroll
   for (int i = 0; i < 8; ++i) { b1[i] = 0.f; b2[i] = 0.f; b3[i] = 0.f; b4[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
   constexpr int U = 4;
-  for (int tb = tg; tb < a.T; tb += TG * U) {
+  for (int tb = t_lo + tg; tb < t_hi; tb += TG * U) {
     uint4 rd[U], ry[U], rs[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = tb + TG * u;
-      if (t < a.T) {
+      if (t < t_hi) {
         const size_t o = ((size_t)b * a.T + t) * CH + c0;
         rd[u] = *reinterpret_cast<const uint4*>(a.dOUT + o);
         ry[u] = *reinterpret_cast<const uint4*>(a.Y3 + o);
@@ -556,7 +620,7 @@ __global__ __launch_bounds__(512) void combine_bwd1_v3_kernel(CombineBwd1V3Args 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = tb + TG * u;
-      if (t < a.T) {
+      if (t < t_hi) {
         const uint32_t row = (uint32_t)b * a.T + t;
         float d[8], y[8], ya[8], sv[8], m[8];
         unpack8(rd[u], d);
@@ -593,6 +657,11 @@ __global__ __launch_bounds__(512) void combine_bwd1_v3_kernel(CombineBwd1V3Args 
       }
     }
   }
+  // padding frames of this workgroup's range: no gradient (written, not read)
+  if (aa.len) {
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    for (int t = max(t_lo, L) + tg; t < t_end; t += TG) *reinterpret_cast<uint4*>(a.dZ + ((size_t)b * a.T + t) * CH + c0) = z4;
+  }
   // hidden 256: the two row groups of a wave (lanes l, l ^ 32) first; then the row groups through LDS
   if (CH == 256) {
 #pragma unroll
@@ -610,12 +679,12 @@ __global__ __launch_bounds__(512) void combine_bwd1_v3_kernel(CombineBwd1V3Args 
     }
   }
   __syncthreads();
-  const int rep = blockIdx.x % TN_NREP;
-  float B[PT][4], gg[PT];
+  const int rep = b % TN_NREP;
+  float B[PT][4];
 #pragma unroll
   for (int q = 0; q < PT; ++q) {
     const int c = tid + 512 * q;
-    B[q][0] = B[q][1] = B[q][2] = B[q][3] = 0.f; gg[q] = 0.f;
+    B[q][0] = B[q][1] = B[q][2] = B[q][3] = 0.f;
     if (c < CH) {
       float v1 = 0.f, v2 = 0.f;
 #pragma unroll
@@ -625,64 +694,64 @@ __global__ __launch_bounds__(512) void combine_bwd1_v3_kernel(CombineBwd1V3Args 
       }
       atomic_add_f32(&a.bsumsS[(size_t)(rep * 2 + 0) * CH + c], v1);
       atomic_add_f32(&a.bsumsS[(size_t)(rep * 2 + 1) * CH + c], v2);
-      const float g = a.gate[(size_t)b * CH + c];
-      gg[q] = g;
-      const float dgate = fmaf(cst[c], B[q][1], cst[CH + c] * B[q][0]);
-      const float d2 = dgate * g * (1.f - g);
-      p2[c] = d2;
-      aa.dpre2[(size_t)b * CH + c] = d2;
+      if (parts > 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomic_add_f32(&aa.bacc[((size_t)b * 4 + k) * CH + c], B[q][k]);
+      }
     }
   }
-  __syncthreads();
-  // p1[j] = relu'(hid[j]) * sum_c W2[c][j] p2[c]  (HR / 8 outputs per wave)
-#pragma unroll
-  for (int jj = 0; jj < HR / 8; ++jj) {
-    const int j = wave + 8 * jj;
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < CH / 64; ++k) s = fmaf(PRE ? w2r[PRE ? jj : 0][PRE ? k : 0] : aa.W2[(size_t)(lane + 64 * k) * HR + j], p2[lane + 64 * k], s);
-    s = wave_sum(s);
-    if (lane == 0) {
-      s = ((PRE ? hidr[PRE ? jj : 0] : aa.hid[(size_t)b * HR + j]) > 0.f) ? s : 0.f;
-      p1[j] = s;
-      aa.dpre1[(size_t)b * HR + j] = s;
-    }
-  }
-  __syncthreads();
+  if (parts > 1) return;                 // workgroup-uniform: combine_bwd1_v3_tail_kernel finishes the utterance
+  cb3_tail<FL3, CH, PRE>(aa, b, L, cst, p2, p1, B, w2r, hidr, w1r);
+}
+// the per-utterance end of a pass that ran as several workgroups per utterance (reads B1..B4 from aa.bacc and zeroes it again)
+template <int FL3, int CH>
+__global__ __launch_bounds__(512) void combine_bwd1_v3_tail_kernel(CombineBwd1V3Args aa) {
+  constexpr int HR = CH / 16, PT = (CH + 511) / 512;
+  const CombineBwd1V2Args& a = aa.a1;
+  __shared__ float cst[8 * CH];          // only sc3, sh3 (0, 1) and mean3*rstd3, rstd3 (6, 7) are used
+  __shared__ float p2[CH], p1[HR];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int L = aa.len ? aa.len[b] : a.T;
+  float B[PT][4];
 #pragma unroll
   for (int q = 0; q < PT; ++q) {
     const int c = tid + 512 * q;
+    B[q][0] = B[q][1] = B[q][2] = B[q][3] = 0.f;
     if (c < CH) {
-      float s = 0.f;
+      float s = 1.f, h = 0.f, m3 = 0.f, r3 = 1.f;
+      if (FL3 & 1) { bn_scale_shift(a.act3, CH, c, s, h); bn_mean_rstd(a.act3, CH, c, m3, r3); }
+      cst[c] = s; cst[CH + c] = h; cst[6 * CH + c] = m3 * r3; cst[7 * CH + c] = r3;
 #pragma unroll
-      for (int j = 0; j < HR; ++j) s = fmaf(PRE ? w1r[PRE ? j : 0] : aa.W1[(size_t)j * CH + c], p1[j], s);
-      const float on = (FL3 & 4) ? a.act3.inv_keep : 1.f;
-      const float ga = gg[q] * on, ub = s / (float)a.T * on;
-      aa.gu[((size_t)b * 2 + 0) * CH + c] = ga;
-      aa.gu[((size_t)b * 2 + 1) * CH + c] = ub;
-      const float sv = fmaf(ga, B[q][0], ub * B[q][2]), sy = fmaf(ga, B[q][1], ub * B[q][3]);
-      atomic_add_f32(&aa.bsums3[(size_t)(rep * 2 + 0) * CH + c], sv);
-      atomic_add_f32(&aa.bsums3[(size_t)(rep * 2 + 1) * CH + c], cst[7 * CH + c] * sy - cst[6 * CH + c] * sv);
+      for (int k = 0; k < 4; ++k) {
+        float* pa = &aa.bacc[((size_t)b * 4 + k) * CH + c];
+        B[q][k] = *pa;
+        *pa = 0.f;
+      }
     }
   }
+  __syncthreads();
+  float w2d[1][4] = {{0.f, 0.f, 0.f, 0.f}}, hd[2] = {0.f, 0.f}, w1d[1] = {0.f};
+  cb3_tail<FL3, CH, false>(aa, b, L, cst, p2, p1, B, w2d, hd, w1d);
 }
 // -1000: no specialisation for this flag combination
 template <int CH>
 inline int launch_combine_bwd1_v3_c(const CombineBwd1V3Args& aa, int B, hipStream_t st) {
   const CombineBwd1V2Args& a = aa.a1;
   const int fl3 = (a.act3.mode != 0 ? 1 : 0) | (a.act3.relu ? 2 : 0) | (a.act3.drop_thr ? 4 : 0);
-  if (a.act3.rm.len || a.parts != 1) return -1000;
+  if (a.parts < 1 || (a.parts > 1 && !aa.bacc)) return -1000;
   constexpr int CV = CH / 8, TG = 512 / CV, NS = CH == 256 ? 8 : TG;
   const size_t smem = (size_t)(8 * CH + NS * 6 * CH + CH + CH / 16) * sizeof(float);
-  const dim3 grid(B), blk(512);
+  const dim3 grid(B * a.parts), blk(512);
   if (fl3 == 7 && a.drop_thr) {
     auto kern = combine_bwd1_v3_kernel<7, true, CH>;
     TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, grid, blk, smem, st, aa);
+    if (a.parts > 1) hipLaunchKernelGGL((combine_bwd1_v3_tail_kernel<7, CH>), dim3(B), blk, 0, st, aa);
   } else if (fl3 == 3 && !a.drop_thr) {
     auto kern = combine_bwd1_v3_kernel<3, false, CH>;
     TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, grid, blk, smem, st, aa);
+    if (a.parts > 1) hipLaunchKernelGGL((combine_bwd1_v3_tail_kernel<3, CH>), dim3(B), blk, 0, st, aa);
   } else return -1000;
   return (int)hipGetLastError();
 }
@@ -703,7 +772,8 @@ inline int launch_combine_bwd1_v3(const CombineBwd1V3Args& aa, int B, int C, hip
 // float32 per 16 bytes of gradient, for every vector: 79 us against 47 for the plain pass at hidden 512).
 template <bool DROP3, int CH>
 __global__ __launch_bounds__(256) void bn_bwd_apply_z3_kernel(const bf16_t* __restrict__ dZ, const bf16_t* __restrict__ Y, BnBwd bn, BnAct act3,
-                                                              const float* __restrict__ gu, bf16_t* __restrict__ dS, int T, int chunk) {
+                                                              const float* __restrict__ gu, bf16_t* __restrict__ dS, int T, int chunk,
+                                                              const int* __restrict__ len) {
   constexpr int VC = CH / 8, RG = 256 / VC;       // channel vectors per row, row groups per workgroup
   __shared__ __attribute__((aligned(16))) float pg_k[5 * CH];      // k0, k1, k2, sc3, sh3
   for (int c = threadIdx.x; c < CH; c += 256) {
@@ -720,7 +790,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_z3_kernel(const bf16_t* __re
   }
   load8(gu + (size_t)b * 2 * CH + c0, ga);
   load8(gu + (size_t)b * 2 * CH + CH + c0, ub);
-  const int t0 = blockIdx.x * chunk, t1 = min(T, t0 + chunk);
+  const int t0 = blockIdx.x * chunk, t_end = min(T, t0 + chunk);
+  const int t1 = len ? min(t_end, len[b]) : t_end;       // padding frames of a variable-length batch: dS = 0 (written below)
+  if (len) {
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    for (int t = max(t0, t1) + rg; t < t_end; t += RG) *reinterpret_cast<uint4*>(dS + ((size_t)b * T + t) * CH + c0) = z4;
+  }
   constexpr int U = 4;
   for (int tb = t0 + rg; tb < t1; tb += RG * U) {
     uint4 rz[U], ry[U];
@@ -759,13 +834,13 @@ inline int launch_bn_bwd_apply_z3_c(const bf16_t* dZ, const bf16_t* Y, const BnB
                                     int T, hipStream_t st) {
   const int chunk = 64;
   const dim3 grid((T + chunk - 1) / chunk, M / T);
-  if (act3.drop_thr) hipLaunchKernelGGL((bn_bwd_apply_z3_kernel<true, CH>), grid, dim3(256), 0, st, dZ, Y, bn, act3, gu, dS, T, chunk);
-  else hipLaunchKernelGGL((bn_bwd_apply_z3_kernel<false, CH>), grid, dim3(256), 0, st, dZ, Y, bn, act3, gu, dS, T, chunk);
+  if (act3.drop_thr) hipLaunchKernelGGL((bn_bwd_apply_z3_kernel<true, CH>), grid, dim3(256), 0, st, dZ, Y, bn, act3, gu, dS, T, chunk, bn.rm.len);
+  else hipLaunchKernelGGL((bn_bwd_apply_z3_kernel<false, CH>), grid, dim3(256), 0, st, dZ, Y, bn, act3, gu, dS, T, chunk, bn.rm.len);
   return (int)hipGetLastError();
 }
 inline int launch_bn_bwd_apply_z3(const bf16_t* dZ, const bf16_t* Y, const BnBwd& bn, const BnAct& act3, const float* gu, bf16_t* dS, int M,
                                   int C, int T, hipStream_t st) {
-  if (bn.rm.len || act3.mode == 0 || !act3.relu || M % T) return TN_E_UNSUPPORTED;
+  if (act3.mode == 0 || !act3.relu || M % T) return TN_E_UNSUPPORTED;
   if (C == 512) return launch_bn_bwd_apply_z3_c<512>(dZ, Y, bn, act3, gu, dS, M, T, st);
   if (C == 1024) return launch_bn_bwd_apply_z3_c<1024>(dZ, Y, bn, act3, gu, dS, M, T, st);
   return TN_E_UNSUPPORTED;
@@ -1396,7 +1471,6 @@ struct DgradDwArgs {
 // padding rows of X read as zeros (no tap-weight gradient through them), the data gradient is written as zero there.
 template <int FL, bool MK = false, bool Z3 = false>
 __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
-  static_assert(!(Z3 && MK), "the rebuilt-gradient variant has no variable-length form");
   constexpr int KD = 3, NT = V2_NT;
   constexpr bool HAS_MASK = (FL & 7) != 0, HAS_ADD = (FL & 8) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1703,10 +1777,7 @@ template <int FL>
 inline int launch_dgrad_dw_v6_t(DgradDwArgs a, int grid, size_t smem, hipStream_t st) {
   auto kern = a.bn.rm.len ? dgrad_dw_v6_kernel<FL, true> : dgrad_dw_v6_kernel<FL, false>;
   if constexpr (FL == 7 || FL == 3) {
-    if (a.gu) {
-      if (a.bn.rm.len) return -1000;
-      kern = dgrad_dw_v6_kernel<FL, false, true>;
-    }
+    if (a.gu) kern = a.bn.rm.len ? dgrad_dw_v6_kernel<FL, true, true> : dgrad_dw_v6_kernel<FL, false, true>;
   } else if (a.gu) return -1000;
   TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
