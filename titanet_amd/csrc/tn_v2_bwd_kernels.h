@@ -1469,15 +1469,17 @@ struct DgradDwArgs {
 
 // MK (variable-length batch, a.bn.rm.len): dS = 0 on padding rows (their dD then adds nothing to the valid rows next to them),
 // padding rows of X read as zeros (no tap-weight gradient through them), the data gradient is written as zero there.
-template <int FL, bool MK = false, bool Z3 = false>
+// P2 (round 4): two barriers per tile instead of three — the stencil of tile t and the transform of tile t + 1 share one phase
+// (raw X rows double-buffered), the MFMAs of tile t + 1 the other.
+template <int FL, bool MK = false, bool Z3 = false, bool P2 = false>
 __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
   constexpr int KD = 3, NT = V2_NT;
   constexpr bool HAS_MASK = (FL & 7) != 0, HAS_ADD = (FL & 8) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* Pt = reinterpret_cast<bf16_t*>(smem);          // [32][264] BN-backward'd dY rows (MFMA B operand)
   bf16_t* Dt = Pt + V6_R * V2_AP;                         // [32][264] dD rows
-  bf16_t* Xs = Dt + V6_R * V2_AP;                         // [32][256] raw X rows
-  float* cst = reinterpret_cast<float*>(Xs + V6_R * V2_C);   // k0,k1,k2, sc,sh,mean*rstd,rstd, wd[3] : [10][256] (+ sc3, sh3 with Z3)
+  bf16_t* Xs = Dt + V6_R * V2_AP;                         // [32][256] raw X rows (P2: two buffers)
+  float* cst = reinterpret_cast<float*>(Xs + (P2 ? 2 : 1) * V6_R * V2_C);   // k0,k1,k2, sc,sh,mean*rstd,rstd, wd[3] : [10][256] (+ sc3, sh3 with Z3)
   float* gus = cst + 12 * V2_C;                               // Z3: ga, ub of the tile's two utterances [2][2][256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int vc = tid & 31, rq = tid >> 5, c0 = vc * 8;   // transform layout: 8 channels x rows rq, rq + 16
@@ -1541,13 +1543,12 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
 #pragma unroll
     for (int k = 0; k < KD; ++k) gw[k][i] = 0.f;
   }
-  for (; tile < a.ntiles; tile += gridDim.x) {
+  // the three phases of a tile (Xb: the tile's raw X rows)
+  auto transform = [&](int tile, bf16_t* Xb) {
     const int g0 = tile * V6_OUT - 1;          // global row of tile row 0
     TileMask tm = {0, 0, 0};
     if (MK) tm = tn_tile_mask(a.bn.rm.len, a.T, a.M, g0);
     const int e0 = Z3 ? ((g0 < 0 ? 0 : g0) / a.T + 1) * a.T : 0;     // first row of the tile's second utterance
-    __syncthreads();   // (1) the previous tile's stencil is done with Dt / Xs, its MFMAs with Pt
-    if (Z3 && tile + (int)gridDim.x < a.ntiles) prefetch_g(tile + gridDim.x);      // (published behind this tile's stencil)
     // ---- BN backward on load -> Pt;  raw X rows -> Xs
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -1596,10 +1597,11 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
       }
       store8(Pt + r * V2_AP + c0, z);
       if (Z3 && a.dS_out && r >= 1 && r <= V6_OUT && gr < a.M) store8(a.dS_out + (size_t)gr * V2_C + c0, z);
-      *reinterpret_cast<uint4*>(Xs + r * V2_C + c0) = px[q];
+      *reinterpret_cast<uint4*>(Xb + r * V2_C + c0) = px[q];
       if (tile + (int)gridDim.x < a.ntiles) prefetch_q(tile + gridDim.x, q);
     }
-    __syncthreads();   // (2)
+  };
+  auto mfma = [&]() {
     // ---- dD = dY * W : 32 rows x this wave's 32 input channels
     {
       f32x16_t acc;
@@ -1616,7 +1618,11 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
         *reinterpret_cast<uint2*>(Dt + (lane & 31) * V2_AP + wave * 32 + 8 * g + 4 * half) = w;
       }
     }
-    __syncthreads();   // (3)
+  };
+  auto stencil = [&](int tile, const bf16_t* Xb) {
+    const int g0 = tile * V6_OUT - 1;
+    TileMask tm = {0, 0, 0};
+    if (MK) tm = tn_tile_mask(a.bn.rm.len, a.T, a.M, g0);
     // ---- transposed stencil + activation backward: wave = strip of 4 output rows (tile rows 1 + 4*wave ..), lane = 4 channels
     {
       // 30 output rows over 8 waves: strips of 4, 4, 4, 4, 4, 4, 3, 3 rows (a 2-row leftover strip would always take the
@@ -1628,7 +1634,7 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
       // (masked: the strip lies inside one utterance, so its rows are valid frames iff the last one is)
       const bool fast = gfirst >= 0 && glast < a.M && (gfirst % a.T) + NR + 1 < a.T && (!MK || tn_tile_valid(tm, glast - 1));   // wave-uniform
       auto ldD = [&](int i, float* D) { unpack4(*reinterpret_cast<const uint2*>(Dt + i * V2_AP + c4), D); };
-      auto ldX = [&](int i, float* Yr) { unpack4(*reinterpret_cast<const uint2*>(Xs + i * V2_C + c4), Yr); };
+      auto ldX = [&](int i, float* Yr) { unpack4(*reinterpret_cast<const uint2*>(Xb + i * V2_C + c4), Yr); };
       uint2 addv[4];
       if (HAS_ADD) {
 #pragma unroll
@@ -1745,7 +1751,44 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
         }
       }
     }
-    if (Z3 && tile + (int)gridDim.x < a.ntiles) publish_g();     // nobody reads gus between barrier (2) and the next barrier (1)
+  };
+  const int G = (int)gridDim.x;
+  if (!P2) {
+    for (; tile < a.ntiles; tile += G) {
+      __syncthreads();   // (1) the previous tile's stencil is done with Dt / Xs, its MFMAs with Pt
+      if (Z3 && tile + G < a.ntiles) prefetch_g(tile + G);      // (published behind this tile's stencil)
+      transform(tile, Xs);
+      __syncthreads();   // (2)
+      mfma();
+      __syncthreads();   // (3)
+      stencil(tile, Xs);
+      if (Z3 && tile + G < a.ntiles) publish_g();     // nobody reads gus between barrier (2) and the next barrier (1)
+    }
+  } else if (tile < a.ntiles) {
+    // prologue: tile 0 up to its dD rows; then per tile: [transform(next) + stencil(this)] | barrier | [MFMAs(next)] | barrier
+    __syncthreads();
+    transform(tile, Xs);
+    if (Z3 && tile + G < a.ntiles) prefetch_g(tile + G);
+    __syncthreads();
+    mfma();
+    if (Z3 && tile + G < a.ntiles) publish_g();       // gus(tile) was read before the barrier above
+    __syncthreads();
+    int buf = 0;
+    for (; tile < a.ntiles; tile += G) {
+      const int next = tile + G;
+      if (next < a.ntiles) {
+        transform(next, Xs + (buf ^ 1) * V6_R * V2_C);       // Pt: the MFMAs of `tile` finished before the last barrier
+        if (Z3 && next + G < a.ntiles) prefetch_g(next + G);
+      }
+      stencil(tile, Xs + buf * V6_R * V2_C);
+      __syncthreads();
+      if (next < a.ntiles) {
+        mfma();                                               // Dt: the stencil of `tile` finished before the barrier
+        if (Z3 && next + G < a.ntiles) publish_g();           // gus(next) was read in the phase above
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
   }
   // s2 was accumulated against the RAW x:  sum dA * xhat = rstd * sum dA*x - mean*rstd * sum dA
 #pragma unroll
@@ -1773,32 +1816,43 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
 }
 
 
-template <int FL>
+template <int FL, bool P2>
 inline int launch_dgrad_dw_v6_t(DgradDwArgs a, int grid, size_t smem, hipStream_t st) {
-  auto kern = a.bn.rm.len ? dgrad_dw_v6_kernel<FL, true> : dgrad_dw_v6_kernel<FL, false>;
+  auto kern = a.bn.rm.len ? dgrad_dw_v6_kernel<FL, true, false, P2> : dgrad_dw_v6_kernel<FL, false, false, P2>;
   if constexpr (FL == 7 || FL == 3) {
-    if (a.gu) kern = a.bn.rm.len ? dgrad_dw_v6_kernel<FL, true, true> : dgrad_dw_v6_kernel<FL, false, true>;
+    if (a.gu) kern = a.bn.rm.len ? dgrad_dw_v6_kernel<FL, true, true, P2> : dgrad_dw_v6_kernel<FL, false, true, P2>;
   } else if (a.gu) return -1000;
   TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
   return (int)hipGetLastError();
 }
-// -1000: no specialisation for this flag combination
-inline int launch_dgrad_dw_v6(DgradDwArgs a, int max_wgs, hipStream_t st) {
+// -1000: no specialisation for this flag combination.  p2: the two-barrier schedule (dgrad_dw_v6_kernel<.., P2>): bit-identical,
+// measured 45.5 vs 40.7 - 46.8 us in the harness and +0.1 ms on the step (the merged phase is longer than the two it replaces:
+// the waves that finish their stencil strip early now wait for the slowest transform as well) - kept as an option, off
+inline int launch_dgrad_dw_v6(DgradDwArgs a, int max_wgs, hipStream_t st, bool p2 = false) {
   if (!a.Wswz) return -1000;
   a.ntiles = (a.M + V6_OUT - 1) / V6_OUT;
   const int grid = a.ntiles < max_wgs ? a.ntiles : max_wgs;
-  const size_t tiles = (size_t)(2 * V6_R * V2_AP + V6_R * V2_C) * sizeof(bf16_t);
+  const size_t tiles = (size_t)(2 * V6_R * V2_AP + (p2 ? 2 : 1) * V6_R * V2_C) * sizeof(bf16_t);
   const size_t red = (size_t)8 * 6 * V2_C * sizeof(float);
   const size_t smem = (tiles > red ? tiles : red) + (size_t)(a.gu ? 12 + 4 : 10) * V2_C * sizeof(float);
   const int fl = (a.actX.mode != 0 ? 1 : 0) | (a.actX.relu ? 2 : 0) | (a.actX.drop_thr ? 4 : 0) | (a.ADD ? 8 : 0);
   // (Z3: the output activation carries dropout exactly when the input activation does — one model-wide rate)
   if (a.gu && ((a.act3.drop_thr != 0) != (a.actX.drop_thr != 0) || a.act3.mode == 0 || !a.act3.relu)) return -1000;
+  if (p2) {
+    switch (fl) {
+      case 7: return launch_dgrad_dw_v6_t<7, true>(a, grid, smem, st);
+      case 3: return launch_dgrad_dw_v6_t<3, true>(a, grid, smem, st);
+      case 8: return launch_dgrad_dw_v6_t<8, true>(a, grid, smem, st);
+      case 11: return launch_dgrad_dw_v6_t<11, true>(a, grid, smem, st);
+      default: return -1000;
+    }
+  }
   switch (fl) {
-    case 7: return launch_dgrad_dw_v6_t<7>(a, grid, smem, st);
-    case 3: return launch_dgrad_dw_v6_t<3>(a, grid, smem, st);
-    case 8: return launch_dgrad_dw_v6_t<8>(a, grid, smem, st);
-    case 11: return launch_dgrad_dw_v6_t<11>(a, grid, smem, st);
+    case 7: return launch_dgrad_dw_v6_t<7, false>(a, grid, smem, st);
+    case 3: return launch_dgrad_dw_v6_t<3, false>(a, grid, smem, st);
+    case 8: return launch_dgrad_dw_v6_t<8, false>(a, grid, smem, st);
+    case 11: return launch_dgrad_dw_v6_t<11, false>(a, grid, smem, st);
     default: return -1000;
   }
 }

@@ -30,24 +30,25 @@ int main(int argc, char** argv) {
   a.actX.mode = 1; a.actX.stats = stats; a.actX.gamma = gamma; a.actX.beta = beta; a.actX.inv_n = 1.f / M; a.actX.eps = 1e-5f; a.actX.relu = 1;
   a.actX.drop_thr = 6554; a.actX.inv_keep = 1.f / 0.9f; a.actX.drop_key = 12345;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int which = 0; which < 2; ++which) {
+  for (int which = 0; which < 4; ++which) {
+    const bool p2 = which & 1;
     auto go = [&](int it) { const int s = it % NSET; a.dZ = dZ[s]; a.Y = Y[s]; a.X = X[s]; a.OUT = OUT[s];
-                            return launch_dgrad_dw_v6(a, 256, 0); };
+                            return launch_dgrad_dw_v6(a, 256, 0, p2); };
     for (int it = 0; it < 4; ++it) { int rc = go(it); if (rc) { printf("launch rc %d\n", rc); return 1; } }
     CK(hipDeviceSynchronize());
     hipEventRecord(e0, 0);
     for (int it = 0; it < 40; ++it) go(it);
     hipEventRecord(e1, 0); CK(hipEventSynchronize(e1));
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("%s<7>: %.2f us per launch (%.2f TB/s over 4 passes)\n", "dgrad_dw_v6", ms * 1e3f / 40, 4.0 * M * C * 2 / (ms * 1e-3 / 40) / 1e12);
+    printf("%s<7> %s: %.2f us per launch (%.2f TB/s over 4 passes)\n", "dgrad_dw_v6", p2 ? "two barriers per tile" : "three barriers per tile", ms * 1e3f / 40, 4.0 * M * C * 2 / (ms * 1e-3 / 40) / 1e12);
   }
   // checksum of the two outputs on the same inputs
-  a.dZ = dZ[0]; a.Y = Y[0]; a.X = X[0]; a.OUT = OUT[0]; launch_dgrad_dw_v6(a, 256, 0);
-  a.OUT = OUT[1]; launch_dgrad_dw_v6(a, 256, 0);
+  a.dZ = dZ[0]; a.Y = Y[0]; a.X = X[0]; a.OUT = OUT[0]; launch_dgrad_dw_v6(a, 256, 0, false);
+  a.OUT = OUT[1]; launch_dgrad_dw_v6(a, 256, 0, true);
   CK(hipDeviceSynchronize());
   std::vector<unsigned short> o0((size_t)M * C), o1((size_t)M * C);
   CK(hipMemcpy(o0.data(), OUT[0], o0.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(o1.data(), OUT[1], o1.size() * 2, hipMemcpyDeviceToHost));
   size_t diff = 0; for (size_t i = 0; i < o0.size(); ++i) diff += o0[i] != o1[i];
-  printf("two launches on the same inputs: %zu of %zu elements differ\n", diff, o0.size());
+  printf("three-barrier vs two-barrier schedule on the same inputs: %zu of %zu elements differ\n", diff, o0.size());
   return 0;
 }
