@@ -104,14 +104,14 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   // dS^T * Q straight into the gradient buffer), layer by layer
   const bool pipe = sizeof(AT) == 2 && !use_v2 && p->wide_wgrad && training && H % 256 == 0 && D % 256 == 0;
   const bool batched_wgrad = sizeof(AT) == 2 && use_v2 && training && p->wg2_layers > 0;
-  // act_out (fused tail, the last sub-block of a mega block): dz already holds dS (bn_bwd_apply_z3_kernel rebuilt the layer's
+  // ds_ready (fused tail, the last sub-block of a mega block): dz already holds dS (bn_bwd_apply_z3_kernel rebuilt the layer's
   // incoming gradient from the tail's dZ before the skip path's in-place pass overwrote that)
   auto pipe_layer = [&](size_t dz, size_t y, const BnRef& bn, int Cout, const WcRef& wc, int Cin, size_t dx_out, const void* q, bool q_plain,
-                        const BnAct& qact, int64_t wgrad_off, const BnAct* act_out = nullptr, bool defer_tn = false) -> int {
+                        const BnAct& qact, int64_t wgrad_off, bool ds_ready = false, bool defer_tn = false) -> int {
     DBG("pipe dZ in", dz, (size_t)M * Cout); DBG("pipe Y", y, (size_t)M * Cout);
     DBGF("pipe bsums", ws + p->bsums[bn.id], TN_NREP * 2 * Cout); DBGF("pipe fstats", ws + p->stats[bn.id], TN_NREP * 2 * Cout);
     int rc = 0;
-    if (!act_out) rc = launch_bn_bwd_apply((bf16_t*)(ws + dz), (const bf16_t*)(ws + y), make_bnbwd(p, bn, M, training), M, Cout, st,
+    if (!ds_ready) rc = launch_bn_bwd_apply((bf16_t*)(ws + dz), (const bf16_t*)(ws + y), make_bnbwd(p, bn, M, training), M, Cout, st,
                                             p->fp8_bwd_emu && Cout == H);
     if (rc) return rc;
     DBG("pipe dS", dz, (size_t)M * Cout);
@@ -484,7 +484,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     DBG("block dOUT", p->dA[cur], (size_t)M * H); DBG("combine dZk", bw.dZk, (size_t)M * H); DBG("combine dY3", bw.dY[nsub - 1], (size_t)M * H);
     // ---- skip connection: d S = BN-backward(dZ); dXs = dS * W_skip; d W_skip = dS^T X
     if (pipe) {
-      int rc = pipe_layer(bw.dZk, bw.S, mb.bnskip, H, bw.wskip, H, p->dXs, xin, is_plain(actx), actx, mb.wskip, nullptr, tn_batched && i > 0);
+      int rc = pipe_layer(bw.dZk, bw.S, mb.bnskip, H, bw.wskip, H, p->dXs, xin, is_plain(actx), actx, mb.wskip, false, tn_batched && i > 0);
       if (rc) return rc;
     } else
     {
@@ -559,7 +559,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       if (pipe) {
         const bool z3 = fuse_tail_wide && j == nsub - 1;
         int rc = pipe_layer(bw.dY[j], bw.Y[j], sb.bn, H, bw.wpw[j], H, p->dD, ws + bw.Q[j], true, identity_act(), sb.wpw,
-                            z3 ? &act3 : nullptr, tn_batched);
+                            z3, tn_batched);
         if (rc) return rc;
       } else {
         GemmShape g{M, H, H, wt(bw.wpw[j])};
