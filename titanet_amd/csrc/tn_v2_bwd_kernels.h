@@ -325,7 +325,13 @@ __global__ void wgrad_v2_reduce_kernel(const WgradV2Out* __restrict__ outs, cons
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V2_C * V2_C; i += gridDim.x * blockDim.x) {
     if ((i >> 8) >= nrow || (i & 255) >= ncol) continue;
     float s = 0.f;
-    for (int k = 0; k < parts; ++k) s += o.slabs[(size_t)k * V2_C * V2_C + i];
+    for (int k0 = 0; k0 < parts; k0 += 4) {        // the partial slabs of an element fetched together, not one round trip each
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (k0 + u < parts) ? o.slabs[(size_t)(k0 + u) * V2_C * V2_C + i] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += v[u];
+    }
     o.out[(size_t)(i >> 8) * o.ld + (i & 255)] = s;
   }
 }
