@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #define TN_NREP 8          // replicated atomic accumulators per statistic (spreads same-address atomics)
 #define TN_WAVE 64

@@ -1004,7 +1004,7 @@ inline int launch_combine_bwd2_v2(const CombineBwd2V2Args& a, int B, hipStream_t
 //     the strip (slots = row index mod K, all compile-time): a window row is read from LDS and unpacked once per strip
 //     instead of once per tap, and ONE window serves both the data gradient and the tap-weight gradient (see the fast
 //     path); 2 K FMAs per output and channel remain, which is what bounds the kernel at K = 11;
-//   * strips whose window crosses an utterance / batch boundary take a per-tap path with wave-uniform tests.
+//   * strips whose window crosses an utterance / batch boundary roll the same window with a wave-uniform test per tap.
 // FL bits as in dw_bwd_v4: 1 BatchNorm on load of X, 2 ReLU, 4 dropout, 8 skip-path addend.
 // ==========================================================================================
 // wait until at most N younger vector-memory operations are outstanding, naming the registers of the asm loads this retires
@@ -1158,108 +1158,89 @@ __global__ __launch_bounds__(512, 2) void dw_bwd_slab_kernel(DwBwdSlabArgs a) {
       for (int i = 0; i < CH; ++i) z[i] = 0.f;
 #pragma unroll
       for (int o = 0; o < RS; ++o) st_ch<CH>(a.OUT + (size_t)(out0 + l0 + o) * a.C + cb + cl, z);
-    } else if (fast) {
+    } else {
       // d w[k] = sum_r dD[r] A[r + k - pad] is summed here over the A rows of the strip (r' = r + k - pad): its dD operand is
       // then dD[r' - k + pad], the SAME row the data gradient of output row r' multiplies with w[k] — one window (of dD) serves
       // both sums and the activation is evaluated once per output row, not once per window row.
-      float D[KD][CH];
+      // ONE body for both kinds of strip: strips whose window crosses an utterance / batch / length boundary roll the same
+      // register window and only add a wave-uniform test per tap (a separate per-tap path reading LDS cost 4x a plain strip,
+      // and with one barrier per tile every workgroup waited for its slowest strip: 189 -> 1xx us per TitaNet-L layer).
+      auto body = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        float D[KD][CH];
 #pragma unroll
-      for (int j = 0; j < KD - 1; ++j) ld_ch<CH>(Ds + (l0 + j) * V2_C + cl, D[j % KD]);
+        for (int j = 0; j < KD - 1; ++j) ld_ch<CH>(Ds + (l0 + j) * V2_C + cl, D[j % KD]);
+        // frame of output row 0 of the strip and the valid frames of its utterance (boundary strips only)
+        int t = 0, Lb = a.T;
+        if constexpr (!FAST) {
+          const int gr0 = out0 + l0;
+          t = gr0 % a.T;
+          if (len && gr0 < a.M) Lb = tn_sload_i32(len, gr0 / a.T);
+        }
 #pragma unroll
-      for (int o = 0; o < RS; ++o) {
-        ld_ch<CH>(Ds + (l0 + o + KD - 1) * V2_C + cl, D[(o + KD - 1) % KD]);
-        float y[CH], Ac[CH], dA[CH];
-        ld_ch<CH>(Xs + (l0 + o + PADR) * V2_C + cl, y);
+        for (int o = 0; o < RS; ++o) {
+          ld_ch<CH>(Ds + (l0 + o + KD - 1) * V2_C + cl, D[(o + KD - 1) % KD]);
+          const int gr = out0 + l0 + o;
+          if (FAST || gr < a.M) {
+            float y[CH], Ac[CH], dA[CH];
+            ld_ch<CH>(Xs + (l0 + o + PADR) * V2_C + cl, y);
 #pragma unroll
-        for (int i = 0; i < CH; ++i) { Ac[i] = y[i]; dA[i] = 0.f; }
-        act_c<(FL & 7), CH>(Ac, sc, sh, dkey, dthr, (uint32_t)(g_first + o + PADR), a.C, cb + cl);
+            for (int i = 0; i < CH; ++i) { Ac[i] = y[i]; dA[i] = 0.f; }
+            act_c<(FL & 7), CH>(Ac, sc, sh, dkey, dthr, (uint32_t)gr, a.C, cb + cl);
+            // padding frame (variable-length batch): no tap-weight gradient through it, its data gradient is written as zero
+            // (dD of a padding row is zero where it was computed; row tiles that are padding only are skipped by the pipelined
+            //  data-gradient GEMM and hold stale values: never read them as data)
+            const bool pad = !FAST && t >= Lb;
+            if (pad) {
 #pragma unroll
-        for (int k = 0; k < KD; ++k) {
-          const int sl = (o + KD - 1 - k) % KD;
+              for (int i = 0; i < CH; ++i) Ac[i] = 0.f;
+            }
 #pragma unroll
-          for (int i = 0; i < CH; ++i) {
-            dA[i] = fmaf(wd[k][i], D[sl][i], dA[i]);
-            gw[k][i] = fmaf(Ac[i], D[sl][i], gw[k][i]);
+            for (int k = 0; k < KD; ++k) {
+              const int sl = (o + KD - 1 - k) % KD;
+              const int tb = t - k + PADR;             // frame of dD[gr - k + PADR]: inside this utterance (and a valid frame)?
+              if (FAST || (tb >= 0 && tb < Lb)) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                  dA[i] = fmaf(wd[k][i], D[sl][i], dA[i]);
+                  gw[k][i] = fmaf(Ac[i], D[sl][i], gw[k][i]);
+                }
+              }
+            }
+            if (!pad) {
+#pragma unroll
+              for (int i = 0; i < CH; ++i) gb[i] += D[(o + PADR) % KD][i];
+            }
+            if (HAS_ADD) {
+#pragma unroll
+              for (int i = 0; i < CH; ++i) dA[i] += addv[o][i];
+            }
+            if (pad) {
+#pragma unroll
+              for (int i = 0; i < CH; ++i) dA[i] = 0.f;
+            }
+            if (HAS_MASK) {
+#pragma unroll
+              for (int i = 0; i < CH; ++i) {
+                const float m = (FL & 2) ? ((Ac[i] > 0.f) ? mscale : 0.f) : mscale;
+                dA[i] *= m;
+                s1[i] += dA[i];
+                s2[i] = fmaf(dA[i], y[i], s2[i]);
+              }
+            }
+            st_ch<CH>(a.OUT + (size_t)gr * a.C + cb + cl, dA);
+            if constexpr (!FAST) {
+              if (++t == a.T) {                        // the next output row opens the next utterance
+                t = 0;
+                Lb = (len && gr + 1 < a.M) ? tn_sload_i32(len, (gr + 1) / a.T) : a.T;
+              }
+            }
           }
+          __builtin_amdgcn_sched_barrier(0);           // rows in order: bounds the live temporaries
         }
-#pragma unroll
-        for (int i = 0; i < CH; ++i) gb[i] += D[(o + PADR) % KD][i];
-        const size_t oo = (size_t)(out0 + l0 + o) * a.C + cb + cl;
-        if (HAS_ADD) {
-#pragma unroll
-          for (int i = 0; i < CH; ++i) dA[i] += addv[o][i];
-        }
-        if (HAS_MASK) {
-#pragma unroll
-          for (int i = 0; i < CH; ++i) {
-            const float m = (FL & 2) ? ((Ac[i] > 0.f) ? mscale : 0.f) : mscale;
-            dA[i] *= m;
-            s1[i] += dA[i];
-            s2[i] = fmaf(dA[i], y[i], s2[i]);
-          }
-        }
-        st_ch<CH>(a.OUT + oo, dA);
-        __builtin_amdgcn_sched_barrier(0);       // rows in order: bounds the live temporaries
-      }
-    } else {
-      // boundary strips: per-tap tests (wave-uniform), the dD rows straight from LDS
-#pragma unroll 1
-      for (int o = 0; o < RS; ++o) {
-        const int gr = out0 + l0 + o;
-        if (gr >= a.M) break;
-        const int t = gr % a.T;
-        float Dc[CH], dA[CH], Ac[CH], Yc[CH];
-        ld_ch<CH>(Ds + (l0 + o + PADR) * V2_C + cl, Dc);
-        ld_ch<CH>(Xs + (l0 + o + PADR) * V2_C + cl, Yc);
-#pragma unroll
-        for (int i = 0; i < CH; ++i) { dA[i] = 0.f; Ac[i] = Yc[i]; }
-        act_c<(FL & 7), CH>(Ac, sc, sh, dkey, dthr, (uint32_t)gr, a.C, cb + cl);
-        bool pad = false;
-        int Lb = a.T;                                // valid frames of this row's utterance
-        if (len) {
-          Lb = tn_sload_i32(len, gr / a.T);
-          pad = t >= Lb;
-        }
-        if (pad) {
-          // (dD of a padding row is zero where it was computed; row tiles that are padding only are skipped by the pipelined
-          //  data-gradient GEMM and hold stale values: never read them as data)
-#pragma unroll
-          for (int i = 0; i < CH; ++i) { Ac[i] = 0.f; Dc[i] = 0.f; }
-        }
-#pragma unroll
-        for (int i = 0; i < CH; ++i) gb[i] += Dc[i];
-#pragma unroll
-        for (int k = 0; k < KD; ++k) {
-          const int tb = t - k + PADR;               // frame of dD[gr - k + PADR]: inside this utterance (and a valid frame)?
-          if (tb >= 0 && tb < Lb) {
-            float v[CH];
-            ld_ch<CH>(Ds + (l0 + o + KD - 1 - k) * V2_C + cl, v);
-#pragma unroll
-            for (int i = 0; i < CH; ++i) { dA[i] = fmaf(wd[k][i], v[i], dA[i]); gw[k][i] = fmaf(Ac[i], v[i], gw[k][i]); }
-          }
-        }
-        const size_t oo = (size_t)gr * a.C + cb + cl;
-        if (HAS_ADD) {
-          float ad[CH];
-          ld_ch<CH>(a.ADD + oo, ad);
-#pragma unroll
-          for (int i = 0; i < CH; ++i) dA[i] += ad[i];
-        }
-        if (pad) {
-#pragma unroll
-          for (int i = 0; i < CH; ++i) dA[i] = 0.f;
-        }
-        if (HAS_MASK) {
-#pragma unroll
-          for (int i = 0; i < CH; ++i) {
-            const float m = (FL & 2) ? ((Ac[i] > 0.f) ? mscale : 0.f) : mscale;
-            dA[i] *= m;
-            s1[i] += dA[i];
-            s2[i] = fmaf(dA[i], Yc[i], s2[i]);
-          }
-        }
-        st_ch<CH>(a.OUT + oo, dA);
-      }
+      };
+      if (fast) body(std::true_type{});
+      else body(std::false_type{});
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

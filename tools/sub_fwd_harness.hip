@@ -44,6 +44,22 @@ int main(int argc, char** argv) {
       float ms; hipEventElapsedTime(&ms, e0, e1);
       printf("sub_fwd_v5<3,true,7> rows/tile %d, depthwise output %s: %.2f us per launch\n", r32 ? 32 : 64, keepq ? "kept" : "not kept", ms * 1e3f / 40);
     }
+  // the skip conv (plain 1x1 on a stored block input): sub_fwd_v4 vs the producer / consumer kernel at both tile heights
+  {
+    SubFwdV2Args b = a; b.act = BnAct{}; b.wdw = nullptr; b.bdw = nullptr; b.Q = nullptr;
+    for (int rep = 0; rep < 2; ++rep)
+      for (int variant = 0; variant < 3; ++variant) {
+        auto go = [&](int it) { const int s = it % NSET; b.X = X[s]; b.Y = Y[s];
+                                return variant == 0 ? launch_sub_fwd_v4<1, false>(b, 256, 0) : variant == 1 ? launch_sub_fwd_v5<1, false, 64>(b, 256, 0) : launch_sub_fwd_v5<1, false, 32>(b, 256, 0); };
+        for (int it = 0; it < 4; ++it) { int rc = go(it); if (rc) { printf("launch rc %d\n", rc); return 1; } }
+        CK(hipDeviceSynchronize());
+        hipEventRecord(e0, 0);
+        for (int it = 0; it < 40; ++it) go(it);
+        hipEventRecord(e1, 0); CK(hipEventSynchronize(e1));
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("skip conv 1x1: %s: %.2f us per launch\n", variant == 0 ? "sub_fwd_v4" : variant == 1 ? "sub_fwd_v5, 64-row tiles" : "sub_fwd_v5, 32-row tiles", ms * 1e3f / 40);
+      }
+  }
   // same result from both tile shapes?
   a.X = X[0]; a.Q = Q[0]; a.Y = Y[0]; launch_sub_fwd_v5<3, true, 64>(a, 256, 0);
   a.Q = Q[1]; a.Y = Y[1]; launch_sub_fwd_v5<3, true, 32>(a, 256, 0);
