@@ -1630,113 +1630,81 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
           addv[q] = (q < NR && gr >= 0 && gr < a.M) ? *reinterpret_cast<const uint2*>(a.ADD + (size_t)gr * V2_C + c4) : make_uint2(0, 0);
         }
       }
-      if (fast) {
-        // rolling 3-row window of dD (slots j % 3).  The tap-weight gradient d w[k] = sum_r dD[r] A[r + k - 1] is summed over
-        // the A rows of the strip (r' = r + k - 1): its dD operand dD[r' - k + 1] is then a row of the SAME window the data
-        // gradient of output row r' uses, and the activation is evaluated for the output rows only (4 per strip, not 6).
+      // rolling 3-row window of dD (slots j % 3).  The tap-weight gradient d w[k] = sum_r dD[r] A[r + k - 1] is summed over
+      // the A rows of the strip (r' = r + k - 1): its dD operand dD[r' - k + 1] is then a row of the SAME window the data
+      // gradient of output row r' uses, and the activation is evaluated for the output rows only (4 per strip, not 6).
+      // Boundary strips (utterance edges, ends of the batch, padding frames) roll the same window and add wave-uniform tests
+      // per row and tap — every wave of the tile waits for the slowest strip at the next barrier.
+      auto strip = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
         float D[3][4];
-        auto place = [&](int j, int slot) { ldD(i0 - 1 + j, D[slot]); };
-        place(0, 0);
-        place(1, 1);
+        ldD(i0 - 1, D[0]);
+        ldD(i0, D[1]);
+        int t = 0;
+        if constexpr (!FAST) t = (g0 + i0) % a.T;                 // frame of the strip's first output row (g0 + i0 >= 0)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           if (q == 3 && !nr4) break;
           const int P = q % 3, C_ = (q + 1) % 3, N = (q + 2) % 3;
-          place(q + 2, N);
-          float Yr[4], Ac[4], dA[4];
-          ldX(i0 + q, Yr);
+          ldD(i0 + q + 1, D[N]);
+          const int gr = g0 + i0 + q;
+          if (FAST || gr < a.M) {
+            float Yr[4], Ac[4], dA[4];
+            ldX(i0 + q, Yr);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) Ac[i] = Yr[i];
-          act4_t<FL>(Ac, sc, sh, dkey, dthr, (uint32_t)(gfirst + q + 1), c4);
+            for (int i = 0; i < 4; ++i) Ac[i] = Yr[i];
+            act4_t<FL>(Ac, sc, sh, dkey, dthr, (uint32_t)gr, c4);
+            const bool pad = !FAST && MK && !tn_tile_valid(tm, gr);
+            if (pad) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            gb[i] += D[C_][i];
-            dA[i] = wd[1][i] * D[C_][i];
-            dA[i] = fmaf(wd[0][i], D[N][i], dA[i]);
-            dA[i] = fmaf(wd[2][i], D[P][i], dA[i]);
-            gw[0][i] = fmaf(Ac[i], D[N][i], gw[0][i]);
-            gw[1][i] = fmaf(Ac[i], D[C_][i], gw[1][i]);
-            gw[2][i] = fmaf(Ac[i], D[P][i], gw[2][i]);
-          }
-          if (HAS_ADD) {
-            float ad[4];
-            unpack4(addv[q], ad);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dA[i] += ad[i];
-          }
-          if (HAS_MASK) {
+              for (int i = 0; i < 4; ++i) Ac[i] = 0.f;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const float m = (FL & 2) ? ((Ac[i] > 0.f) ? mscale : 0.f) : mscale;
-              dA[i] *= m;
-              s1[i] += dA[i];
-              s2[i] = fmaf(dA[i], Yr[i], s2[i]);
+              gb[i] += D[C_][i];
+              dA[i] = wd[1][i] * D[C_][i];
+              gw[1][i] = fmaf(Ac[i], D[C_][i], gw[1][i]);
+            }
+            if (FAST || (t + 1 < a.T && gr + 1 < a.M)) {          // the next row belongs to the same utterance
+#pragma unroll
+              for (int i = 0; i < 4; ++i) { dA[i] = fmaf(wd[0][i], D[N][i], dA[i]); gw[0][i] = fmaf(Ac[i], D[N][i], gw[0][i]); }
+            }
+            if (FAST || t > 0) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) { dA[i] = fmaf(wd[2][i], D[P][i], dA[i]); gw[2][i] = fmaf(Ac[i], D[P][i], gw[2][i]); }
+            }
+            if (HAS_ADD) {
+              float ad[4];
+              unpack4(addv[q], ad);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) dA[i] += ad[i];
+            }
+            if (pad) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) dA[i] = 0.f;
+            }
+            if (HAS_MASK) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float m = (FL & 2) ? ((Ac[i] > 0.f) ? mscale : 0.f) : mscale;
+                dA[i] *= m;
+                s1[i] += dA[i];
+                s2[i] = fmaf(dA[i], Yr[i], s2[i]);
+              }
+            }
+            uint2 ov;
+            ov.x = f2bf_pk(dA[0], dA[1]);
+            ov.y = f2bf_pk(dA[2], dA[3]);
+            *reinterpret_cast<uint2*>(a.OUT + (size_t)gr * V2_C + c4) = ov;
+            if constexpr (!FAST) {
+              if (++t == a.T) t = 0;
             }
           }
-          uint2 ov;
-          ov.x = f2bf_pk(dA[0], dA[1]);
-          ov.y = f2bf_pk(dA[2], dA[3]);
-          *reinterpret_cast<uint2*>(a.OUT + (size_t)(g0 + i0 + q) * V2_C + c4) = ov;
           __builtin_amdgcn_sched_barrier(0);       // rows in order: bounds the live temporaries
         }
-      } else {
-        // boundary strips (utterance edges, ends of the batch, the short last strip): per-row wave-uniform tests
-#pragma unroll 1
-        for (int q = 0; q < NR; ++q) {
-          const int i = i0 + q, gr = g0 + i;
-          if (i > V6_OUT || gr < 0 || gr >= a.M) continue;
-          const int t = gr % a.T;
-          const bool pad = MK && !tn_tile_valid(tm, gr);
-          float Dc[4], Dn[4], Dp[4], Ac[4], Yc[4], dA[4];
-          ldD(i, Dc); ldX(i, Yc);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) Ac[c] = Yc[c];
-          act4_t<FL>(Ac, sc, sh, dkey, dthr, (uint32_t)gr, c4);
-          if (pad) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) Ac[c] = 0.f;
-          }
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            gb[c] += Dc[c];
-            dA[c] = wd[1][c] * Dc[c];
-            gw[1][c] = fmaf(Ac[c], Dc[c], gw[1][c]);
-          }
-          if (t + 1 < a.T && gr + 1 < a.M) {      // next row belongs to the same utterance (tile row i + 1 <= 31 exists)
-            ldD(i + 1, Dn);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { dA[c] = fmaf(wd[0][c], Dn[c], dA[c]); gw[0][c] = fmaf(Ac[c], Dn[c], gw[0][c]); }
-          }
-          if (t > 0) {
-            ldD(i - 1, Dp);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { dA[c] = fmaf(wd[2][c], Dp[c], dA[c]); gw[2][c] = fmaf(Ac[c], Dp[c], gw[2][c]); }
-          }
-          if (HAS_ADD) {
-            float ad[4];
-            unpack4(*reinterpret_cast<const uint2*>(a.ADD + (size_t)gr * V2_C + c4), ad);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) dA[c] += ad[c];
-          }
-          if (pad) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) dA[c] = 0.f;
-          }
-          if (HAS_MASK) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const float m = (FL & 2) ? ((Ac[c] > 0.f) ? mscale : 0.f) : mscale;
-              dA[c] *= m;
-              s1[c] += dA[c];
-              s2[c] = fmaf(dA[c], Yc[c], s2[c]);
-            }
-          }
-          uint2 ov;
-          ov.x = f2bf_pk(dA[0], dA[1]);
-          ov.y = f2bf_pk(dA[2], dA[3]);
-          *reinterpret_cast<uint2*>(a.OUT + (size_t)gr * V2_C + c4) = ov;
-        }
-      }
+      };
+      if (fast) strip(std::true_type{});
+      else strip(std::false_type{});
     }
   };
   const int G = (int)gridDim.x;
