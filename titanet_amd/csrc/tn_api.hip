@@ -171,6 +171,14 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   p->B = batch; p->T = frames; p->M = batch * frames; p->prec = precision;
   p->fp8 = precision == TN_PREC_FP8;
   { const char* e = getenv("TN_FP8_BWD_EMU"); p->fp8_bwd_emu = p->fp8 && e && atoi(e) != 0; }
+  {
+    // fp8 data gradients of the sub-block pointwise convs (wide models on the pipelined GEMMs; a row of dS is one or two waves
+    // of the BatchNorm-backward pass that quantises it)
+    const char* e = getenv("TN_FP8_BWD");
+    const int Hh = m->cfg.hidden;
+    p->fp8_bwd = p->fp8 && !p->fp8_bwd_emu && (Hh == 512 || Hh == 1024) && ((size_t)batch * frames * (Hh / 8)) % 256 == 0 &&
+                 !(e && atoi(e) == 0);
+  }
   if (p->fp8) precision = TN_PREC_BF16;      // storage, statistics and the backward pass are the bf16 plan's
   p->prec = precision;
   p->esz = precision == TN_PREC_BF16 ? 2 : 4;
@@ -266,7 +274,17 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     p->q8 = b.take(M * H);
     for (auto& bw : p->blk)
       for (int j = 0; j < c.n_sub_blocks; ++j) { bw.w8.push_back(b.take(H * H)); bw.w8s.push_back(b.take(H * sizeof(float))); }
-    p->fp8_table = b.take(sizeof(Fp8CastDesc) * (size_t)std::max(1, c.n_mega_blocks * c.n_sub_blocks));
+    p->fp8_table = b.take(sizeof(Fp8CastDesc) * (size_t)std::max(1, c.n_mega_blocks * (2 * c.n_sub_blocks + 1)));
+    if (p->fp8_bwd) {
+      p->ds8 = b.take(M * H);
+      p->dsexp = b.take(((size_t)(M + 255) / 256) * 256);
+      p->ds8s = b.take(M * H);
+      p->dsexps = b.take(((size_t)(M + 255) / 256) * 256);
+      for (auto& bw : p->blk) {
+        for (int j = 0; j < c.n_sub_blocks; ++j) { bw.w8t.push_back(b.take(H * H)); bw.w8ts.push_back(b.take(H * sizeof(float))); }
+        bw.w8t_skip = b.take(H * H); bw.w8ts_skip = b.take(H * sizeof(float));
+      }
+    }
   }
   p->E = b.take(M * D * e);
   p->HID = b.take(M * A * e + 512);      // + slack: the batched weight-gradient units read it 256 wide (row stride 128)
@@ -525,10 +543,19 @@ extern "C" int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbu
   }
   if (p->fp8) {
     std::vector<Fp8CastDesc> fd;
-    for (int i = 0; i < c.n_mega_blocks; ++i)
+    for (int i = 0; i < c.n_mega_blocks; ++i) {
+      if (p->fp8_bwd)
+        fd.push_back(Fp8CastDesc{nullptr, (uint8_t*)(p->ws + p->blk[i].w8t_skip), (float*)(p->ws + p->blk[i].w8ts_skip), c.hidden, c.hidden,
+                                 (const bf16_t*)(p->ws + p->blk[i].wskip.wt)});
       for (int j = 0; j < c.n_sub_blocks; ++j)
+      {
         fd.push_back(Fp8CastDesc{params + m->blocks[i].sub[j].wpw, (uint8_t*)(p->ws + p->blk[i].w8[j]), (float*)(p->ws + p->blk[i].w8s[j]),
-                                 c.hidden, c.hidden});
+                                 c.hidden, c.hidden, nullptr});
+        if (p->fp8_bwd)      // rows of the transposed bf16 copy (cast_params_kernel runs first)
+          fd.push_back(Fp8CastDesc{nullptr, (uint8_t*)(p->ws + p->blk[i].w8t[j]), (float*)(p->ws + p->blk[i].w8ts[j]), c.hidden, c.hidden,
+                                   (const bf16_t*)(p->ws + p->blk[i].wpw[j].wt)});
+      }
+    }
     p->n_fp8 = (int)fd.size();
     if (p->n_fp8) TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->fp8_table, fd.data(), fd.size() * sizeof(Fp8CastDesc), hipMemcpyHostToDevice, st));
     TN_CHECK_HIP(hipStreamSynchronize(st));

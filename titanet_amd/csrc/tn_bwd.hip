@@ -107,20 +107,33 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   // ds_ready (fused tail, the last sub-block of a mega block): dz already holds dS (bn_bwd_apply_z3_kernel rebuilt the layer's
   // incoming gradient from the tail's dZ before the skip path's in-place pass overwrote that)
   auto pipe_layer = [&](size_t dz, size_t y, const BnRef& bn, int Cout, const WcRef& wc, int Cin, size_t dx_out, const void* q, bool q_plain,
-                        const BnAct& qact, int64_t wgrad_off, bool ds_ready = false, bool defer_tn = false) -> int {
+                        const BnAct& qact, int64_t wgrad_off, bool ds_ready = false, bool defer_tn = false,
+                        Fp8Rows f8rows = Fp8Rows{nullptr, nullptr}, size_t w8t = 0, size_t w8ts = 0) -> int {
     DBG("pipe dZ in", dz, (size_t)M * Cout); DBG("pipe Y", y, (size_t)M * Cout);
     DBGF("pipe bsums", ws + p->bsums[bn.id], TN_NREP * 2 * Cout); DBGF("pipe fstats", ws + p->stats[bn.id], TN_NREP * 2 * Cout);
     int rc = 0;
+    // f8rows (fp8 plans, hidden x hidden layers): the pass also writes dS as e4m3 rows + row exponents, the data gradient below
+    // reads those
+    const bool f8 = f8rows.q != nullptr;
     if (!ds_ready) rc = launch_bn_bwd_apply((bf16_t*)(ws + dz), (const bf16_t*)(ws + y), make_bnbwd(p, bn, M, training), M, Cout, st,
-                                            p->fp8_bwd_emu && Cout == H);
+                                            p->fp8_bwd_emu && Cout == H, f8rows);
     if (rc) return rc;
     DBG("pipe dS", dz, (size_t)M * Cout);
-    GemmShape g{M, Cin, Cout, ws + wc.wt};
     const bool listed = p->masked && p->n_rowtiles > 0;
     const int* rowtiles = listed ? (const int*)(ws + p->rowtiles) : nullptr;
-    PGemmNtArgs pa{(const bf16_t*)(ws + dz), Cout, rowtiles, listed ? p->n_rowtiles : 0};
-    PGemmEpiArgs pe{(bf16_t*)(ws + dx_out), Cin, nullptr, nullptr, nullptr};
-    rc = launch_pgemm_nt(g, pa, pe, st);
+    if (f8) {
+      // dX = (dS8 2^e) * (W^T8 s[ci]): e4m3 x e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4, row exponents as its A block scale,
+      // the weight scales in the epilogue
+      GemmShape g8{M, Cin, Cout, ws + w8t};
+      PGemmNtArgs pa8{(const bf16_t*)f8rows.q, Cout, rowtiles, listed ? p->n_rowtiles : 0, f8rows.rowexp};
+      PGemmEpiArgs pe8{(bf16_t*)(ws + dx_out), Cin, nullptr, nullptr, (const float*)(ws + w8ts)};
+      rc = launch_pgemm_nt_f8(g8, pa8, pe8, st);
+    } else {
+      GemmShape g{M, Cin, Cout, ws + wc.wt};
+      PGemmNtArgs pa{(const bf16_t*)(ws + dz), Cout, rowtiles, listed ? p->n_rowtiles : 0};
+      PGemmEpiArgs pe{(bf16_t*)(ws + dx_out), Cin, nullptr, nullptr, nullptr};
+      rc = launch_pgemm_nt(g, pa, pe, st);
+    }
     if (rc) return rc;
     DBG("pipe dX", dx_out, (size_t)M * Cin);
     if (q_plain && defer_tn) return 0;      // its weight gradient rides in the bucket's batched launch (finalize_bucket)
@@ -430,7 +443,9 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
           // dS of the last sub-block NOW: the skip connection's BatchNorm-backward pass below works in place on dZk
           rc = launch_bn_bwd_apply_z3((const bf16_t*)(ws + bw.dZk), (const bf16_t*)(ws + bw.Y[nsub - 1]),
                                       make_bnbwd(p, mb.sub[nsub - 1].bn, M, training), act3, (const float*)(ws + p->se_gu),
-                                      (bf16_t*)(ws + bw.dY[nsub - 1]), M, H, T, st);
+                                      (bf16_t*)(ws + bw.dY[nsub - 1]), M, H, T, st,
+                                      (p->fp8_bwd && !bw.w8t.empty()) ? Fp8Rows{(uint8_t*)(ws + p->ds8), (uint8_t*)(ws + p->dsexp)}
+                                                                     : Fp8Rows{nullptr, nullptr});
           if (rc) return rc;
         }
       } else {
@@ -484,7 +499,11 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     DBG("block dOUT", p->dA[cur], (size_t)M * H); DBG("combine dZk", bw.dZk, (size_t)M * H); DBG("combine dY3", bw.dY[nsub - 1], (size_t)M * H);
     // ---- skip connection: d S = BN-backward(dZ); dXs = dS * W_skip; d W_skip = dS^T X
     if (pipe) {
-      int rc = pipe_layer(bw.dZk, bw.S, mb.bnskip, H, bw.wskip, H, p->dXs, xin, is_plain(actx), actx, mb.wskip, false, tn_batched && i > 0);
+      // (fp8 plans: its own e4m3 dS buffer — the last sub-block's, written by the one-pass tail above, is still pending)
+      const bool f8s = p->fp8_bwd && bw.w8t_skip != 0;
+      int rc = pipe_layer(bw.dZk, bw.S, mb.bnskip, H, bw.wskip, H, p->dXs, xin, is_plain(actx), actx, mb.wskip, false, tn_batched && i > 0,
+                          f8s ? Fp8Rows{(uint8_t*)(ws + p->ds8s), (uint8_t*)(ws + p->dsexps)} : Fp8Rows{nullptr, nullptr},
+                          f8s ? bw.w8t_skip : 0, f8s ? bw.w8ts_skip : 0);
       if (rc) return rc;
     } else
     {
@@ -558,8 +577,10 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       }
       if (pipe) {
         const bool z3 = fuse_tail_wide && j == nsub - 1;
+        const bool f8 = p->fp8_bwd && !bw.w8t.empty();
         int rc = pipe_layer(bw.dY[j], bw.Y[j], sb.bn, H, bw.wpw[j], H, p->dD, ws + bw.Q[j], true, identity_act(), sb.wpw,
-                            z3, tn_batched);
+                            z3, tn_batched, f8 ? Fp8Rows{(uint8_t*)(ws + p->ds8), (uint8_t*)(ws + p->dsexp)} : Fp8Rows{nullptr, nullptr},
+                            f8 ? bw.w8t[j] : 0, f8 ? bw.w8ts[j] : 0);
         if (rc) return rc;
       } else {
         GemmShape g{M, H, H, wt(bw.wpw[j])};

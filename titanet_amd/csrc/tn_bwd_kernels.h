@@ -1294,8 +1294,12 @@ __global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const float* __restr
 // EMU8 (experiment, TN_FP8_BWD_EMU=1 on an fp8 plan): dS is rounded through e4m3 with one power-of-two scale per ROW — what a
 // data-gradient / weight-gradient GEMM on the f8f6f4 MFMA would read — so that the accuracy of an fp8 backward can be
 // measured against the parity tests before its kernels exist (C = 512 / 1024 only: a row is one or two waves).
-template <bool EMU8>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ dZ, const bf16_t* __restrict__ Y, BnBwd bn, int M, int C) {
+// MODE 2 (fp8 plans, hidden 512 / 1024): dS additionally as e4m3 bytes with one power-of-two scale per row + the E8M0 exponent
+// bytes (Fp8Rows, tn_common.h) — the operand of the data gradient on the f8f6f4 MFMA; the bf16 dS stays for the weight gradient
+// (a contraction over rows: per-row scales do not factor out of it).
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ dZ, const bf16_t* __restrict__ Y, BnBwd bn, int M, int C, Fp8Rows f8) {
+  constexpr bool EMU8 = MODE == 1, OUT8 = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) float pg_k[];      // k0, k1, k2 : [3][C]
   __shared__ float wmax[4];
   for (int c = threadIdx.x; c < C; c += 256) bn_bwd_coefs(bn, C, c, pg_k[c], pg_k[C + c], pg_k[2 * C + c]);
@@ -1305,17 +1309,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ 
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
     const int c0 = (int)(i % VC) * 8;
     float z[8], y[8];
-    if (!EMU8 && bn.rm.len && !tn_row_valid(bn.rm, (uint32_t)(i / VC))) {     // padding rows carry no gradient
+    const bool padrow = bn.rm.len && !tn_row_valid(bn.rm, (uint32_t)(i / VC));     // padding rows carry no gradient (uniform per row)
+    if (MODE == 0 && padrow) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) z[u] = 0.f;
       store8(dZ + i * 8, z);
       continue;
     }
-    load8(dZ + i * 8, z);
-    load8(Y + i * 8, y);
+    if (!padrow) {
+      load8(dZ + i * 8, z);
+      load8(Y + i * 8, y);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) z[u] = fmaf(pg_k[c0 + u], z[u], fmaf(pg_k[C + c0 + u], y[u], pg_k[2 * C + c0 + u]));
-    if (EMU8) {
+      for (int u = 0; u < 8; ++u) z[u] = fmaf(pg_k[c0 + u], z[u], fmaf(pg_k[C + c0 + u], y[u], pg_k[2 * C + c0 + u]));
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) z[u] = 0.f;
+    }
+    if (EMU8 || OUT8) {
+      // (every thread of the workgroup is in this iteration: M * VC is a multiple of 256, launch_bn_bwd_apply)
       float m = 0.f;
 #pragma unroll
       for (int u = 0; u < 8; ++u) m = fmaxf(m, fabsf(z[u]));
@@ -1328,16 +1339,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ 
         __syncthreads();
       }
       const float sc = tn_e4m3_row_scale(m);
-      tn_e4m3_roundtrip8(z, sc, 1.f / sc);
+      if (EMU8) tn_e4m3_roundtrip8(z, sc, 1.f / sc);
+      if (OUT8) {
+        *reinterpret_cast<uint2*>(f8.q + i * 8) = tn_e4m3_pack8(z, 1.f / sc);
+        if (c0 == 0) f8.rowexp[tn_rowexp_pos(i / VC)] = tn_e8m0_of_pow2(sc);
+      }
     }
     store8(dZ + i * 8, z);
   }
 }
-inline int launch_bn_bwd_apply(bf16_t* dZ, const bf16_t* Y, const BnBwd& bn, int M, int C, hipStream_t st, bool emu8 = false) {
+// emu8: the e4m3 round trip in place (experiment);  f8: also write the fp8 operand (q != null)
+inline int launch_bn_bwd_apply(bf16_t* dZ, const bf16_t* Y, const BnBwd& bn, int M, int C, hipStream_t st, bool emu8 = false, Fp8Rows f8 = Fp8Rows{nullptr, nullptr}) {
   if (C % 8 || C > 4096) return TN_E_UNSUPPORTED;
-  if (emu8 && !bn.rm.len && (C == 512 || C == 1024) && ((size_t)M * (C / 8)) % 256 == 0)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C);
+  const bool rows_ok = (C == 512 || C == 1024) && ((size_t)M * (C / 8)) % 256 == 0;
+  if (f8.q && !rows_ok) return TN_E_UNSUPPORTED;
+  if (f8.q)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C, f8);
+  else if (emu8 && !bn.rm.len && rows_ok)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C, f8);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C, f8);
   return (int)hipGetLastError();
 }

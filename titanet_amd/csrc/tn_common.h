@@ -299,6 +299,28 @@ __device__ __forceinline__ void tn_e4m3_roundtrip8(float v[8], float s, float in
 __device__ __forceinline__ float tn_e4m3_row_scale(float amax) {
   return amax > 0.f ? exp2f(ceilf(log2f(amax * (1.f / 448.f)))) : 1.f;
 }
+// ---- fp8 data gradient (TN_PREC_FP8 plans, tn_pgemm.h F8 + rowexp): the BatchNorm-backward passes also write dS as e4m3
+// bytes, each row scaled by its own power of two 2^-e, and e as an E8M0 byte (127 + e) — the per-row block scale operand
+// of v_mfma_scale_f32_32x32x64_f8f6f4, so the scale costs the GEMM nothing.  The exponent bytes are stored in the order the
+// GEMM's lanes read them: the four 32-row fragments a lane (wave row wm, fragment row fi) multiplies in a 256-row tile are
+// rows 128 h + 64 wm + 32 mt + fi — their bytes form ONE dword at index 32 wm + fi of the tile's 256 bytes.
+__host__ __device__ __forceinline__ size_t tn_rowexp_pos(size_t row) {
+  const size_t tile = row >> 8;
+  const unsigned r = (unsigned)(row & 255);
+  return tile * 256 + (size_t)((((r >> 6) & 1) * 32 + (r & 31)) * 4 + ((r >> 7) * 2 + ((r >> 5) & 1)));
+}
+// e4m3 bytes of 8 values times inv_s
+__device__ __forceinline__ uint2 tn_e4m3_pack8(const float v[8], float inv_s) {
+  uint2 w = make_uint2(0u, 0u);
+  w.x = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv_s, v[1] * inv_s, w.x, false);
+  w.x = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv_s, v[3] * inv_s, w.x, true);
+  w.y = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv_s, v[5] * inv_s, w.y, false);
+  w.y = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv_s, v[7] * inv_s, w.y, true);
+  return w;
+}
+// the E8M0 byte of a power-of-two scale (its biased float exponent)
+__device__ __forceinline__ uint8_t tn_e8m0_of_pow2(float sc) { return (uint8_t)((__float_as_uint(sc) >> 23) & 0xffu); }
+struct Fp8Rows { uint8_t* q; uint8_t* rowexp; };      // [M][C] e4m3 bytes, [ceil(M / 256) * 256] exponent bytes (tn_rowexp_pos); or nulls
 
 #define TN_CHECK_HIP(expr)                          \
   do {                                              \

@@ -74,22 +74,30 @@ __device__ __forceinline__ uint32_t f2fp8x4(float a, float b, float c, float d) 
   w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
   return w;
 }
-struct Fp8CastDesc { const float* src; uint8_t* dst; float* scale; int R, C; };
+// src16 != null: the rows are read from a bf16 matrix (the transposed compute-precision copy W^T [ci][co] of a pointwise
+// weight: its e4m3 rows with one scale per INPUT channel are the B operand of the fp8 data gradient dS * W)
+struct Fp8CastDesc { const float* src; uint8_t* dst; float* scale; int R, C; const bf16_t* src16; };
 __global__ __launch_bounds__(64) void cast_fp8_rows_kernel(const Fp8CastDesc* descs) {
   const Fp8CastDesc d = descs[blockIdx.y];
   const int lane = threadIdx.x;
+  auto ld4 = [&](int r, int c) -> float4 {
+    if (d.src16) {
+      const uint2 w = *reinterpret_cast<const uint2*>(d.src16 + (size_t)r * d.C + c);
+      return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u));
+    }
+    return *reinterpret_cast<const float4*>(d.src + (size_t)r * d.C + c);
+  };
   for (int r = blockIdx.x; r < d.R; r += gridDim.x) {
-    const float* w = d.src + (size_t)r * d.C;
     float m = 0.f;
     for (int c = lane * 4; c < d.C; c += 256) {
-      const float4 v = *reinterpret_cast<const float4*>(w + c);
+      const float4 v = ld4(r, c);
       m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
     m = wave_max(m);
     const float sc = m > 0.f ? m * (1.f / 448.f) : 1.f, inv = 1.f / sc;
     if (lane == 0) d.scale[r] = sc;
     for (int c = lane * 4; c < d.C; c += 256) {
-      const float4 v = *reinterpret_cast<const float4*>(w + c);
+      const float4 v = ld4(r, c);
       *reinterpret_cast<uint32_t*>(d.dst + (size_t)r * d.C + c) = f2fp8x4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
     }
   }

@@ -68,6 +68,8 @@ struct BlockWs {
   size_t m, h, g;          // SE: mean [B][C], hidden [B][Hr], gate [B][C]  (float)
   std::vector<WcRef> wpw;
   std::vector<size_t> w8, w8s;   // TN_PREC_FP8: e4m3 pointwise weights [H][H] and their per-row scales [H] (float)
+  std::vector<size_t> w8t, w8ts; // fp8 data gradient: e4m3 rows of W^T [ci][co] and their per-input-channel scales [H]
+  size_t w8t_skip = 0, w8ts_skip = 0;   // ... of the skip connection's 1x1 conv
   WcRef wskip;
   // backward (float): SE pre-activation grads
   size_t dpre2, dpre1, dgate;
@@ -99,6 +101,9 @@ struct tn_plan {
                                         // gradient dS of the pipelined path is rounded through e4m3 (one power-of-two scale per
                                         // row) before the data- and weight-gradient GEMMs read it: the accuracy an fp8 backward
                                         // would have, measured before its kernels exist
+  bool fp8_bwd = false;                 // fp8 plans at hidden 512 / 1024: sub-block data gradients on the f8f6f4 MFMA (TN_FP8_BWD=0: bf16)
+  size_t ds8s = 0, dsexps = 0;          // ... and of the skip connection's layer (its dS is made while the last sub-block's is still pending)
+  size_t ds8 = 0, dsexp = 0;            // ... their A operand: e4m3 dS [M][H] bytes + row exponent bytes (one layer at a time)
   size_t q8 = 0, fp8_table = 0;         // e4m3 copy of the current depthwise output [M][H] bytes; weight-cast descriptors
   int n_fp8 = 0;
   bool split_dw = false;                // wide models: depthwise producer as its own streaming kernel (forward)

@@ -57,6 +57,12 @@ __device__ __forceinline__ pg_i32x4_t pg_make_srd(const void* base, unsigned byt
 
 // what an absent bias / column scale reads in the deep-ring variants (N <= 3072; one copy per translation unit)
 static __device__ const float pg_const_zeros[3072] = {};
+// ... and what absent row exponents read: E8M0 127 = scale 1 in every byte
+#define PG_X4 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu
+#define PG_X16 PG_X4, PG_X4, PG_X4, PG_X4
+static __device__ const uint32_t pg_const_unit_exp[64] = {PG_X16, PG_X16, PG_X16, PG_X16};
+#undef PG_X16
+#undef PG_X4
 
 struct PGemmNtArgs {
   const bf16_t* A;   // [M][lda], K contiguous, used as stored
@@ -66,6 +72,9 @@ struct PGemmNtArgs {
   // every consumer of this path masks or zero-weights padding rows
   const int* rowtiles;
   int n_rowtiles;
+  // F8 only: one E8M0 exponent byte per row of A (a power-of-two scale per row, stored in the lanes' order: tn_rowexp_pos in
+  // tn_common.h) — the A block scale of the scaled MFMA; null = unit scales
+  const uint8_t* rowexp;
 };
 struct PGemmEpiArgs {
   bf16_t* Y;               // [M][ldy]
@@ -202,6 +211,25 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(cvn) : "v"(pc) : "memory");
   };
 
+  // F8 with row scales: this lane's dword of exponent bytes (its four 32-row fragments of a 256-row tile), requested a whole
+  // tile ahead by a hidden load (in-order vmcnt queue: retired long before the tile begins) and moved into xs_cur by a volatile
+  // v_mov at the tile change
+  // (branch-free like fetch_bias: absent exponents read a constant array of unit scales)
+  uint32_t xs_cur, xs_next;
+  constexpr bool has_xs = F8 && HT == 2;
+  auto fetch_xs = [&](int tile) {
+    if constexpr (has_xs) {
+      tile = tile < total_tiles ? tile : total_tiles - 1;
+      const int mi = tile / tiles_n;
+      const int mt = rowtiles ? tn_sload_i32(rowtiles, mi) : mi;
+      const uint8_t* px = pa.rowexp ? pa.rowexp + (size_t)mt * 256 + (size_t)(wm * 32 + (lane & 31)) * 4
+                                    : reinterpret_cast<const uint8_t*>(pg_const_unit_exp) + (size_t)(wm * 32 + (lane & 31)) * 4;
+      asm volatile("global_load_dword %0, %1, off" : "=v"(xs_next) : "v"(px) : "memory");
+    }
+  };
+  auto take_xs = [&]() {
+    if constexpr (has_xs) asm volatile("v_mov_b32 %0, %1" : "=v"(xs_cur) : "v"(xs_next));
+  };
   int itile = v, ikt = 0;       // next K step to request
   int ctile = v, ckt = 0;       // K step being multiplied
   int cstage = 0, istage = 0;
@@ -213,6 +241,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
     istage = istage + 1 == NSTAGE ? 0 : istage + 1;
   };
   fetch_bias(ctile);
+  fetch_xs(ctile);
   dma_setup(itile < total_tiles ? itile : total_tiles - 1);
 #pragma unroll 1
   for (int d = 0; d < AHEAD; ++d) {                 // steps 0 .. AHEAD - 1 in flight
@@ -222,6 +251,8 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
     advance_issue();
   }
   pg_wait<(AHEAD - 1) * GRP>();     // step 0 has landed (the later ones stay in flight)
+  take_xs();
+  fetch_xs(ctile + G);
   pg_barrier();
   while (ctile < total_tiles) {
     const int kt_req = itile < total_tiles ? ikt : 0;
@@ -257,8 +288,17 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
           if (DBG & 1) {
             asm volatile("" ::"v"(a8), "v"(b0), "v"(b1));
           } else {
-            acc[i >> 1][i & 1][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b0, acc[i >> 1][i & 1][0], 0, 0, 0, SC1, 0, SC1);
-            acc[i >> 1][i & 1][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b1, acc[i >> 1][i & 1][1], 0, 0, 0, SC1, 0, SC1);
+            // A block scale: byte i of xs_cur = the exponent of this lane's row in fragment i (unit scales: 0x7f in every byte)
+            const int xa = has_xs ? (int)xs_cur : SC1;
+            auto mm = [&](auto sel) {
+              constexpr int S = decltype(sel)::value;
+              acc[i >> 1][i & 1][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b0, acc[i >> 1][i & 1][0], 0, 0, S, xa, 0, SC1);
+              acc[i >> 1][i & 1][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b1, acc[i >> 1][i & 1][1], 0, 0, S, xa, 0, SC1);
+            };
+            if (i == 0) mm(std::integral_constant<int, 0>{});
+            else if (i == 1) mm(std::integral_constant<int, 1>{});
+            else if (i == 2) mm(std::integral_constant<int, 2>{});
+            else mm(std::integral_constant<int, 3>{});
           }
         }
       } else
@@ -327,6 +367,8 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
       ctile += G;
       fresh = (cols_ok && !(DBG & 8)) ? 0 : AHEAD;
       fetch_bias(ctile);
+      take_xs();                  // the exponents of the tile that begins now (requested a tile ago)
+      fetch_xs(ctile + G);
     }
     // this wave's part of the next stage has landed.  The vmcnt queue retires in order: the two groups requested after it
     // may stay in flight, and so may this tile's 64 output stores (+ statistics atomics) while they are YOUNGER than the

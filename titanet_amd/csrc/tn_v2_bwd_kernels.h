@@ -776,12 +776,14 @@ inline int launch_combine_bwd1_v3(const CombineBwd1V3Args& aa, int B, int C, hip
 // One workgroup = (utterance, 64-frame chunk); a thread keeps the constants of its 8 channels — k0 k1 k2, sc3 sh3 and the
 // utterance's ga / ub — in registers and walks the chunk's rows (a flat grid-stride loop re-read ga / ub, 64 bytes of
 // float32 per 16 bytes of gradient, for every vector: 79 us against 47 for the plain pass at hidden 512).
-template <bool DROP3, int CH>
+// OUT8 (fp8 plans): dS also as e4m3 bytes with one power-of-two scale per row + the exponent bytes (Fp8Rows, tn_common.h)
+template <bool DROP3, int CH, bool OUT8>
 __global__ __launch_bounds__(256) void bn_bwd_apply_z3_kernel(const bf16_t* __restrict__ dZ, const bf16_t* __restrict__ Y, BnBwd bn, BnAct act3,
                                                               const float* __restrict__ gu, bf16_t* __restrict__ dS, int T, int chunk,
-                                                              const int* __restrict__ len) {
+                                                              const int* __restrict__ len, Fp8Rows f8) {
   constexpr int VC = CH / 8, RG = 256 / VC;       // channel vectors per row, row groups per workgroup
   __shared__ __attribute__((aligned(16))) float pg_k[5 * CH];      // k0, k1, k2, sc3, sh3
+  __shared__ float wmax[4];
   for (int c = threadIdx.x; c < CH; c += 256) {
     bn_bwd_coefs(bn, CH, c, pg_k[c], pg_k[CH + c], pg_k[2 * CH + c]);
     bn_scale_shift(act3, CH, c, pg_k[3 * CH + c], pg_k[4 * CH + c]);
@@ -800,14 +802,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_z3_kernel(const bf16_t* __re
   const int t1 = len ? min(t_end, len[b]) : t_end;       // padding frames of a variable-length batch: dS = 0 (written below)
   if (len) {
     const uint4 z4 = make_uint4(0, 0, 0, 0);
-    for (int t = max(t0, t1) + rg; t < t_end; t += RG) *reinterpret_cast<uint4*>(dS + ((size_t)b * T + t) * CH + c0) = z4;
+    for (int t = max(t0, t1) + rg; t < t_end; t += RG) {
+      const size_t row = (size_t)b * T + t;
+      *reinterpret_cast<uint4*>(dS + row * CH + c0) = z4;
+      if (OUT8) {
+        *reinterpret_cast<uint2*>(f8.q + row * CH + c0) = make_uint2(0u, 0u);
+        if (c0 == 0) f8.rowexp[tn_rowexp_pos(row)] = (uint8_t)127;
+      }
+    }
   }
   constexpr int U = 4;
-  for (int tb = t0 + rg; tb < t1; tb += RG * U) {
+  // (tb is uniform over the workgroup: the row maximum of the fp8 output crosses two waves at 1024 channels)
+  for (int tb = t0; tb < t1; tb += RG * U) {
     uint4 rz[U], ry[U];
 #pragma unroll
     for (int q = 0; q < U; ++q) {
-      const int t = tb + RG * q;
+      const int t = tb + rg + RG * q;
       if (t < t1) {
         const size_t o = ((size_t)b * T + t) * CH + c0;
         rz[q] = *reinterpret_cast<const uint4*>(dZ + o);
@@ -816,10 +826,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_z3_kernel(const bf16_t* __re
     }
 #pragma unroll
     for (int q = 0; q < U; ++q) {
-      const int t = tb + RG * q;
-      if (t < t1) {
-        const uint32_t row = (uint32_t)b * T + t;
-        float z[8], y[8], m[8];
+      const int t = tb + rg + RG * q;
+      const bool live = t < t1;
+      const uint32_t row = (uint32_t)b * T + t;
+      float z[8];
+      if (live) {
+        float y[8], m[8];
         unpack8(rz[q], z);
         unpack8(ry[q], y);
 #pragma unroll
@@ -831,24 +843,48 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_z3_kernel(const bf16_t* __re
           z[u] = fmaf(k0[u], v, fmaf(k1[u], y[u], k2[u]));
         }
         store8(dS + (size_t)row * CH + c0, z);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) z[u] = 0.f;
+      }
+      if (OUT8) {
+        float mx = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mx = fmaxf(mx, fabsf(z[u]));
+        mx = wave_max(mx);
+        if (VC == 128) {                    // a row is two waves
+          const int w = threadIdx.x >> 6;
+          wmax[w] = mx;
+          __syncthreads();
+          mx = fmaxf(mx, wmax[w ^ 1]);
+          __syncthreads();
+        }
+        if (live) {
+          const float sc = tn_e4m3_row_scale(mx);
+          *reinterpret_cast<uint2*>(f8.q + (size_t)row * CH + c0) = tn_e4m3_pack8(z, 1.f / sc);
+          if (c0 == 0) f8.rowexp[tn_rowexp_pos(row)] = tn_e8m0_of_pow2(sc);
+        }
       }
     }
   }
 }
 template <int CH>
 inline int launch_bn_bwd_apply_z3_c(const bf16_t* dZ, const bf16_t* Y, const BnBwd& bn, const BnAct& act3, const float* gu, bf16_t* dS, int M,
-                                    int T, hipStream_t st) {
+                                    int T, hipStream_t st, Fp8Rows f8) {
   const int chunk = 64;
   const dim3 grid((T + chunk - 1) / chunk, M / T);
-  if (act3.drop_thr) hipLaunchKernelGGL((bn_bwd_apply_z3_kernel<true, CH>), grid, dim3(256), 0, st, dZ, Y, bn, act3, gu, dS, T, chunk, bn.rm.len);
-  else hipLaunchKernelGGL((bn_bwd_apply_z3_kernel<false, CH>), grid, dim3(256), 0, st, dZ, Y, bn, act3, gu, dS, T, chunk, bn.rm.len);
+  const bool d3 = act3.drop_thr != 0;
+#define TN_Z3(D, O) hipLaunchKernelGGL((bn_bwd_apply_z3_kernel<D, CH, O>), grid, dim3(256), 0, st, dZ, Y, bn, act3, gu, dS, T, chunk, bn.rm.len, f8)
+  if (f8.q) { if (d3) TN_Z3(true, true); else TN_Z3(false, true); }
+  else { if (d3) TN_Z3(true, false); else TN_Z3(false, false); }
+#undef TN_Z3
   return (int)hipGetLastError();
 }
 inline int launch_bn_bwd_apply_z3(const bf16_t* dZ, const bf16_t* Y, const BnBwd& bn, const BnAct& act3, const float* gu, bf16_t* dS, int M,
-                                  int C, int T, hipStream_t st) {
+                                  int C, int T, hipStream_t st, Fp8Rows f8 = Fp8Rows{nullptr, nullptr}) {
   if (act3.mode == 0 || !act3.relu || M % T) return TN_E_UNSUPPORTED;
-  if (C == 512) return launch_bn_bwd_apply_z3_c<512>(dZ, Y, bn, act3, gu, dS, M, T, st);
-  if (C == 1024) return launch_bn_bwd_apply_z3_c<1024>(dZ, Y, bn, act3, gu, dS, M, T, st);
+  if (C == 512) return launch_bn_bwd_apply_z3_c<512>(dZ, Y, bn, act3, gu, dS, M, T, st, f8);
+  if (C == 1024) return launch_bn_bwd_apply_z3_c<1024>(dZ, Y, bn, act3, gu, dS, M, T, st, f8);
   return TN_E_UNSUPPORTED;
 }
 

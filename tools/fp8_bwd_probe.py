@@ -1,7 +1,8 @@
-"""What rounding every BatchNorm-backward'd gradient dS through e4m3 (one power-of-two scale per row: TN_FP8_BWD_EMU=1) does
-to the gradient of TitaNet-L/5 and -M/10 under the fp8 plan: two runs of the same forward (same weights, batch, dropout
-stream), backward in bf16 vs backward with e4m3 dS, compared tensor by tensor; a third run (bf16 again) gives the run-to-run
-noise floor (atomics).     python tools/fp8_bwd_probe.py"""
+"""The fp8 data gradient of the fp8 plan against its bf16 backward (TN_FP8_BWD=0), TitaNet-L/5 and -M/10: runs of the same
+forward (same weights, batch, dropout stream) with (i) the bf16 backward, (ii) dS rounded through e4m3 with one power-of-two
+scale per row but multiplied in bf16 (TN_FP8_BWD_EMU=1: the experiment that preceded the kernels), (iii) the built path — e4m3
+dS rows x e4m3 W^T rows on the f8f6f4 MFMA (default), (iv) bf16 again = the run-to-run noise floor (atomics); compared tensor
+by tensor.     python tools/fp8_bwd_probe.py"""
 import os, subprocess, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,7 +20,7 @@ if len(sys.argv) > 2:
     sys.exit(0)
 for size, nb in (("l", 5), ("m", 10)):
     runs = {}
-    for tag, env in (("bf16", {}), ("e4m3", {"TN_FP8_BWD_EMU": "1"}), ("bf16_again", {})):
+    for tag, env in (("bf16", {"TN_FP8_BWD": "0"}), ("e4m3_emulated", {"TN_FP8_BWD_EMU": "1"}), ("fp8_built", {}), ("bf16_again", {"TN_FP8_BWD": "0"})):
         subprocess.run([sys.executable, __file__, f"/tmp/fp8p_{tag}.npz", size, str(nb)], check=True, env=dict(os.environ, **env))
         runs[tag] = dict(np.load(f"/tmp/fp8p_{tag}.npz"))
     def dist(a, b):
@@ -27,7 +28,7 @@ for size, nb in (("l", 5), ("m", 10)):
         cos = float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb)))
         per = {k: float(np.linalg.norm(a[k] - b[k]) / (np.linalg.norm(b[k]) + 1e-30)) for k in b if b[k].size >= 16384}
         return cos, per
-    for tag in ("e4m3", "bf16_again"):
+    for tag in ("e4m3_emulated", "fp8_built", "bf16_again"):
         cos, per = dist(runs[tag], runs["bf16"])
         blk = [max(v for k, v in per.items() if f"mega_blocks.{i}." in k) for i in range(nb)]
         print(f"TitaNet-{size.upper()}/{nb} fp8 plan, backward {tag} vs bf16: whole-gradient cosine {cos:.5f}; worst large tensor per mega block (first .. last)",
