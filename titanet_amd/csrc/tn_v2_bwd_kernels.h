@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_z3_kernel(const bf16_t* __re
                                                               const int* __restrict__ len, Fp8Rows f8) {
   constexpr int VC = CH / 8, RG = 256 / VC;       // channel vectors per row, row groups per workgroup
   __shared__ __attribute__((aligned(16))) float pg_k[5 * CH];      // k0, k1, k2, sc3, sh3
-  __shared__ float wmax[4];
+  __shared__ float wmax[4][4];
   for (int c = threadIdx.x; c < CH; c += 256) {
     bn_bwd_coefs(bn, CH, c, pg_k[c], pg_k[CH + c], pg_k[2 * CH + c]);
     bn_scale_shift(act3, CH, c, pg_k[3 * CH + c], pg_k[4 * CH + c]);
@@ -824,6 +824,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_z3_kernel(const bf16_t* __re
         ry[q] = *reinterpret_cast<const uint4*>(Y + o);
       }
     }
+    float zq[OUT8 ? U : 1][8], mxq[U];
 #pragma unroll
     for (int q = 0; q < U; ++q) {
       const int t = tb + rg + RG * q;
@@ -850,18 +851,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_z3_kernel(const bf16_t* __re
       if (OUT8) {
         float mx = 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) mx = fmaxf(mx, fabsf(z[u]));
-        mx = wave_max(mx);
-        if (VC == 128) {                    // a row is two waves
-          const int w = threadIdx.x >> 6;
-          wmax[w] = mx;
-          __syncthreads();
-          mx = fmaxf(mx, wmax[w ^ 1]);
-          __syncthreads();
-        }
-        if (live) {
-          const float sc = tn_e4m3_row_scale(mx);
-          *reinterpret_cast<uint2*>(f8.q + (size_t)row * CH + c0) = tn_e4m3_pack8(z, 1.f / sc);
+        for (int u = 0; u < 8; ++u) { mx = fmaxf(mx, fabsf(z[u])); zq[q][u] = z[u]; }
+        mxq[q] = wave_max(mx);
+      }
+    }
+    if (OUT8) {
+      // row maxima of the U rows: at 1024 channels a row is two waves — ONE exchange for all of them
+      if (VC == 128) {
+        const int w = threadIdx.x >> 6;
+#pragma unroll
+        for (int q = 0; q < U; ++q) wmax[w][q] = mxq[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < U; ++q) mxq[q] = fmaxf(mxq[q], wmax[w ^ 1][q]);
+        __syncthreads();
+      }
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        const int t = tb + rg + RG * q;
+        if (t < t1) {
+          const size_t row = (size_t)b * T + t;
+          const float sc = tn_e4m3_row_scale(mxq[q]);
+          *reinterpret_cast<uint2*>(f8.q + row * CH + c0) = tn_e4m3_pack8(zq[q], 1.f / sc);
           if (c0 == 0) f8.rowexp[tn_rowexp_pos(row)] = tn_e8m0_of_pow2(sc);
         }
       }

@@ -6,7 +6,7 @@ from titanet_amd import LOSSES, TitaNet
 from titanet_amd.trainer import Trainer
 size, nb = sys.argv[1], int(sys.argv[2])
 loss = LOSSES["ce"](192, 251, device="cuda")
-m = TitaNet.get_titanet(n_mega_blocks=nb, model_size=size, loss_function=loss, dropout=0.1, device="cuda", precision="bf16").train()
+m = TitaNet.get_titanet(n_mega_blocks=nb, model_size=size, loss_function=loss, dropout=0.1, device="cuda", precision=(sys.argv[3] if len(sys.argv) > 3 else "bf16")).train()
 tr = Trainer(m)
 x = torch.randn(256, 80, 300, device="cuda") * 0.11 - 0.1
 y = torch.randint(0, 251, (256,), device="cuda")

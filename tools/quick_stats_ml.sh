@@ -4,7 +4,7 @@ set -u
 TAG=${1:-ml}; SIZE=${2:-l}; NB=${3:-5}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -o ${TAG} -- python tools/profile_ml.py $SIZE $NB > gpurun_out/${TAG}.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -o ${TAG} -- python tools/profile_ml.py $SIZE $NB ${4:-bf16} > gpurun_out/${TAG}.log 2>&1
 find gpurun_out/${TAG}_trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats.csv \;
 rm -rf gpurun_out/${TAG}_trace
 python - <<PY
