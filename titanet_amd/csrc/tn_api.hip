@@ -343,6 +343,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     p->dw_table = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * 32);
   }
   if (precision == TN_PREC_BF16) p->se_gu = b.take((size_t)batch * 2 * H * sizeof(float));      // fused mega-block tail backward
+  if (p->wide_wgrad) p->a0 = b.take(M * H * e);      // the activated prolog output as a stored operand (first block's skip conv)
   if (p->wide_wgrad) p->tn_table = b.take((size_t)c.n_mega_blocks * (c.n_sub_blocks + 1) * 64);   // >= sizeof(PGemmTnDesc) each
   p->cast_table = b.take(sizeof(CastDesc) * (8 + (size_t)c.n_mega_blocks * (c.n_sub_blocks + 1)));
   p->swz_table = b.take(sizeof(SwzDesc) * (2 * (size_t)c.n_mega_blocks * (c.n_sub_blocks + 1) + 8));
@@ -723,12 +724,21 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   }
   const void* xin = ws + p->Y0;
   BnAct actx = make_act(p, m->prolog_bn, M, training, 1, 0.f, seed, 0);
+  const bool keep_a0 = p->a0 != 0 && sizeof(AT) == 2 && c.n_mega_blocks > 0;
+  if (keep_a0)
+    hipLaunchKernelGGL(act_store_kernel, dim3(2048), dim3(256), (size_t)2 * H * sizeof(float), st, (const bf16_t*)xin, actx,
+                       (bf16_t*)(ws + p->a0), M, H);
   for (int i = 0; i < c.n_mega_blocks; ++i) {
     const MegaBlockRef& mb = m->blocks[i];
     BlockWs& bw = p->blk[i];
     // skip connection: 1x1 conv (reference src/models.py:452-455)
     {
       int rc = -1000;
+      if (keep_a0 && i == 0) {
+        GemmShape g{M, H, H, wsel<AT>(p, mb.wskip, bw.wskip)};
+        EpiStoreArgs ea{ws + bw.S, H, params + mb.bskip, statp(mb.bnskip), rm};
+        rc = gemm_plain_pipe<AT>(p, g, ws + p->a0, H, identity_rows(p), ea, st);
+      }
       if (use_v2) {
         SubFwdV2Args va{(const bf16_t*)xin, actx, nullptr, nullptr, (const bf16_t*)(ws + bw.wskip.w), params + mb.bskip,
                         (bf16_t*)(ws + bw.S), statp(mb.bnskip), M, T, 0,

@@ -153,7 +153,8 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   const bool tn_batched = pipe && p->tn_table != 0;
   // table layout (plan_upload_bwd_tables): blocks from the last down, per block the skip conv (blocks > 0), then the
   // sub-blocks from the last down
-  auto tn_entries = [&](int blk) { return nsub + (blk > 0 ? 1 : 0); };
+  // (the first block's skip conv joins when its input — the activated prolog output — is kept as a stored operand, p->a0)
+  auto tn_entries = [&](int blk) { return nsub + ((blk > 0 || p->a0) ? 1 : 0); };
   auto tn_offset = [&](int blk) { int o = 0; for (int k = c.n_mega_blocks - 1; k > blk; --k) o += tn_entries(k); return o; };
   const bool v2_bwd = sizeof(AT) == 2 && use_v2;
   // round 4: the mega-block tail backward in ONE pass (combine_bwd1_v3 finishes the SE backward per utterance; the last
@@ -501,7 +502,10 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     if (pipe) {
       // (fp8 plans: its own e4m3 dS buffer — the last sub-block's, written by the one-pass tail above, is still pending)
       const bool f8s = p->fp8_bwd && bw.w8t_skip != 0;
-      int rc = pipe_layer(bw.dZk, bw.S, mb.bnskip, H, bw.wskip, H, p->dXs, xin, is_plain(actx), actx, mb.wskip, false, tn_batched && i > 0,
+      const bool a0 = i == 0 && p->a0 != 0;        // the skip conv read the stored activated prolog output (forward_impl)
+      const void* xs = a0 ? (const void*)(ws + p->a0) : xin;
+      const BnAct axs = a0 ? identity_rows() : actx;
+      int rc = pipe_layer(bw.dZk, bw.S, mb.bnskip, H, bw.wskip, H, p->dXs, xs, is_plain(axs), axs, mb.wskip, false, tn_batched && (i > 0 || a0),
                           f8s ? Fp8Rows{(uint8_t*)(ws + p->ds8s), (uint8_t*)(ws + p->dsexps)} : Fp8Rows{nullptr, nullptr},
                           f8s ? bw.w8t_skip : 0, f8s ? bw.w8ts_skip : 0);
       if (rc) return rc;
@@ -704,8 +708,9 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
     std::vector<PGemmTnDesc> td;
     for (int i = c.n_mega_blocks - 1; i >= 0; --i) {
       const BlockWs& bw = p->blk[i];
-      if (i > 0) td.push_back(PGemmTnDesc{(const bf16_t*)(p->ws + bw.dZk), (const bf16_t*)(p->ws + p->blk[i - 1].OUT),
-                                          p->grads + m->blocks[i].wskip, H, H, H, H / 256});
+      if (i > 0 || p->a0)
+        td.push_back(PGemmTnDesc{(const bf16_t*)(p->ws + bw.dZk), (const bf16_t*)(p->ws + (i > 0 ? p->blk[i - 1].OUT : p->a0)),
+                                 p->grads + m->blocks[i].wskip, H, H, H, H / 256});
       for (int j = nsub - 1; j >= 0; --j)
         td.push_back(PGemmTnDesc{(const bf16_t*)(p->ws + bw.dY[j]), (const bf16_t*)(p->ws + bw.Q[j]), p->grads + m->blocks[i].sub[j].wpw,
                                  H, H, H, H / 256});

@@ -485,6 +485,27 @@ __global__ __launch_bounds__(512) void se_squeeze_fc_kernel(const AT* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// A = act(X) stored as a plain bf16 operand (wide models, the prolog's output): the first mega block's skip conv and its weight
+// gradient then run on the pipelined GEMMs like every other block's (with the activation applied on load they were the
+// generic GEMM and the generic weight gradient: 368 + 498 us per TitaNet-L step against 188 + ~125)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_store_kernel(const bf16_t* __restrict__ X, BnAct act, bf16_t* __restrict__ OUT, int M, int C) {
+  extern __shared__ __attribute__((aligned(16))) float as_k[];      // sc, sh : [2][C]
+  act = tn_resolve_key(act);
+  for (int c = threadIdx.x; c < C; c += 256) bn_scale_shift(act, C, c, as_k[c], as_k[C + c]);
+  __syncthreads();
+  const int VC = C / 8;
+  const size_t nvec = (size_t)M * VC;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    const int c0 = (int)(i % VC) * 8;
+    float v[8];
+    load8(X + i * 8, v);
+    act8(v, as_k + c0, as_k + C + c0, act, (uint32_t)(i / VC), C, c0);
+    store8(OUT + i * 8, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Mega-block tail: OUT = dropout(relu(BN(S) + g * act3(Y3)))   (reference src/models.py:467-472)
 // ------------------------------------------------------------------------------------------
 template <typename AT, bool MK = false>

@@ -101,6 +101,7 @@ struct tn_plan {
                                         // gradient dS of the pipelined path is rounded through e4m3 (one power-of-two scale per
                                         // row) before the data- and weight-gradient GEMMs read it: the accuracy an fp8 backward
                                         // would have, measured before its kernels exist
+  size_t a0 = 0;                        // wide bf16 plans: the activated prolog output, stored (act_store_kernel); 0 = not kept
   bool fp8_bwd = false;                 // fp8 plans at hidden 512 / 1024: sub-block data gradients on the f8f6f4 MFMA (TN_FP8_BWD=0: bf16)
   size_t ds8s = 0, dsexps = 0;          // ... and of the skip connection's layer (its dS is made while the last sub-block's is still pending)
   size_t ds8 = 0, dsexp = 0;            // ... their A operand: e4m3 dS [M][H] bytes + row exponent bytes (one layer at a time)
