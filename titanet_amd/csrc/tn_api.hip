@@ -338,8 +338,19 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     p->wg2_asp_units = (p->wg2_epi_slabs > 0 && p->use_v2 && H == 256 && A == 128 && !c.simple_pool) ? 2 * (int)(D / 256) : 0;
     p->wg2_layers += p->wg2_asp_units;
     p->wg2_grid = 256;
-    p->wg2_desc = b.take((size_t)2 * p->wg2_layers * 256);   // two tables, >= sizeof(WgradV2Desc) per unit (checked at upload)
+    p->wg2_desc = b.take((size_t)3 * p->wg2_layers * 256);   // three tables, >= sizeof(WgradV2Desc) per unit (checked at upload)
     p->wg2_out = b.take((size_t)p->wg2_layers * 32);
+    p->wg2_out3 = b.take((size_t)p->wg2_layers * 32);
+    // the sub-block pointwise weight gradients as one pipelined TN contraction over stored operands (dS kept by dgrad_dw_v6,
+    // the kept depthwise output): needs the one-pass tail (the last sub-block's dS) and one 256 x 256 slab per layer
+    p->v2_tn = p->use_v2 && H == 256 && c.n_sub_blocks >= 2 && p->wg2_upl == 1;
+    if (p->v2_tn) {
+      for (auto& bw : p->blk) {
+        bw.dS.assign(c.n_sub_blocks, 0);
+        for (int j = 0; j + 1 < c.n_sub_blocks; ++j) bw.dS[j] = b.take(M * H * e);
+      }
+      p->tn_table = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * 64);
+    }
     p->dw_table = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * 32);
   }
   if (precision == TN_PREC_BF16) p->se_gu = b.take((size_t)batch * 2 * H * sizeof(float));      // fused mega-block tail backward
@@ -395,9 +406,12 @@ void plan_layout_tail(tn_plan* p) {
     // every group's launch cuts its (layer, 32-row chunk) units into one contiguous range per workgroup: the number of
     // partial slabs a layer can receive is bounded by the smallest group
     const int chunks = (p->M + 31) / 32;
-    const int per_blk = (c.n_sub_blocks + 1) * p->wg2_upl;
     int maxparts = 1;
+    // (v2_tn plans launch only the skip conv of each block here — fewer units, more partial slabs per unit — unless the one-pass
+    //  tail is off for the step: both layouts must fit)
+    for (int layout = 0; layout < (p->v2_tn ? 2 : 1); ++layout)
     for (const auto& bk : p->buckets) {
+      const int per_blk = layout == 1 ? 1 : (c.n_sub_blocks + 1) * p->wg2_upl;
       const int layers = (bk.blk_hi >= bk.blk_lo ? (bk.blk_hi - bk.blk_lo + 1) * per_blk : 0) + (bk.tail ? p->wg2_epi_slabs + p->wg2_asp_units : 0);
       if (layers == 0) continue;
       // (variable-length batches launch the group of block 0 without its first layer: both partitions must fit)

@@ -150,7 +150,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   auto is_plain = [](const BnAct& a) { return a.mode == 0 && !a.relu && !a.drop_thr; };
   // wide models: the pointwise weight gradients of the mega blocks in ONE pipelined launch per gradient bucket
   // (pgemm_tn_batched_kernel: ~2 atomic flushes per workgroup and step instead of one per layer)
-  const bool tn_batched = pipe && p->tn_table != 0;
+  const bool tn_batched = pipe && p->tn_table != 0 && !p->v2_tn;
   // table layout (plan_upload_bwd_tables): blocks from the last down, per block the skip conv (blocks > 0), then the
   // sub-blocks from the last down
   // (the first block's skip conv joins when its input — the activated prolog output — is kept as a stored operand, p->a0)
@@ -167,6 +167,10 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   // ... and of the wide models on the pipelined path: the rebuild sits in the streaming pass that makes the stored dS operand
   const bool fuse_tail_wide = pipe && (H == 512 || H == 1024) && Hr * 16 == H && tail_ok &&
                               !p->fp8_bwd_emu;      // (the e4m3 experiment rounds dS in the plain pass)
+  // headline shape: the sub-block pointwise weight gradients of a bucket as one pipelined TN contraction over the dS that
+  // dgrad_dw_v6 stores and the kept depthwise outputs (pgemm_tn_batched: 5.6 TB/s against 3.9 for the rebuild-on-load units of
+  // wgrad_batched_v2, which keeps the skip convs, the epilog and the pooling units: third descriptor table)
+  const bool v2_tn = fuse_tail && p->v2_tn && p->tn_table != 0;
   const int nb = c.n_mega_blocks;
   const int per_blk = nsub + 1;
   int rc_fin = 0;
@@ -203,8 +207,15 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
                                              listed ? (const int*)(ws + p->rowtiles) : nullptr, listed ? p->n_rowtiles : 0, st);
       if (rc) { rc_fin = rc; return; }
     }
+    if (v2_tn && has_blocks) {
+      // table: blocks from the last down, per block the sub-blocks from the last down
+      const int first = (nb - 1 - bk.blk_hi) * nsub, count = (bk.blk_hi - bk.blk_lo + 1) * nsub;
+      ProfScope ps(p, TN_PROF_BWD_WGRAD, st);
+      const int rc = launch_pgemm_tn_batched((const PGemmTnDesc*)(ws + p->tn_table) + first, count, M, 1, nullptr, 0, st);
+      if (rc) { rc_fin = rc; return; }
+    }
     if (batched_wgrad) {
-      const int upb = per_blk * p->wg2_upl;      // weight-gradient units per mega block
+      const int upb = v2_tn ? 1 : per_blk * p->wg2_upl;      // weight-gradient units per mega block (v2_tn: the skip conv only)
       int first = has_blocks ? bk.blk_lo * upb : nb * upb;
       int count = (has_blocks ? (bk.blk_hi - bk.blk_lo + 1) * upb : 0) + (bk.tail ? p->wg2_epi_slabs + p->wg2_asp_units : 0);
       // variable-length batches: the first unit (block 0's skip conv: its other operand is the ACTIVATED prolog output, not
@@ -223,10 +234,10 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         {
           ProfScope ps(p, TN_PROF_BWD_WGRAD, st);
           hipLaunchKernelGGL(kern, dim3(p->wg2_grid), dim3(V2_NT), smem, st,
-                             (const WgradV2Desc*)(ws + p->wg2_desc) + (fuse_tail ? p->wg2_layers : 0) + first, count, M, T,
+                             (const WgradV2Desc*)(ws + p->wg2_desc) + (v2_tn ? 2 * p->wg2_layers : fuse_tail ? p->wg2_layers : 0) + first, count, M, T,
                              chunks, upw, (int*)(ws + p->wg2_count) + first, seed, 1.f / (float)(p->masked ? std::max(p->n_valid, 1) : M));
         }
-        hipLaunchKernelGGL(wgrad_v2_reduce_kernel, dim3(32, count), dim3(256), 0, st, (const WgradV2Out*)(ws + p->wg2_out) + first,
+        hipLaunchKernelGGL(wgrad_v2_reduce_kernel, dim3(32, count), dim3(256), 0, st, (const WgradV2Out*)(ws + (v2_tn ? p->wg2_out3 : p->wg2_out)) + first,
                            (const int*)(ws + p->wg2_count) + first);
       }
     }
@@ -564,6 +575,8 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
           // of this layer reads it as a plain operand: second descriptor table)
           fa.dZ = (const bf16_t*)(ws + bw.dZk); fa.gu = (const float*)(ws + p->se_gu); fa.act3 = act3;
           fa.dS_out = (bf16_t*)(ws + bw.dY[j]);
+        } else if (v2_tn) {
+          fa.dS_out = (bf16_t*)(ws + bw.dS[j]);      // kept for the pipelined weight-gradient launch (finalize_bucket)
         }
         if (j > 0) {
           fa.ADD = nullptr; fa.OUT = (bf16_t*)(ws + bw.dY[j - 1]); fa.bsumsX = bsum(mb.sub[j - 1].bn);
@@ -706,6 +719,16 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
     const tn_config& c = m->cfg;
     const int nsub = c.n_sub_blocks, H = c.hidden;
     std::vector<PGemmTnDesc> td;
+    if (p->v2_tn) {
+      // headline-shape plans: the sub-block layers only, P = the dS that dgrad_dw_v6 stored (the last sub-block's sits where its
+      // incoming gradient would have been: one-pass tail), Q = the kept depthwise output
+      for (int i = c.n_mega_blocks - 1; i >= 0; --i) {
+        const BlockWs& bw = p->blk[i];
+        for (int j = nsub - 1; j >= 0; --j)
+          td.push_back(PGemmTnDesc{(const bf16_t*)(p->ws + (j == nsub - 1 ? bw.dY[j] : bw.dS[j])), (const bf16_t*)(p->ws + bw.Q[j]),
+                                   p->grads + m->blocks[i].sub[j].wpw, H, H, H, 1});
+      }
+    } else
     for (int i = c.n_mega_blocks - 1; i >= 0; --i) {
       const BlockWs& bw = p->blk[i];
       if (i > 0 || p->a0)
@@ -813,6 +836,18 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
                                   wd2.size() * sizeof(WgradV2Desc), hipMemcpyHostToDevice, st));
     }
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_out, wo.data(), wo.size() * sizeof(WgradV2Out), hipMemcpyHostToDevice, st));
+    if (p->v2_tn) {
+      // third table: what stays in wgrad_batched_v2 when the sub-block layers go to the pipelined TN launch — the skip convs
+      // (one unit per block, compact: unit i = block i), then the epilog / pooling units as in the full table
+      std::vector<WgradV2Desc> wd3;
+      std::vector<WgradV2Out> wo3;
+      for (int i = 0; i < c.n_mega_blocks; ++i) { wd3.push_back(wd[(size_t)i * (nsub + 1)]); wo3.push_back(wo[(size_t)i * (nsub + 1)]); }
+      for (size_t u = (size_t)c.n_mega_blocks * (nsub + 1); u < wd.size(); ++u) { wd3.push_back(wd[u]); wo3.push_back(wo[u]); }
+      TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_desc + (size_t)2 * p->wg2_layers * sizeof(WgradV2Desc), wd3.data(),
+                                  wd3.size() * sizeof(WgradV2Desc), hipMemcpyHostToDevice, st));
+      TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_out3, wo3.data(), wo3.size() * sizeof(WgradV2Out), hipMemcpyHostToDevice, st));
+      TN_CHECK_HIP(hipStreamSynchronize(st));      // (wd3 / wo3 die with this scope)
+    }
     std::vector<DwGradOut> dg;
     for (int i = 0; i < c.n_mega_blocks; ++i)
       for (int j = 0; j < nsub; ++j) {

@@ -67,6 +67,7 @@ struct BlockWs {
   size_t S, OUT;
   size_t m, h, g;          // SE: mean [B][C], hidden [B][Hr], gate [B][C]  (float)
   std::vector<WcRef> wpw;
+  std::vector<size_t> dS;        // headline-shape plans: the BatchNorm-backward'd gradient of sub-block j as stored by dgrad_dw_v6 (0: none)
   std::vector<size_t> w8, w8s;   // TN_PREC_FP8: e4m3 pointwise weights [H][H] and their per-row scales [H] (float)
   std::vector<size_t> w8t, w8ts; // fp8 data gradient: e4m3 rows of W^T [ci][co] and their per-input-channel scales [H]
   size_t w8t_skip = 0, w8ts_skip = 0;   // ... of the skip connection's 1x1 conv
@@ -101,6 +102,8 @@ struct tn_plan {
                                         // gradient dS of the pipelined path is rounded through e4m3 (one power-of-two scale per
                                         // row) before the data- and weight-gradient GEMMs read it: the accuracy an fp8 backward
                                         // would have, measured before its kernels exist
+  bool v2_tn = false;                   // headline-shape plans: sub-block pointwise weight gradients as ONE pipelined TN contraction
+  size_t wg2_out3 = 0;                  // ... and the compact unit tables of what stays in wgrad_batched_v2 (skip convs, epilog, ASP)
   size_t a0 = 0;                        // wide bf16 plans: the activated prolog output, stored (act_store_kernel); 0 = not kept
   bool fp8_bwd = false;                 // fp8 plans at hidden 512 / 1024: sub-block data gradients on the f8f6f4 MFMA (TN_FP8_BWD=0: bf16)
   size_t ds8s = 0, dsexps = 0;          // ... and of the skip connection's layer (its dS is made while the last sub-block's is still pending)

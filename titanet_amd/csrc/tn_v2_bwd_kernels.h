@@ -1498,7 +1498,8 @@ struct DgradDwArgs {
   const float* gu;                                     // [B][2][256]: ga, ub (combine_bwd1_v3), or null
   BnAct act3;                                          // activation of this sub-block's output (BatchNorm, ReLU, dropout)
   bf16_t* dS_out;                                      // the BatchNorm-backward'd gradient is also stored (rows x 256): the
-                                                       // weight-gradient launch then reads it as a plain operand
+                                                       // weight-gradient launch then reads it as a plain operand (any variant;
+                                                       // or null)
 };
 
 // MK (variable-length batch, a.bn.rm.len): dS = 0 on padding rows (their dD then adds nothing to the valid rows next to them),
@@ -1630,7 +1631,7 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
         }
       }
       store8(Pt + r * V2_AP + c0, z);
-      if (Z3 && a.dS_out && r >= 1 && r <= V6_OUT && gr < a.M) store8(a.dS_out + (size_t)gr * V2_C + c0, z);
+      if (a.dS_out && r >= 1 && r <= V6_OUT && gr >= 0 && gr < a.M) store8(a.dS_out + (size_t)gr * V2_C + c0, z);
       *reinterpret_cast<uint4*>(Xb + r * V2_C + c0) = px[q];
       if (tile + (int)gridDim.x < a.ntiles) prefetch_q(tile + gridDim.x, q);
     }
