@@ -98,10 +98,12 @@ def kernel_own_bytes(cls, rows, hidden, esz):
     return {
         1: 3 * t,                          # read input rows once, write raw output once + the kept depthwise output (for wgrad)
         2: 3 * t + hidden * hidden * 4,    # read dYbn, Y (BN backward on load), the kept depthwise output; write dW
+                                           # (round 4: the sub-block layers read the stored dS + the kept depthwise output in
+                                           #  pgemm_tn_batched_kernel instead; this class's launch keeps skip / epilog / pooling)
         3: 3 * t,                          # read dYbn, Y; write dD
-        4: (4 * t * 32 // 30) + t // 3,    # fused data gradient + depthwise backward: read dYbn, Y, previous raw output; write
-                                           # dYbn(prev); 32-row tiles yield 30 rows (the overlap is re-read); one launch in three
-                                           # (the last sub-block of a mega block) also stores the BatchNorm-backward'd dS
+        4: (4 * t * 32 // 30) + t,         # fused data gradient + depthwise backward: read dYbn, Y, previous raw output; write
+                                           # dYbn(prev); 32-row tiles yield 30 rows (the overlap is re-read); + the stored
+                                           # BatchNorm-backward'd dS (every launch since round 4: the weight gradient's operand)
     }[cls]
 
 

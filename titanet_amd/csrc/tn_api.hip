@@ -348,8 +348,9 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
       for (auto& bw : p->blk) {
         bw.dS.assign(c.n_sub_blocks, 0);
         for (int j = 0; j + 1 < c.n_sub_blocks; ++j) bw.dS[j] = b.take(M * H * e);
+        if (&bw != &p->blk[0]) bw.dS_skip = b.take(M * H * e);      // (block 0's skip conv reads the prolog output through its activation: stays in wgrad_batched_v2)
       }
-      p->tn_table = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * 64);
+      p->tn_table = b.take((size_t)c.n_mega_blocks * (c.n_sub_blocks + 1) * 64);
     }
     p->dw_table = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * 32);
   }
@@ -411,8 +412,10 @@ void plan_layout_tail(tn_plan* p) {
     //  tail is off for the step: both layouts must fit)
     for (int layout = 0; layout < (p->v2_tn ? 2 : 1); ++layout)
     for (const auto& bk : p->buckets) {
-      const int per_blk = layout == 1 ? 1 : (c.n_sub_blocks + 1) * p->wg2_upl;
-      const int layers = (bk.blk_hi >= bk.blk_lo ? (bk.blk_hi - bk.blk_lo + 1) * per_blk : 0) + (bk.tail ? p->wg2_epi_slabs + p->wg2_asp_units : 0);
+      const int per_blk = (c.n_sub_blocks + 1) * p->wg2_upl;
+      const bool hasb = bk.blk_hi >= bk.blk_lo;
+      const int layers = (layout == 1 ? ((hasb && bk.blk_lo == 0) ? 1 : 0) : (hasb ? (bk.blk_hi - bk.blk_lo + 1) * per_blk : 0)) +
+                         (bk.tail ? p->wg2_epi_slabs + p->wg2_asp_units : 0);
       if (layers == 0) continue;
       // (variable-length batches launch the group of block 0 without its first layer: both partitions must fit)
       for (int drop = 0; drop <= ((bk.blk_hi >= bk.blk_lo && bk.blk_lo == 0) ? p->wg2_upl : 0); drop += std::max(p->wg2_upl, 1)) {

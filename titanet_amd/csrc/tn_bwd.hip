@@ -208,16 +208,24 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       if (rc) { rc_fin = rc; return; }
     }
     if (v2_tn && has_blocks) {
-      // table: blocks from the last down, per block the sub-blocks from the last down
-      const int first = (nb - 1 - bk.blk_hi) * nsub, count = (bk.blk_hi - bk.blk_lo + 1) * nsub;
+      // table: blocks from the last down, per block the skip conv (blocks > 0), then the sub-blocks from the last down
+      auto ent = [&](int blk) { return nsub + (blk > 0 ? 1 : 0); };
+      int first = 0, count = 0;
+      for (int k2 = nb - 1; k2 > bk.blk_hi; --k2) first += ent(k2);
+      for (int k2 = bk.blk_hi; k2 >= bk.blk_lo; --k2) count += ent(k2);
       ProfScope ps(p, TN_PROF_BWD_WGRAD, st);
       const int rc = launch_pgemm_tn_batched((const PGemmTnDesc*)(ws + p->tn_table) + first, count, M, 1, nullptr, 0, st);
       if (rc) { rc_fin = rc; return; }
     }
     if (batched_wgrad) {
-      const int upb = v2_tn ? 1 : per_blk * p->wg2_upl;      // weight-gradient units per mega block (v2_tn: the skip conv only)
+      const int upb = per_blk * p->wg2_upl;      // weight-gradient units per mega block
       int first = has_blocks ? bk.blk_lo * upb : nb * upb;
       int count = (has_blocks ? (bk.blk_hi - bk.blk_lo + 1) * upb : 0) + (bk.tail ? p->wg2_epi_slabs + p->wg2_asp_units : 0);
+      if (v2_tn) {      // compact table: [block 0's skip conv, epilog / pooling units]
+        const bool b0 = has_blocks && bk.blk_lo == 0;
+        first = b0 ? 0 : 1;
+        count = (b0 ? 1 : 0) + (bk.tail ? p->wg2_epi_slabs + p->wg2_asp_units : 0);
+      }
       // variable-length batches: the first unit (block 0's skip conv: its other operand is the ACTIVATED prolog output, not
       // zero on padding rows) is done by the generic masked kernel instead (see the skip connection below)
       if (p->masked && has_blocks && bk.blk_lo == 0) { first += p->wg2_upl; count -= p->wg2_upl; }
@@ -534,6 +542,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         va.dZ = (const bf16_t*)(ws + bw.dZk); va.Y = (const bf16_t*)(ws + bw.S); va.bn = pa.bn;
         va.Wt = (const bf16_t*)(ws + bw.wskip.wt); va.OUT = (bf16_t*)(ws + p->dXs); va.M = M;
         va.Wswz = bw.wskip.swt ? (const uint4*)(ws + bw.wskip.swt) : nullptr;
+        va.dS_out = (v2_tn && bw.dS_skip) ? (bf16_t*)(ws + bw.dS_skip) : nullptr;      // operand of the pipelined weight-gradient launch
         ProfScope ps(p, TN_PROF_BWD_DGRAD, st);
         rc = launch_dgrad_v2<64>(va, 256, st);
       } else {
@@ -724,6 +733,9 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
       // incoming gradient would have been: one-pass tail), Q = the kept depthwise output
       for (int i = c.n_mega_blocks - 1; i >= 0; --i) {
         const BlockWs& bw = p->blk[i];
+        // the skip conv of blocks > 0: P = the dS stored by dgrad_v2, Q = the previous block's output (stored activated)
+        if (i > 0) td.push_back(PGemmTnDesc{(const bf16_t*)(p->ws + bw.dS_skip), (const bf16_t*)(p->ws + p->blk[i - 1].OUT),
+                                            p->grads + m->blocks[i].wskip, H, H, H, 1});
         for (int j = nsub - 1; j >= 0; --j)
           td.push_back(PGemmTnDesc{(const bf16_t*)(p->ws + (j == nsub - 1 ? bw.dY[j] : bw.dS[j])), (const bf16_t*)(p->ws + bw.Q[j]),
                                    p->grads + m->blocks[i].sub[j].wpw, H, H, H, 1});
@@ -837,11 +849,11 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
     }
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_out, wo.data(), wo.size() * sizeof(WgradV2Out), hipMemcpyHostToDevice, st));
     if (p->v2_tn) {
-      // third table: what stays in wgrad_batched_v2 when the sub-block layers go to the pipelined TN launch — the skip convs
-      // (one unit per block, compact: unit i = block i), then the epilog / pooling units as in the full table
+      // third table: what stays in wgrad_batched_v2 when the mega blocks' pointwise layers go to the pipelined TN launch — the
+      // first block's skip conv (its operand is the prolog output through its activation), then the epilog / pooling units
       std::vector<WgradV2Desc> wd3;
       std::vector<WgradV2Out> wo3;
-      for (int i = 0; i < c.n_mega_blocks; ++i) { wd3.push_back(wd[(size_t)i * (nsub + 1)]); wo3.push_back(wo[(size_t)i * (nsub + 1)]); }
+      wd3.push_back(wd[0]); wo3.push_back(wo[0]);
       for (size_t u = (size_t)c.n_mega_blocks * (nsub + 1); u < wd.size(); ++u) { wd3.push_back(wd[u]); wo3.push_back(wo[u]); }
       TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_desc + (size_t)2 * p->wg2_layers * sizeof(WgradV2Desc), wd3.data(),
                                   wd3.size() * sizeof(WgradV2Desc), hipMemcpyHostToDevice, st));

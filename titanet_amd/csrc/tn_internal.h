@@ -67,6 +67,7 @@ struct BlockWs {
   size_t S, OUT;
   size_t m, h, g;          // SE: mean [B][C], hidden [B][Hr], gate [B][C]  (float)
   std::vector<WcRef> wpw;
+  size_t dS_skip = 0;            // ... and of the skip connection's conv as stored by dgrad_v2 (blocks > 0)
   std::vector<size_t> dS;        // headline-shape plans: the BatchNorm-backward'd gradient of sub-block j as stored by dgrad_dw_v6 (0: none)
   std::vector<size_t> w8, w8s;   // TN_PREC_FP8: e4m3 pointwise weights [H][H] and their per-row scales [H] (float)
   std::vector<size_t> w8t, w8ts; // fp8 data gradient: e4m3 rows of W^T [ci][co] and their per-input-channel scales [H]

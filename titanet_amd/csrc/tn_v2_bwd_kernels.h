@@ -1360,6 +1360,7 @@ struct DgradV2Args {
   bf16_t* OUT;         // [M][256]
   int M, ntiles;
   const uint4* Wswz;   // optional: Wt in MFMA-fragment order [8 waves][16 k-steps][64 lanes] x 16 bytes
+  bf16_t* dS_out;      // optional: the BatchNorm-backward'd gradient, stored [M][256] (operand of the pipelined weight gradient)
 };
 
 template <int R>
@@ -1415,6 +1416,7 @@ __global__ __launch_bounds__(V2_NT, (R == 32 ? 4 : 2)) void dgrad_v2_kernel(Dgra
       if (out0 + r < a.M) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) z[i] = k0[i] * z[i] + k1[i] * y[i] + k2[i];
+        if (a.dS_out) store8(a.dS_out + (size_t)(out0 + r) * V2_C + c0, z);
       }
       store8(Pt + r * V2_AP + c0, z);
     }
