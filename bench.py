@@ -91,6 +91,17 @@ def pmc_traffic(cls):
         return None, None, None
 
 
+def device_note(dev):
+    """Which GPU rank 0 ran on, for whoever samples `rocm-smi` beside the run: HIP index 0 is the FIRST VISIBLE device
+    (HIP_/ROCR_VISIBLE_DEVICES), matched to an SMI card by its PCI bus id, not by number; and the GPU is busy for seconds
+    only — the timed region is steps x ms_per_step, the other legs a few hundred steps, the CPU baseline leg tens of seconds
+    of host-only work — so a 5-second sampler mostly sees it idle."""
+    pr = torch.cuda.get_device_properties(dev)
+    return {"hip_index": dev.index, "name": pr.name, "pci_bus_id": getattr(pr, "pci_bus_id", None),
+            "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES"),
+            "gpu_busy_note": "GPU legs total a few seconds of the run; match the SMI card by pci_bus_id"}
+
+
 def kernel_own_bytes(cls, rows, hidden, esz):
     """HBM bytes one launch of the kernel class moves by its own design (kept depthwise outputs and kept
     per-layer gradients included)."""
@@ -532,7 +543,8 @@ def main():
                        "grad_groups": args.grad_groups if world > 1 else 1,
                        "grad_groups_note": ("N > 1 runs the weight-gradient launch per gradient bucket (overlapped all-reduce): the same rank "
                                             "program costs ~0.1 ms/step more than the single-bucket N = 1 program (DESIGN.md 5)") if world > 1 else None,
-                       "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)}},
+                       "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
+                       "device": device_note(dev)},
             "roofline": {
                 "bound": "hbm", "scope": "whole step: SURVEY.md 8(d) algorithmic bytes / step time (per GPU)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
