@@ -381,9 +381,179 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
   pg_wait<0>();
 }
 
+// ==========================================================================================
+// rwgemm_k512_kernel: C = A W^T for K = 512 (TitaNet-M: every pointwise conv of the forward and of the data gradient) with the
+// WEIGHTS RESIDENT IN REGISTERS, the structure of the hidden-256 kernels (tn_v2_*): a workgroup owns one 256-column tile of
+// the output for the whole launch — its W tile [256 out][512 k] is 256 KB = 128 VGPRs per lane as MFMA A fragments (wave w: out
+// columns 32 w .. 32 w + 31) — and walks 64-row tiles of A: rows prefetched one tile ahead in registers (8 x 16 bytes per
+// thread), staged in LDS as the MFMA B operand (padded pitch), 64 MFMAs per wave and tile, the result rows back through LDS
+// for coalesced 16-byte stores.  pgemm_nt_kernel streams A AND W through the LDS ring for every tile: at K = 512 its operand
+// stream (393 KB per 128 x 256 tile, two thirds of it weights, at ~38 GB/s per CU) bounds it at 64 us per 76800 x 512 x 512
+// layer = 2.4 TB/s of its own bytes; here the only stream is A.
+// Column statistics (BatchNorm batch sums) are taken from the STORED (bf16-rounded) values in the store phase: per-thread
+// partial sums of a thread's 8 columns over all its rows and tiles, one LDS reduction + replicated atomics per workgroup.
+// Row-tile lists / pad_rows as in pgemm_nt_kernel (a listed 256-row tile = 4 tiles here).
+// ==========================================================================================
+#define RW_K 512
+#define RW_AP (RW_K + 8)       // pitch of the A tile rows in LDS (bf16 elements)
+#define RW_DP (256 + 8)        // pitch of the result rows
+#define RW_R 64
+// EPI: bias + column statistics (forward); false: plain product (data gradient) — 32 more registers for fragment prefetch
+template <bool EPI>
+__global__ __launch_bounds__(512, 2) void rwgemm_k512_kernel(GemmShape g, PGemmNtArgs pa, PGemmEpiArgs ea, int tiles_n, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* Pt = reinterpret_cast<bf16_t*>(smem);                 // [64][520] A rows (MFMA B operand)
+  bf16_t* Dt = Pt + RW_R * RW_AP;                               // [64][264] result rows
+  float* red = reinterpret_cast<float*>(smem);                  // [16][2][256] at the end (inside Pt)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int G = gridDim.x, v = pg_virtual_id(blockIdx.x, G);
+  const int ct = v % tiles_n, first = v / tiles_n, stride = G / tiles_n;      // G is a multiple of tiles_n (launcher)
+  const int col0 = ct * 256;
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
+  const int* __restrict__ rowtiles = pa.rowtiles;
+  // ---- this wave's weight fragments: out column col0 + 32 wave + (lane & 31), k = 16 ks + 8 half .. + 8
+  bf16x8_t wf[32];
+  {
+    const bf16_t* wr = W + (size_t)(col0 + wave * 32 + (lane & 31)) * RW_K + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) wf[ks] = *reinterpret_cast<const bf16x8_t*>(wr + ks * 16);
+  }
+  // bias of this lane's 16 result columns (MFMA layout: column 8 g + 4 half + r of the wave's 32)
+  float bv[EPI ? 16 : 1];
+  if constexpr (EPI) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[4 * gq + r] = ea.bias ? ea.bias[col0 + wave * 32 + 8 * gq + 4 * half + r] : 0.f;
+  }
+  // ---- A rows: thread (rq = tid >> 6: rows rq + 8 q, vc = tid & 63: 16-byte vector of the 1 KB row)
+  const int vc = tid & 63, rq = tid >> 6;
+  auto tile_row0 = [&](int t) -> int { return rowtiles ? tn_sload_i32(rowtiles, t >> 2) * 256 + (t & 3) * RW_R : t * RW_R; };
+  uint4 pre[8];
+  auto prefetch = [&](int t) {
+    const int r0 = tile_row0(t);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int gr = r0 + rq + 8 * q;
+      pre[q] = gr < g.M ? *reinterpret_cast<const uint4*>(pa.A + (size_t)gr * pa.lda + vc * 8) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  // store phase: thread (sv = tid & 31: 8 columns, sr = tid >> 5: rows sr + 16 q)
+  const int sv = tid & 31, sr = tid >> 5;
+  float ssum[EPI ? 8 : 1], ssq[EPI ? 8 : 1];
+  if constexpr (EPI) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ssum[i] = 0.f; ssq[i] = 0.f; }
+  }
+  int tile = first;
+  if (tile < ntiles) prefetch(tile);
+  for (; tile < ntiles; tile += stride) {
+    const int r0 = tile_row0(tile);
+    // (no barrier here: every wave is past barrier (3) of the previous tile, so its MFMAs are done with Pt; and Dt is rewritten
+    //  only behind barrier (2) below, which every wave reaches after its stores of the previous tile)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *reinterpret_cast<uint4*>(Pt + (rq + 8 * q) * RW_AP + vc * 8) = pre[q];
+    if (tile + stride < ntiles) prefetch(tile + stride);
+    __syncthreads();   // (2)
+    f32x16_t acc[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    const bf16_t* brow = Pt + (lane & 31) * RW_AP + half * 8;
+    // fragment reads PF k-steps ahead of their MFMAs (rotating registers): an LDS read issued right in front of its MFMA is a
+    // ~100-cycle wait per 32-cycle instruction with two waves per SIMD
+    constexpr int PF = EPI ? 2 : 8;
+    bf16x8_t bq[PF][2];
+#pragma unroll
+    for (int d = 0; d < PF; ++d)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) bq[d][n] = *reinterpret_cast<const bf16x8_t*>(brow + n * 32 * RW_AP + d * 16);
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+      bf16x8_t b0 = bq[ks % PF][0], b1 = bq[ks % PF][1];
+      if (ks + PF < 32) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bq[ks % PF][n] = *reinterpret_cast<const bf16x8_t*>(brow + n * 32 * RW_AP + (ks + PF) * 16);
+      }
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b1, acc[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        uint2 w;
+        if constexpr (EPI) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[n][4 * gq + r] += bv[4 * gq + r];
+        }
+        w.x = f2bf_pk(acc[n][4 * gq], acc[n][4 * gq + 1]);
+        w.y = f2bf_pk(acc[n][4 * gq + 2], acc[n][4 * gq + 3]);
+        *reinterpret_cast<uint2*>(Dt + (n * 32 + (lane & 31)) * RW_DP + wave * 32 + 8 * gq + 4 * half) = w;
+      }
+    __syncthreads();   // (3)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = sr + 16 * q, gr = r0 + o;
+      if (gr < g.M) {
+        const uint4 u = *reinterpret_cast<const uint4*>(Dt + o * RW_DP + sv * 8);
+        *reinterpret_cast<uint4*>(ea.Y + (size_t)gr * ea.ldy + col0 + sv * 8) = u;
+        if (EPI && ea.stats) {
+          const uint32_t uw[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float y0 = __uint_as_float(uw[i] << 16), y1 = __uint_as_float(uw[i] & 0xffff0000u);
+            ssum[2 * i] += y0; ssq[2 * i] = fmaf(y0, y0, ssq[2 * i]);
+            ssum[2 * i + 1] += y1; ssq[2 * i + 1] = fmaf(y1, y1, ssq[2 * i + 1]);
+          }
+        }
+      }
+    }
+  }
+  if (EPI && ea.stats) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[(sr * 2 + 0) * 256 + sv * 8 + i] = ssum[i]; red[(sr * 2 + 1) * 256 + sv * 8 + i] = ssq[i]; }
+    __syncthreads();
+    {
+      const int which = tid >> 8, c = tid & 255;      // 512 threads: sums | sums of squares of the 256 columns
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += red[(k * 2 + which) * 256 + c];
+      // variable-length batches: the all-zero padding rows inside the computed tiles gave y == bf16(bias) exactly — one
+      // workgroup per column tile takes their contribution out again
+      if (first == 0 && ea.pad_rows != 0.f && ea.bias) {
+        const float b = bf2f((bf16_t)(f2bf_pk(ea.bias[col0 + c], 0.f) & 0xffffu));
+        s = which ? fmaf(-ea.pad_rows * b, b, s) : fmaf(-ea.pad_rows, b, s);
+      }
+      atomic_add_f32(ea.stats + (size_t)((blockIdx.x % TN_NREP) * 2 + which) * g.N + col0 + c, s);
+    }
+  }
+}
+// -1000: not this kernel's shape
+inline int launch_rwgemm_k512(const GemmShape& g, const PGemmNtArgs& pa, const PGemmEpiArgs& ea, hipStream_t st, int max_wgs) {
+  if (g.K != RW_K || g.N % 256 || g.N <= 0 || g.N > 1024 || pa.lda % 8 || ea.ldy % 8 || ea.colscale || pa.rowexp) return -1000;
+  const int tiles_n = g.N / 256;
+  const int ntiles = pa.rowtiles ? pa.n_rowtiles * 4 : (g.M + RW_R - 1) / RW_R;
+  if (ntiles <= 0) return 0;
+  if (ntiles * tiles_n < max_wgs) return -1000;      // small problems: the tiled kernel
+  int grid = (max_wgs / (8 * tiles_n)) * 8 * tiles_n;   // multiple of 8 (XCD-contiguous order) and of the column tiles
+  if (grid <= 0) return -1000;
+  const size_t smem = (size_t)(RW_R * RW_AP + RW_R * RW_DP) * sizeof(bf16_t);
+  auto kern = (ea.bias || ea.stats) ? rwgemm_k512_kernel<true> : rwgemm_k512_kernel<false>;
+  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g, pa, ea, tiles_n, ntiles);
+  return (int)hipGetLastError();
+}
+
 template <int DBG = 0, bool F8 = false>
 inline int launch_pgemm_nt_t(const GemmShape& g, const PGemmNtArgs& pa, const PGemmEpiArgs& ea, hipStream_t st, int max_wgs, bool even_rounds = true) {
   if (g.K % (F8 ? 64 : 32) || g.K <= 0 || pa.lda % (F8 ? 16 : 8) || g.N % 64 || g.N > 3072 || ea.ldy % 2 || g.M <= 0) return TN_E_UNSUPPORTED;
+  if (!F8 && DBG == 0) {      // K = 512: weights resident in registers (rwgemm_k512_kernel)
+    const int rc = launch_rwgemm_k512(g, pa, ea, st, max_wgs);
+    if (rc != -1000) return rc;
+  }
   if ((long)g.M * pa.lda >= (1L << 32) || (long)g.N * g.K >= (1L << 32) || (long)g.M * ea.ldy * 2 >= (1L << 32)) return TN_E_UNSUPPORTED;
   const int tiles_n = (g.N + 255) / 256;
   // persistent workgroups with the same number of tiles each (1200 tiles: 240 x 5 beats 256 x 4.7, the last round of which
