@@ -429,15 +429,25 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_kernel(GemmShape g, PGemmN
   // ---- A rows: thread (rq = tid >> 6: rows rq + 8 q, vc = tid & 63: 16-byte vector of the 1 KB row)
   const int vc = tid & 63, rq = tid >> 6;
   auto tile_row0 = [&](int t) -> int { return rowtiles ? tn_sload_i32(rowtiles, t >> 2) * 256 + (t & 3) * RW_R : t * RW_R; };
-  uint4 pre[8];
+  // BUFFER loads / stores (rows beyond M read as zeros / are dropped by the descriptor's bounds check), the loads issued from
+  // inline asm and waited for with a COUNTED vmcnt: with predicated global loads / stores (each in its own exec-masked block)
+  // — and even with plain buffer loads, because the loop header merges the entry path (8 loads) with the back edge (8 loads +
+  // 4 stores) — hipcc waits with vmcnt(0) at the top of every tile, i.e. for the previous tile's output stores to be
+  // acknowledged: 41 % of the wave time sat in that s_waitcnt.  Here the loads of the next tile are older than the stores
+  // of this one (in-order queue), so "at most 4 outstanding" at the end of the tile retires exactly the loads.
+  typedef __attribute__((ext_vector_type(4))) unsigned int rw_u32x4_t;
+  const pg_i32x4_t srdA = pg_make_srd(pa.A, (unsigned)((size_t)g.M * pa.lda * sizeof(bf16_t)));
+  const __amdgpu_buffer_rsrc_t srdY = __builtin_amdgcn_make_buffer_rsrc(ea.Y, 0, (int)((size_t)g.M * ea.ldy * sizeof(bf16_t)), 0x00020000);
+  rw_u32x4_t pre[8];
   auto prefetch = [&](int t) {
     const int r0 = tile_row0(t);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int gr = r0 + rq + 8 * q;
-      pre[q] = gr < g.M ? *reinterpret_cast<const uint4*>(pa.A + (size_t)gr * pa.lda + vc * 8) : make_uint4(0, 0, 0, 0);
+      const unsigned voff = (unsigned)(((r0 + rq + 8 * q) * pa.lda + vc * 8) * sizeof(bf16_t));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(pre[q]) : "v"(voff), "s"(srdA) : "memory");
     }
   };
+#define RW_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]), "+v"(pre[4]), "+v"(pre[5]), "+v"(pre[6]), "+v"(pre[7]) : : "memory")
   // store phase: thread (sv = tid & 31: 8 columns, sr = tid >> 5: rows sr + 16 q)
   const int sv = tid & 31, sr = tid >> 5;
   float ssum[EPI ? 8 : 1], ssq[EPI ? 8 : 1];
@@ -446,14 +456,14 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_kernel(GemmShape g, PGemmN
     for (int i = 0; i < 8; ++i) { ssum[i] = 0.f; ssq[i] = 0.f; }
   }
   int tile = first;
-  if (tile < ntiles) prefetch(tile);
+  if (tile < ntiles) { prefetch(tile); RW_WAIT(0); }
   for (; tile < ntiles; tile += stride) {
     const int r0 = tile_row0(tile);
     // (no barrier here: every wave is past barrier (3) of the previous tile, so its MFMAs are done with Pt; and Dt is rewritten
     //  only behind barrier (2) below, which every wave reaches after its stores of the previous tile)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) *reinterpret_cast<uint4*>(Pt + (rq + 8 * q) * RW_AP + vc * 8) = pre[q];
-    if (tile + stride < ntiles) prefetch(tile + stride);
+    for (int q = 0; q < 8; ++q) *reinterpret_cast<rw_u32x4_t*>(Pt + (rq + 8 * q) * RW_AP + vc * 8) = pre[q];
+    prefetch(tile + stride < ntiles ? tile + stride : ntiles - 1);      // (unconditional: the wait below can then be counted)
     __syncthreads();   // (2)
     f32x16_t acc[2];
 #pragma unroll
@@ -496,11 +506,11 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_kernel(GemmShape g, PGemmN
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int o = sr + 16 * q, gr = r0 + o;
-      if (gr < g.M) {
-        const uint4 u = *reinterpret_cast<const uint4*>(Dt + o * RW_DP + sv * 8);
-        *reinterpret_cast<uint4*>(ea.Y + (size_t)gr * ea.ldy + col0 + sv * 8) = u;
-        if (EPI && ea.stats) {
-          const uint32_t uw[4] = {u.x, u.y, u.z, u.w};
+      const rw_u32x4_t u = *reinterpret_cast<const rw_u32x4_t*>(Dt + o * RW_DP + sv * 8);
+      __builtin_amdgcn_raw_buffer_store_b128(u, srdY, (int)((gr * ea.ldy + col0 + sv * 8) * sizeof(bf16_t)), 0, 0);
+      if (EPI && ea.stats && gr < g.M) {
+        {
+          const uint32_t uw[4] = {u[0], u[1], u[2], u[3]};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float y0 = __uint_as_float(uw[i] << 16), y1 = __uint_as_float(uw[i] & 0xffff0000u);
@@ -510,7 +520,9 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_kernel(GemmShape g, PGemmN
         }
       }
     }
+    RW_WAIT(4);        // the next tile's rows have landed (the 4 stores above, younger, may still be in flight)
   }
+#undef RW_WAIT
   if (EPI && ea.stats) {
     __syncthreads();
 #pragma unroll
@@ -534,6 +546,7 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_kernel(GemmShape g, PGemmN
 // -1000: not this kernel's shape
 inline int launch_rwgemm_k512(const GemmShape& g, const PGemmNtArgs& pa, const PGemmEpiArgs& ea, hipStream_t st, int max_wgs) {
   if (g.K != RW_K || g.N % 256 || g.N <= 0 || g.N > 1024 || pa.lda % 8 || ea.ldy % 8 || ea.colscale || pa.rowexp) return -1000;
+  if ((size_t)g.M * pa.lda * 2 >= ((size_t)1 << 31) || (size_t)g.M * ea.ldy * 2 >= ((size_t)1 << 31)) return -1000;      // 32-bit buffer offsets
   const int tiles_n = g.N / 256;
   const int ntiles = pa.rowtiles ? pa.n_rowtiles * 4 : (g.M + RW_R - 1) / RW_R;
   if (ntiles <= 0) return 0;
