@@ -615,11 +615,23 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
   // workgroup barriers), so that the register allocator sees max(producer, consumer) live values, not their sum.
   if (producer) {
     // ---- producer: raw rows of the next tile (8 rows per thread) -> activated rows -> stencil -> operand tile
+    // unconditional BUFFER loads / stores (rows outside the tensor and tiles past the last one are out of the descriptor's
+    // range: zeros / dropped): predicated accesses sit in exec-masked blocks, hipcc then waits with vmcnt(0) for the next
+    // tile's rows — and with them for the kept depthwise output rows it has just stored
+    typedef __attribute__((ext_vector_type(4))) unsigned int v5_u32x4_t;
+    const int tbytes = (int)((size_t)a.M * V2_C * sizeof(bf16_t));
+    const __amdgpu_buffer_rsrc_t srdX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.X), 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdQ = __builtin_amdgcn_make_buffer_rsrc(a.Q, 0, a.Q ? tbytes : 0, 0x00020000);
+    constexpr int V5_OOB = 0x7ffffff0;
+    auto store_q = [&](int row, bool keep, const float (&v)[8]) {
+      v5_u32x4_t w;
+      w[0] = f2bf_pk(v[0], v[1]); w[1] = f2bf_pk(v[2], v[3]); w[2] = f2bf_pk(v[4], v[5]); w[3] = f2bf_pk(v[6], v[7]);
+      __builtin_amdgcn_raw_buffer_store_b128(w, srdQ, keep ? (row * V2_C + c0) * (int)sizeof(bf16_t) : V5_OOB, 0, 0);
+    };
     uint4 pf[R / 8];
     auto prefetch_q = [&](int tile, int q) {
       const int gr = tile * OUTR - PADR + rq + 8 * q;
-      if (tile < a.ntiles && gr >= 0 && gr < a.M) pf[q] = *reinterpret_cast<const uint4*>(a.X + (size_t)gr * V2_C + c0);
-      else pf[q] = make_uint4(0, 0, 0, 0);
+      pf[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srdX, (tile < a.ntiles) ? (gr * V2_C + c0) * (int)sizeof(bf16_t) : V5_OOB, 0, 0));
     };
     auto prefetch = [&](int tile) {
 #pragma unroll
@@ -676,7 +688,7 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
 #pragma unroll
               for (int i = 0; i < 8; ++i) acc[i] = fmaf(wd[k][i], win[q + k][i], acc[i]);
             store8(As + (o0 + q) * V2_AP + c0, acc);
-            if (a.Q && o0 + q < OUTR && out0 + o0 + q < a.M) store8(a.Q + (size_t)(out0 + o0 + q) * V2_C + c0, acc);
+            store_q(out0 + o0 + q, o0 + q < OUTR && out0 + o0 + q < a.M, acc);
           }
         } else {
 #pragma unroll
@@ -701,7 +713,7 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
               }
             }
             store8(As + o * V2_AP + c0, acc);
-            if (a.Q && o < OUTR && out0 + o < a.M) store8(a.Q + (size_t)(out0 + o) * V2_C + c0, acc);
+            store_q(out0 + o, o < OUTR && out0 + o < a.M, acc);
           }
         }
       }
@@ -727,6 +739,8 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
     bf16x8_t wf[2][16];
     float biasr[2][16];
     float st_s[8], st_q[8];
+    typedef __attribute__((ext_vector_type(4))) unsigned int v5c_u32x4_t;
+    const __amdgpu_buffer_rsrc_t srdYc = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, (int)((size_t)a.M * V2_C * sizeof(bf16_t)), 0x00020000);
 #pragma unroll
     for (int cbk = 0; cbk < 2; ++cbk) {
       const int co = cw * 64 + cbk * 32 + (lane & 31);
@@ -782,9 +796,10 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
 #pragma unroll
         for (int q = 0; q < R / 8; ++q) {
           const int o = rq + 8 * q, gr = out0 + o;
-          if (o < OUTR && gr < a.M) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(Cs + o * V2_AP + c0);
-            *reinterpret_cast<uint4*>(a.Y + (size_t)gr * V2_C + c0) = raw;
+          const bool keep = o < OUTR && gr < a.M;
+          const uint4 raw = *reinterpret_cast<const uint4*>(Cs + (keep ? o : 0) * V2_AP + c0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v5c_u32x4_t, raw), srdYc, keep ? (gr * V2_C + c0) * (int)sizeof(bf16_t) : 0x7ffffff0, 0, 0);
+          if (keep) {
             float y[8];
             unpack8(raw, y);
 #pragma unroll
