@@ -1388,13 +1388,19 @@ __global__ __launch_bounds__(V2_NT, (R == 32 ? 4 : 2)) void dgrad_v2_kernel(Dgra
       else wf[ks] = *reinterpret_cast<const bf16x8_t*>(a.Wt + (size_t)ci * V2_C + ks * 16 + half * 8);
     }
   }
+  // unconditional buffer loads / stores, as in sub_fwd_v5 (rows beyond the tensor: zeros / dropped; an absent dS_out: every
+  // store dropped): the compiler's vmcnt waits then stay counted instead of vmcnt(0) behind this tile's output stores
+  typedef __attribute__((ext_vector_type(4))) unsigned int dg_u32x4_t;
+  const int tbytes = (int)((size_t)a.M * V2_C * sizeof(bf16_t));
+  const __amdgpu_buffer_rsrc_t srdZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.dZ), 0, tbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdY = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.Y), 0, tbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc(a.OUT, 0, tbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdS = __builtin_amdgcn_make_buffer_rsrc(a.dS_out, 0, a.dS_out ? tbytes : 0, 0x00020000);
   uint4 pz[NQ], py[NQ];
   auto prefetch_q = [&](int tile, int q) {
-    const int gr = tile * R + rq + 16 * q;
-    const bool ok = gr < a.M;
-    const size_t o = (size_t)gr * V2_C + c0;
-    pz[q] = ok ? *reinterpret_cast<const uint4*>(a.dZ + o) : make_uint4(0, 0, 0, 0);
-    py[q] = ok ? *reinterpret_cast<const uint4*>(a.Y + o) : make_uint4(0, 0, 0, 0);
+    const int o = ((tile * R + rq + 16 * q) * V2_C + c0) * (int)sizeof(bf16_t);
+    pz[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srdZ, o, 0, 0));
+    py[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srdY, o, 0, 0));
   };
   int tile = blockIdx.x;
   if (tile < a.ntiles) {
@@ -1417,14 +1423,17 @@ __global__ __launch_bounds__(V2_NT, (R == 32 ? 4 : 2)) void dgrad_v2_kernel(Dgra
       if (out0 + r < a.M) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) z[i] = k0[i] * z[i] + k1[i] * y[i] + k2[i];
-        if (a.dS_out) store8(a.dS_out + (size_t)(out0 + r) * V2_C + c0, z);
+      }
+      {
+        dg_u32x4_t zs;
+        zs[0] = f2bf_pk(z[0], z[1]); zs[1] = f2bf_pk(z[2], z[3]); zs[2] = f2bf_pk(z[4], z[5]); zs[3] = f2bf_pk(z[6], z[7]);
+        __builtin_amdgcn_raw_buffer_store_b128(zs, srdS, ((out0 + r) * V2_C + c0) * (int)sizeof(bf16_t), 0, 0);      // (rows >= M: out of range)
       }
       store8(Pt + r * V2_AP + c0, z);
     }
-    if (tile + (int)gridDim.x < a.ntiles) {     // (refilling inside the loop above measured 2.5 us slower)
+    // (refilling inside the loop above measured 2.5 us slower; past the last tile: rows beyond M, zeros)
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) prefetch_q(tile + gridDim.x, q);
-    }
+    for (int q = 0; q < NQ; ++q) prefetch_q(tile + gridDim.x, q);
     __syncthreads();   // (2)
     f32x16_t acc[NTILE];
 #pragma unroll
@@ -1454,7 +1463,8 @@ __global__ __launch_bounds__(V2_NT, (R == 32 ? 4 : 2)) void dgrad_v2_kernel(Dgra
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int o = rq + 16 * q, gr = out0 + o;
-      if (gr < a.M) *reinterpret_cast<uint4*>(a.OUT + (size_t)gr * V2_C + c0) = *reinterpret_cast<const uint4*>(Dt + o * V2_AP + c0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dg_u32x4_t, *reinterpret_cast<const uint4*>(Dt + o * V2_AP + c0)), srdO,
+                                             (gr * V2_C + c0) * (int)sizeof(bf16_t), 0, 0);      // (rows >= M: out of range)
     }
   }
 }

@@ -158,14 +158,18 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v4_kernel(SubFwdV2Args a) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
 
+  // unconditional buffer loads / stores, as in sub_fwd_v5 (rows outside the tensor: zeros / dropped)
+  typedef __attribute__((ext_vector_type(4))) unsigned int v4_u32x4_t;
+  const int tbytes = (int)((size_t)a.M * V2_C * sizeof(bf16_t));
+  const __amdgpu_buffer_rsrc_t srdX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.X), 0, tbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdY = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, tbytes, 0x00020000);
   uint4 pf[4];
   auto prefetch = [&](int tile) {
     const int raw0 = tile * OUTR - PADR;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int gr = raw0 + rq + 16 * q;
-      if (gr >= 0 && gr < a.M) pf[q] = *reinterpret_cast<const uint4*>(a.X + (size_t)gr * V2_C + c0);
-      else pf[q] = make_uint4(0, 0, 0, 0);
+      pf[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srdX, (gr * V2_C + c0) * (int)sizeof(bf16_t), 0, 0));
     }
   };
   int tile = blockIdx.x;
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v4_kernel(SubFwdV2Args a) {
         else store8(As + r * V2_AP + c0, v);
       }
     }
-    if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);   // next tile's loads fly during the rest
+    prefetch(tile + gridDim.x);   // next tile's loads fly during the rest (past the last tile: rows beyond M, zeros)
     __syncthreads();   // (2)
     if (DW) {
       // ---- depthwise stencil over time -> MFMA operand tile.  Each thread owns 4 CONSECUTIVE output rows
@@ -293,9 +297,10 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v4_kernel(SubFwdV2Args a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int o = rq + 16 * q, gr = out0 + o;
-      if (o < OUTR && gr < a.M) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(Cs + o * V2_AP + c0);
-        *reinterpret_cast<uint4*>(a.Y + (size_t)gr * V2_C + c0) = raw;
+      const bool keep = o < OUTR && gr < a.M;
+      const uint4 raw = *reinterpret_cast<const uint4*>(Cs + (keep ? o : 0) * V2_AP + c0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4_u32x4_t, raw), srdY, keep ? (gr * V2_C + c0) * (int)sizeof(bf16_t) : 0x7ffffff0, 0, 0);
+      if (keep) {
         float y[8];
         unpack8(raw, y);
 #pragma unroll
