@@ -36,11 +36,17 @@ extern "C" {
 
 #define TN_PREC_FP32 0 /* f32 storage, v_mfma_f32_32x32x2_f32: the 1e-3 parity path */
 #define TN_PREC_BF16 1 /* bf16 activations/weights, v_mfma_f32_32x32x16_bf16, f32 accumulate/statistics */
-#define TN_PREC_FP8 2  /* BASELINE.json configs[4] (TitaNet-L): the pointwise (1x1) convs of the mega-block sub-blocks —
-                          reference src/modules.py:76-78, 91 % of the model's FLOPs — run their FORWARD GEMM on the fp8 matrix
-                          cores (v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales), OCP e4m3 operands: the depthwise output as produced, the
-                          weights with one scale per output channel), f32 accumulation; everything else (storage, statistics,
-                          the whole backward pass, skip / epilog / attention GEMMs) is the bf16 plan */
+#define TN_PREC_FP8 2  /* BASELINE.json configs[4] (TitaNet-L): the pointwise (1x1) convs of the mega blocks — reference
+                          src/modules.py:76-78, 91 % of the model's FLOPs — on the fp8 matrix cores
+                          (v_mfma_scale_f32_32x32x64_f8f6f4, OCP e4m3 operands, f32 accumulation):
+                            forward   the sub-blocks' GEMMs: the depthwise output as produced, weights with one scale per
+                                      output channel (unit block scales);
+                            backward  (hidden 512 / 1024) the data gradients dS * W of the sub-blocks and of the skip
+                                      connections: dS rows as e4m3 with one power-of-two scale per row, passed as the MFMA's
+                                      own block-scale operand; W^T rows with one scale per input channel.
+                          Storage, statistics, the weight gradients, the depthwise / SE arithmetic and the 1536-wide decoder
+                          GEMMs are the bf16 plan's. */
+#define TN_PREC_FP8_FWD 3 /* TN_PREC_FP8 with the whole backward pass in bf16 (forward GEMMs only on the fp8 matrix cores) */
 
 #define TN_LOSS_NONE 0
 #define TN_LOSS_CE 1     /* reference src/losses.py:22-44  (fc has a bias)                     */

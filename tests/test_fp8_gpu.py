@@ -75,7 +75,7 @@ def test_fp8_eval_and_training_run():
 def test_fp8_data_gradient_vs_bf16_data_gradient(hidden, kernel, masked, monkeypatch):
     """Round 4: under the fp8 plan the sub-block data gradients dS * W run on the f8f6f4 MFMA too (e4m3 dS rows with one
     power-of-two scale per row as the MFMA's block scale, e4m3 W^T rows with per-input-channel scales; tn_pgemm.h F8 + rowexp).
-    Same weights, batch and dropout stream with TN_FP8_BWD=0 (bf16 backward of the same plan): every large gradient tensor
+    Same weights, batch and dropout stream with precision="fp8_fwd" (TN_PREC_FP8_FWD: bf16 backward of the same plan): every large gradient tensor
     within 8e-2, whole-gradient cosine > 0.998 — and not identical, i.e. the fp8 kernels did run."""
     case = _case(hidden, kernel, blocks=2, batch=16, frames=128)
     x, y = case_inputs(case, torch.float32)
@@ -85,9 +85,9 @@ def test_fp8_data_gradient_vs_bf16_data_gradient(hidden, kernel, masked, monkeyp
         lengths = torch.randint(20, 129, (16,), generator=g)
         lengths[3] = 128
     grads = {}
-    for tag, env in (("fp8", "1"), ("bf16", "0")):
-        monkeypatch.setenv("TN_FP8_BWD", env)
-        m = build(case, "ce", precision="fp8").train()
+    monkeypatch.delenv("TN_FP8_BWD", raising=False)
+    for tag, prec in (("fp8", "fp8"), ("bf16", "fp8_fwd")):      # fp8_fwd == TN_PREC_FP8_FWD: the same plan, backward in bf16
+        m = build(case, "ce", precision=prec).train()
         m._seed_base, m._step = 11, 0
         emb, preds, lv = m(x.cuda(), speakers=y.cuda(), lengths=lengths)
         lv.backward()

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtitanet_amd.so")
 
-TN_PREC_FP32, TN_PREC_BF16, TN_PREC_FP8 = 0, 1, 2
+TN_PREC_FP32, TN_PREC_BF16, TN_PREC_FP8, TN_PREC_FP8_FWD = 0, 1, 2, 3
 TN_LOSS_NONE, TN_LOSS_CE, TN_LOSS_MARGIN = 0, 1, 2
 TN_KIND_PARAM, TN_KIND_BUFFER, TN_KIND_NBT = 0, 1, 2
 
@@ -132,21 +132,32 @@ class HostMarks:
         self._t = torch.zeros(n, dtype=torch.int32).pin_memory()
         self._np = self._t.numpy()              # shares the pinned memory: element reads are plain loads
         self._want = [0] * n
+        self._streams = [0] * n
         self._seq = 0
         self._lib = load()
 
     def mark(self, i, stream):
-        self._seq = (self._seq + 1) & 0x3FFFFFFF
+        self._seq = self._seq % 0x3FFFFFFF + 1      # 1 .. 2^30 - 1: never 0, which means "nothing pending"
         self._want[i] = self._seq
+        self._streams[i] = stream
         check(self._lib.tn_mark_host(C.c_void_p(self._t.data_ptr() + 4 * i), C.c_uint32(self._seq), C.c_void_p(stream)), "tn_mark_host")
 
     def pending(self, i):
         return self._want[i] != 0 and int(self._np[i]) != self._want[i]
 
-    def wait(self, i):
+    def wait(self, i, timeout_s=60.0):
+        """Polls word ``i`` with short sleeps.  A mark that never lands (GPU fault, sticky HIP error, the stream destroyed)
+        must not hang the caller silently: past ``timeout_s`` the stream is synchronised through the runtime — which surfaces
+        the error an event wait would have raised — and a store that is still missing after that raises."""
         want = self._want[i]
         if want:
             import time
             a = self._np
+            t0 = time.monotonic()
             while int(a[i]) != want:
                 time.sleep(2e-4)
+                if time.monotonic() - t0 > timeout_s:
+                    import torch
+                    torch.cuda.synchronize()        # raises on a faulted device / sticky error
+                    if int(a[i]) != want:
+                        raise TitaNetLibraryError(f"HostMarks.wait: mark {want} of slot {i} never landed (stream {self._streams[i]})")

@@ -163,7 +163,9 @@ struct Bump {
 
 extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, int32_t precision, tn_plan** out) {
   if (!m || !out || batch <= 0 || frames <= 0) return TN_E_BADARG;
-  if (precision != TN_PREC_FP32 && precision != TN_PREC_BF16 && precision != TN_PREC_FP8) return TN_E_BADARG;
+  if (precision != TN_PREC_FP32 && precision != TN_PREC_BF16 && precision != TN_PREC_FP8 && precision != TN_PREC_FP8_FWD) return TN_E_BADARG;
+  const bool fp8_fwd_only = precision == TN_PREC_FP8_FWD;
+  if (fp8_fwd_only) precision = TN_PREC_FP8;
   if (precision == TN_PREC_FP8 && m->cfg.hidden % 16) return TN_E_UNSUPPORTED;
   if ((int64_t)batch * frames * std::max(m->cfg.enc_out, m->cfg.hidden) >= ((int64_t)1 << 32)) return TN_E_UNSUPPORTED;
   tn_plan* p = new tn_plan();
@@ -174,10 +176,13 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   {
     // fp8 data gradients of the sub-block pointwise convs (wide models on the pipelined GEMMs; a row of dS is one or two waves
     // of the BatchNorm-backward pass that quantises it)
+    // (TN_PREC_FP8_FWD: forward GEMMs only; TN_FP8_BWD=0 in the environment does the same for A/B scripts.  Only plans on the
+    //  pipelined GEMMs — the wide_wgrad condition below — have the kernels; elsewhere the flag and its buffers stay off)
     const char* e = getenv("TN_FP8_BWD");
+    const char* eg = getenv("TN_GENERIC");
     const int Hh = m->cfg.hidden;
-    p->fp8_bwd = p->fp8 && !p->fp8_bwd_emu && (Hh == 512 || Hh == 1024) && ((size_t)batch * frames * (Hh / 8)) % 256 == 0 &&
-                 !(e && atoi(e) == 0);
+    p->fp8_bwd = p->fp8 && !fp8_fwd_only && !p->fp8_bwd_emu && (Hh == 512 || Hh == 1024) && ((size_t)batch * frames * (Hh / 8)) % 256 == 0 &&
+                 m->cfg.enc_out % 256 == 0 && m->cfg.n_mega_blocks > 0 && !(eg && atoi(eg) != 0) && !(e && atoi(e) == 0);
   }
   if (p->fp8) precision = TN_PREC_BF16;      // storage, statistics and the backward pass are the bf16 plan's
   p->prec = precision;
@@ -367,6 +372,19 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   p->se_table = b.take((size_t)(c.n_mega_blocks + 1) * 64);
   p->ws_fixed_bytes = (b.off + 255) & ~(size_t)255;
   plan_layout_tail(p);
+  {
+    // TN_OVERLAP=0 turns the side stream off (A/B switch, read at plan creation)
+    const char* eo = getenv("TN_OVERLAP");
+    p->overlap = p->use_v2 && c.n_mega_blocks > 0 && !(eo && atoi(eo) == 0);
+    if (p->overlap) {
+      if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) { p->side = nullptr; p->overlap = false; }
+      for (int i = 0; p->overlap && i < 4 * c.n_mega_blocks; ++i) {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { p->overlap = false; break; }
+        p->ov_events.push_back(ev);
+      }
+    }
+  }
   *out = p;
   return 0;
 }
@@ -407,26 +425,40 @@ void plan_layout_tail(tn_plan* p) {
     // every group's launch cuts its (layer, 32-row chunk) units into one contiguous range per workgroup: the number of
     // partial slabs a layer can receive is bounded by the smallest group
     const int chunks = (p->M + 31) / 32;
+    auto parts_for = [&](int count) {
+      if (count <= 0) return 0;
+      const long total = (long)count * chunks;
+      const int upw = (int)((total + p->wg2_grid - 1) / p->wg2_grid);
+      return (chunks + upw - 1) / upw + 1;
+    };
+    const int per_blk = (c.n_sub_blocks + 1) * p->wg2_upl;
+    const int n_tail = p->wg2_epi_slabs + p->wg2_asp_units;
+    // full layout (every unit of a bucket in its launch; uniform stride of wg2_maxparts slabs per unit)
     int maxparts = 1;
-    // (v2_tn plans launch only the skip conv of each block here — fewer units, more partial slabs per unit — unless the one-pass
-    //  tail is off for the step: both layouts must fit)
-    for (int layout = 0; layout < (p->v2_tn ? 2 : 1); ++layout)
     for (const auto& bk : p->buckets) {
-      const int per_blk = (c.n_sub_blocks + 1) * p->wg2_upl;
       const bool hasb = bk.blk_hi >= bk.blk_lo;
-      const int layers = (layout == 1 ? ((hasb && bk.blk_lo == 0) ? 1 : 0) : (hasb ? (bk.blk_hi - bk.blk_lo + 1) * per_blk : 0)) +
-                         (bk.tail ? p->wg2_epi_slabs + p->wg2_asp_units : 0);
-      if (layers == 0) continue;
+      const int layers = (hasb ? (bk.blk_hi - bk.blk_lo + 1) * per_blk : 0) + (bk.tail ? n_tail : 0);
       // (variable-length batches launch the group of block 0 without its first layer: both partitions must fit)
-      for (int drop = 0; drop <= ((bk.blk_hi >= bk.blk_lo && bk.blk_lo == 0) ? p->wg2_upl : 0); drop += std::max(p->wg2_upl, 1)) {
-        if (layers - drop <= 0) break;
-        const long total = (long)(layers - drop) * chunks;
-        const int upw = (int)((total + p->wg2_grid - 1) / p->wg2_grid);
-        maxparts = std::max(maxparts, (chunks + upw - 1) / upw + 1);
-      }
+      maxparts = std::max(maxparts, parts_for(layers));
+      if (hasb && bk.blk_lo == 0) maxparts = std::max(maxparts, parts_for(layers - p->wg2_upl));
     }
     p->wg2_maxparts = maxparts;
-    p->wg2_slabs = b.take((size_t)p->wg2_layers * p->wg2_maxparts * 256 * 256 * sizeof(float));
+    size_t need = (size_t)p->wg2_layers * maxparts;
+    // compact layout of v2_tn plans (third descriptor table: block 0's skip conv, then the epilog / pooling units): a bucket's
+    // launch may hold ONE unit, cut over the whole grid — so its units get their own slab ranges inside the same region
+    // (unit 0: parts3_u0 slabs, every tail unit: parts3_tail) instead of inflating the uniform stride of all ~86 units
+    p->wg2_parts3_u0 = p->wg2_parts3_tail = 0;
+    if (p->v2_tn) {
+      for (const auto& bk : p->buckets) {
+        const bool b0 = bk.blk_hi >= bk.blk_lo && bk.blk_lo == 0;
+        const int cnt = (b0 ? 1 : 0) + (bk.tail ? n_tail : 0);
+        const int parts = std::max(parts_for(cnt), b0 ? parts_for(cnt - 1) : 0);
+        if (b0) p->wg2_parts3_u0 = std::max(p->wg2_parts3_u0, parts);
+        if (bk.tail) p->wg2_parts3_tail = std::max(p->wg2_parts3_tail, parts);
+      }
+      need = std::max(need, (size_t)p->wg2_parts3_u0 + (size_t)n_tail * p->wg2_parts3_tail);
+    }
+    p->wg2_slabs = b.take(need * 256 * 256 * sizeof(float));
   }
   p->ws_bytes = (b.off + 255) & ~(size_t)255;
 }
@@ -469,6 +501,8 @@ extern "C" void tn_plan_destroy(tn_plan* p) {
   if (!p) return;
   for (auto e : p->prof_events) (void)hipEventDestroy(e);
   for (auto e : p->bucket_events) (void)hipEventDestroy(e);
+  for (auto e : p->ov_events) (void)hipEventDestroy(e);
+  if (p->side) (void)hipStreamDestroy(p->side);
   delete p;
 }
 
@@ -700,10 +734,13 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   const int use_v2 = (p->masked && T < 64) ? 0 : p->use_v2;
   const RowMask rm = plan_row_mask(p);
   if (p->masked && c.simple_pool) return TN_E_UNSUPPORTED;
-  auto pad_fixup = [&](float* stats, const float* bias, int C) {
+  auto pad_fixup_on = [&](float* stats, const float* bias, int C, hipStream_t s2) {
     if (p->masked && training && stats && p->M > p->n_valid)
-      hipLaunchKernelGGL(stats_pad_fixup_kernel<0>, dim3(1), dim3(256), 0, st, stats, bias, (float)(p->M - p->n_valid), C, 1);
+      hipLaunchKernelGGL(stats_pad_fixup_kernel<0>, dim3(1), dim3(256), 0, s2, stats, bias, (float)(p->M - p->n_valid), C, 1);
   };
+  auto pad_fixup = [&](float* stats, const float* bias, int C) { pad_fixup_on(stats, bias, C, st); };
+  // side stream (tn_plan::overlap): the skip conv of a mega block runs beside its sub-block chain
+  const bool ov = p->overlap && use_v2 && p->side != nullptr;
 
   TN_CHECK_HIP(hipMemsetAsync(ws + p->zero_begin, 0, p->zero_bytes, st));
   if (p->n_cast > 0) {
@@ -749,6 +786,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
     const MegaBlockRef& mb = m->blocks[i];
     BlockWs& bw = p->blk[i];
     // skip connection: 1x1 conv (reference src/models.py:452-455)
+    bool skip_on_side = false;
     {
       int rc = -1000;
       if (keep_a0 && i == 0) {
@@ -760,8 +798,17 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
         SubFwdV2Args va{(const bf16_t*)xin, actx, nullptr, nullptr, (const bf16_t*)(ws + bw.wskip.w), params + mb.bskip,
                         (bf16_t*)(ws + bw.S), statp(mb.bnskip), M, T, 0,
                         bw.wskip.sw ? (const uint4*)(ws + bw.wskip.sw) : nullptr, nullptr};
-        rc = launch_sub_fwd_v4<1, false>(va, 256, st);
-        if (rc == 0) pad_fixup(statp(mb.bnskip), params + mb.bskip, H);
+        hipStream_t ss = st;
+        if (ov) {
+          TN_CHECK_HIP(hipEventRecord(p->ov_events[4 * i], st));            // fork: the block input is complete
+          TN_CHECK_HIP(hipStreamWaitEvent(p->side, p->ov_events[4 * i], 0));
+          ss = p->side;
+        }
+        rc = launch_sub_fwd_v4<1, false>(va, 256, ss);
+        if (rc == 0) pad_fixup_on(statp(mb.bnskip), params + mb.bskip, H, ss);
+        if (ov) TN_CHECK_HIP(hipEventRecord(p->ov_events[4 * i + 1], p->side));   // joined in front of the combine below
+        if (ov && rc == -1000) TN_CHECK_HIP(hipStreamWaitEvent(st, p->ov_events[4 * i + 1], 0));
+        skip_on_side = ov && rc == 0;
       }
       if (rc == -1000) {
         GemmShape g{M, H, H, wsel<AT>(p, mb.wskip, bw.wskip)};
@@ -839,6 +886,10 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
     // SE gate + residual combine (reference src/modules.py:173-189, src/models.py:467-472)
     {
       const int CV = H / 8, TG = 512 / CV;
+      auto join_skip = [&]() -> int {
+        if (skip_on_side) { TN_CHECK_HIP(hipStreamWaitEvent(st, p->ov_events[4 * i + 1], 0)); skip_on_side = false; }
+        return 0;
+      };
       size_t smem = (size_t)(3 * H + ((Hr + 3) & ~3) + TG * H) * sizeof(float);
       int rc1 = -1000;
       if (sizeof(AT) == 2 && H == V2_C && Hr == 16 && use_v2) {
@@ -857,6 +908,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
         hipLaunchKernelGGL(se_squeeze_fc_kernel<AT>, dim3(B), dim3(512), smem, st, (const AT*)cur, acur, T, H, Hr,
                            params + mb.se_w1, params + mb.se_w2, (float*)(ws + bw.m), (float*)(ws + bw.h), (float*)(ws + bw.g), acc, acc ? 2 : 0, p->tail_parts);
       }
+      { int rcj = join_skip(); if (rcj) return rcj; }      // the combine reads S and the skip BatchNorm's statistics
       BnAct acts = make_act(p, mb.bnskip, M, training, 0, 0.f, seed, 0);
       uint32_t thr = 0, key = 0;
       float ik = 1.f;

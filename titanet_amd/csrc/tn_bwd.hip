@@ -157,6 +157,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   auto tn_entries = [&](int blk) { return nsub + ((blk > 0 || p->a0) ? 1 : 0); };
   auto tn_offset = [&](int blk) { int o = 0; for (int k = c.n_mega_blocks - 1; k > blk; --k) o += tn_entries(k); return o; };
   const bool v2_bwd = sizeof(AT) == 2 && use_v2;
+  const bool ov = p->overlap && v2_bwd && p->side != nullptr;      // independent launches on the plan's side stream (tn_internal.h)
   // round 4: the mega-block tail backward in ONE pass (combine_bwd1_v3 finishes the SE backward per utterance; the last
   // sub-block's fused data-gradient kernel rebuilds its incoming gradient on load and stores the BatchNorm-backward'd dS for
   // the weight-gradient launch): fixed-length training batches of the headline shape
@@ -204,7 +205,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       const bool listed = p->masked && p->n_rowtiles > 0;
       ProfScope ps(p, TN_PROF_BWD_WGRAD, st);
       const int rc = launch_pgemm_tn_batched((const PGemmTnDesc*)(ws + p->tn_table) + first, count, M, (H / 256) * (H / 256),
-                                             listed ? (const int*)(ws + p->rowtiles) : nullptr, listed ? p->n_rowtiles : 0, st);
+                                             listed ? (const int*)(ws + p->rowtiles) : nullptr, listed ? p->n_rowtiles : 0, st, 256, H);
       if (rc) { rc_fin = rc; return; }
     }
     if (v2_tn && has_blocks) {
@@ -214,7 +215,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       for (int k2 = nb - 1; k2 > bk.blk_hi; --k2) first += ent(k2);
       for (int k2 = bk.blk_hi; k2 >= bk.blk_lo; --k2) count += ent(k2);
       ProfScope ps(p, TN_PROF_BWD_WGRAD, st);
-      const int rc = launch_pgemm_tn_batched((const PGemmTnDesc*)(ws + p->tn_table) + first, count, M, 1, nullptr, 0, st);
+      const int rc = launch_pgemm_tn_batched((const PGemmTnDesc*)(ws + p->tn_table) + first, count, M, 1, nullptr, 0, st, 256, H);
       if (rc) { rc_fin = rc; return; }
     }
     if (batched_wgrad) {
@@ -518,6 +519,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     }
     DBG("block dOUT", p->dA[cur], (size_t)M * H); DBG("combine dZk", bw.dZk, (size_t)M * H); DBG("combine dY3", bw.dY[nsub - 1], (size_t)M * H);
     // ---- skip connection: d S = BN-backward(dZ); dXs = dS * W_skip; d W_skip = dS^T X
+    bool skip_on_side = false;
     if (pipe) {
       // (fp8 plans: its own e4m3 dS buffer — the last sub-block's, written by the one-pass tail above, is still pending)
       const bool f8s = p->fp8_bwd && bw.w8t_skip != 0;
@@ -543,8 +545,20 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         va.Wt = (const bf16_t*)(ws + bw.wskip.wt); va.OUT = (bf16_t*)(ws + p->dXs); va.M = M;
         va.Wswz = bw.wskip.swt ? (const uint4*)(ws + bw.wskip.swt) : nullptr;
         va.dS_out = (v2_tn && bw.dS_skip) ? (bf16_t*)(ws + bw.dS_skip) : nullptr;      // operand of the pipelined weight-gradient launch
-        ProfScope ps(p, TN_PROF_BWD_DGRAD, st);
-        rc = launch_dgrad_v2<64>(va, 256, st);
+        // side stream: the skip data gradient depends on the tail pass above only, and only the FIRST sub-block's launch
+        // (its ADD operand) needs it — it runs beside the data-gradient launches of the other sub-blocks.  (p->dXs is shared by
+        // all blocks: the fork event of block i - 1 sits behind block i's last reader on `st`)
+        hipStream_t ss = st;
+        if (ov && nsub >= 2) {
+          TN_CHECK_HIP(hipEventRecord(p->ov_events[4 * i + 2], st));
+          TN_CHECK_HIP(hipStreamWaitEvent(p->side, p->ov_events[4 * i + 2], 0));
+          ss = p->side;
+        }
+        {
+          ProfScope ps(p, TN_PROF_BWD_DGRAD, ss);
+          rc = launch_dgrad_v2<64>(va, 256, ss);
+        }
+        if (ss != st) { TN_CHECK_HIP(hipEventRecord(p->ov_events[4 * i + 3], p->side)); skip_on_side = true; }
       } else {
         GemmShape g{M, H, H, wt(bw.wskip)};
         EpiStoreArgs ea{ws + p->dXs, H, nullptr, nullptr};
@@ -592,6 +606,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         } else {
           fa.ADD = (const bf16_t*)(ws + p->dXs); fa.OUT = (bf16_t*)(ws + p->dA[cur ^ 1]);
           fa.bsumsX = (i == 0) ? bsum(m->prolog_bn) : nullptr;
+          if (skip_on_side) { TN_CHECK_HIP(hipStreamWaitEvent(st, p->ov_events[4 * i + 3], 0)); skip_on_side = false; }   // join: dXs
         }
         int rc;
         {
@@ -838,8 +853,9 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_desc, wd.data(), wd.size() * sizeof(WgradV2Desc), hipMemcpyHostToDevice, st));
     // second table: the fused-tail flow of backward_impl — the last sub-block's gradient buffer then holds the
     // BatchNorm-backward'd dS itself (stored by dgrad_dw_v6<.., Z3>): a plain P operand
+    std::vector<WgradV2Desc> wd2;      // (source of an asynchronous copy: lives until the synchronise that ends this block)
     if (hs == 1 && nsub >= 2) {
-      std::vector<WgradV2Desc> wd2 = wd;
+      wd2 = wd;
       for (int i = 0; i < c.n_mega_blocks; ++i) {
         WgradV2Desc& d = wd2[(size_t)i * (nsub + 1) + 1 + (nsub - 1)];
         d.Y = nullptr; d.fstats = nullptr; d.bsums = nullptr;
@@ -855,6 +871,12 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
       std::vector<WgradV2Out> wo3;
       wd3.push_back(wd[0]); wo3.push_back(wo[0]);
       for (size_t u = (size_t)c.n_mega_blocks * (nsub + 1); u < wd.size(); ++u) { wd3.push_back(wd[u]); wo3.push_back(wo[u]); }
+      // their own slab ranges (plan_layout_tail): unit 0 may be cut over the whole grid when it is alone in its bucket's launch
+      for (size_t u = 0; u < wd3.size(); ++u) {
+        const size_t first = u == 0 ? 0 : (size_t)p->wg2_parts3_u0 + (u - 1) * (size_t)p->wg2_parts3_tail;
+        wd3[u].slabs = (float*)(p->ws + p->wg2_slabs) + first * 256 * 256;
+        wo3[u].slabs = wd3[u].slabs;
+      }
       TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_desc + (size_t)2 * p->wg2_layers * sizeof(WgradV2Desc), wd3.data(),
                                   wd3.size() * sizeof(WgradV2Desc), hipMemcpyHostToDevice, st));
       TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->wg2_out3, wo3.data(), wo3.size() * sizeof(WgradV2Out), hipMemcpyHostToDevice, st));
@@ -871,6 +893,7 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
       }
     if (sizeof(DwGradOut) > 32) return TN_E_STATE;
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->dw_table, dg.data(), dg.size() * sizeof(DwGradOut), hipMemcpyHostToDevice, st));
+    TN_CHECK_HIP(hipStreamSynchronize(st));      // wd, wd2, wo, dg are pageable sources of the copies above
   }
   TN_CHECK_HIP(hipStreamSynchronize(st));
   return 0;

@@ -153,6 +153,7 @@ struct tn_plan {
   size_t dw_gacc, dw_table;                         // depthwise gradient accumulators [layer][NREP][KD+1][256] + finalize table
   int wg2_layers = 0, wg2_maxparts = 0, wg2_units_per_wg = 0, wg2_grid = 0, wg2_epi_slabs = 0, wg2_asp_units = 0;
   int wg2_upl = 1;              // units per pointwise layer: (hidden / 256)^2 output slabs of 256 x 256
+  int wg2_parts3_u0 = 0, wg2_parts3_tail = 0;   // v2_tn plans: partial slabs of the compact table's units (block 0's skip conv / each tail unit)
   bool wide_wgrad = false;      // hidden = 512 / 1024 (TitaNet-M / -L), bf16: slab depthwise kernels + the pipelined GEMMs of tn_pgemm.h
   size_t bwd_table_bytes = 0;
   // gradient buckets in COMPLETION order (data-parallel overlap: bucket i's all-reduce starts when its event fires)
@@ -166,6 +167,12 @@ struct tn_plan {
   int grad_groups = 1;            // 1: one bucket, every deferred weight gradient in one launch at the end of backward
   std::vector<GradBucket> buckets;
   std::vector<hipEvent_t> bucket_events;
+  // independent launches of a mega block on a side stream (round 5): the skip conv beside the sub-block chain (forward), the
+  // skip data gradient beside the last two sub-blocks' fused data-gradient launches (backward) — one kernel's ramp-up fills
+  // the other's drain.  Fork / join with plan-owned events; works under stream capture (the side stream joins the capture).
+  bool overlap = false;
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> ov_events;   // [block][4]: forward fork / join, backward fork / join
   // per-kernel event timing (tn_profile_*)
   int prof_class = 0;
   int prof_stride = 1;            // tn_profile_sample: bracket every n-th launch of the class

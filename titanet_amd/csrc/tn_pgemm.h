@@ -817,10 +817,13 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_batched_kernel(const PGemmTnD
     pos += n;
   }
 }
+// ld_max: the widest row stride (elements) among the descriptors' operands — they live in device memory, so the 32-bit
+// buffer-offset limit of the kernel is checked against what the caller says it put there
 inline int launch_pgemm_tn_batched(const PGemmTnDesc* descs_dev, int n_descs, int rows, int U, const int* rowtiles, int n_rowtiles, hipStream_t st,
-                                   int max_wgs = 256) {
+                                   int max_wgs = 256, int ld_max = 1024) {
   if (n_descs <= 0) return 0;
-  if (U <= 0 || U > max_wgs || rows <= 0) return TN_E_UNSUPPORTED;
+  if (U <= 0 || U > max_wgs || rows <= 0 || ld_max % 8) return TN_E_UNSUPPORTED;
+  if ((long)(rows + 512) * ld_max * 2 >= (1L << 32)) return TN_E_UNSUPPORTED;
   const int nsteps = rowtiles ? n_rowtiles * 8 : (rows + 31) / 32;
   if (nsteps <= 0) return 0;
   const long total = (long)n_descs * nsteps;

@@ -1471,6 +1471,7 @@ __global__ __launch_bounds__(V2_NT, (R == 32 ? 4 : 2)) void dgrad_v2_kernel(Dgra
 
 template <int R>
 inline int launch_dgrad_v2(DgradV2Args a, int max_wgs, hipStream_t st) {
+  if ((long)a.M * V2_C * 2 >= (1L << 31)) return -1000;      // 32-bit buffer offsets: the generic kernel takes such a batch
   a.ntiles = (a.M + R - 1) / R;
   const int grid = a.ntiles < max_wgs ? a.ntiles : max_wgs;
   const size_t smem = (size_t)2 * R * V2_AP * sizeof(bf16_t) + (size_t)3 * V2_C * sizeof(float);

@@ -342,6 +342,7 @@ inline int launch_sub_fwd_v4_t(SubFwdV2Args a, int grid, size_t smem, hipStream_
 }
 template <int KD, bool DW>
 inline int launch_sub_fwd_v4(SubFwdV2Args a, int resident_wgs, hipStream_t st) {
+  if ((long)a.M * V2_C * 2 >= (1L << 31)) return -1000;      // 32-bit buffer offsets: the generic kernel takes such a batch
   constexpr int OUTR = DW ? V2_R - (KD - 1) : V2_R;
   a.ntiles = (a.M + OUTR - 1) / OUTR;
   const int grid = a.ntiles < resident_wgs ? a.ntiles : resident_wgs;
@@ -846,6 +847,7 @@ inline int launch_sub_fwd_v5_t(SubFwdV2Args a, int grid, size_t smem, hipStream_
 // R: raw rows per tile (64, or 32: twice the tiles per workgroup — a shorter pipeline fill / drain per launch)
 template <int KD, bool DW, int R = V2_R>
 inline int launch_sub_fwd_v5(SubFwdV2Args a, int resident_wgs, hipStream_t st) {
+  if ((long)a.M * V2_C * 2 >= (1L << 31)) return -1000;      // 32-bit buffer offsets: the generic kernel takes such a batch
   constexpr int OUTR = DW ? R - (KD - 1) : R;
   a.ntiles = (a.M + OUTR - 1) / OUTR;
   const int grid = a.ntiles < resident_wgs ? a.ntiles : resident_wgs;

@@ -326,7 +326,7 @@ class TitaNet(nn.Module):
 
     # ------------------------------------------------------------------ native calls
     def _prec(self):
-        return {"fp32": _lib.TN_PREC_FP32, "bf16": _lib.TN_PREC_BF16, "fp8": _lib.TN_PREC_FP8}[self.precision]
+        return {"fp32": _lib.TN_PREC_FP32, "bf16": _lib.TN_PREC_BF16, "fp8": _lib.TN_PREC_FP8, "fp8_fwd": _lib.TN_PREC_FP8_FWD}[self.precision]
 
     def _get_plan(self, batch, frames):
         key = (batch, frames, self._prec(), bool(self.training))      # train and eval forwards never share saved state
