@@ -41,8 +41,8 @@ ALG_BYTES_PER_UTT_BF16 = 70.66e6   # 7,065,600 elements x 5 pa
 
 PROF_CLASSES = {1: "fwd_subblock_gemm", 2: "bwd_pointwise_wgrad", 3: "bwd_skip_dgrad", 4: "bwd_subblock_dgrad_depthwise"}
 # kernel behind each class on the headline shape (for the PMC traffic lookup)
-PROF_KERNELS = {1: "sub_fwd_v5_kernel<3, true, 7", 2: "wgrad_batched_v2_kernel<3, false>", 3: "dgrad_v2_kernel<64>",
-                4: "dgrad_dw_v6_kernel<7"}       # (name prefixes: every instance of the class's main flag set)
+PROF_KERNELS = {1: ("sub_fwd_v5_kernel<3, true, 7",), 2: ("pgemm_tn_batched_kernel", "wgrad_batched_v2_kernel<3, false>"),
+                3: ("dgrad_v2_kernel<64>",), 4: ("dgrad_dw_v6_kernel<7",)}       # (name prefixes: every instance of the class's main flag set)
 
 
 def _pmc_file():
@@ -81,7 +81,7 @@ def pmc_traffic(cls):
             return None, None, os.path.relpath(path, ROOT) + " (STALE: taken at kernel digest %s, this build is %s)" % (
                 meta.get("kernel_digest"), _kernel_digest())
         steps = float(meta.get("steps", 0))
-        ks = [v for n, v in data.items() if n != "_meta" and n.startswith(PROF_KERNELS[cls])]
+        ks = [v for n, v in data.items() if n != "_meta" and n.startswith(PROF_KERNELS[cls])]      # (a tuple of prefixes)
         per_launch = int(sum(_pmc_bytes(v) * v.get("launches", 0) for v in ks) / max(sum(v.get("launches", 0) for v in ks), 1)) if ks else None
         per_step = None
         if steps > 0:
@@ -108,9 +108,10 @@ def kernel_own_bytes(cls, rows, hidden, esz):
     t = rows * hidden * esz
     return {
         1: 3 * t,                          # read input rows once, write raw output once + the kept depthwise output (for wgrad)
-        2: 3 * t + hidden * hidden * 4,    # read dYbn, Y (BN backward on load), the kept depthwise output; write dW
-                                           # (round 4: the sub-block layers read the stored dS + the kept depthwise output in
-                                           #  pgemm_tn_batched_kernel instead; this class's launch keeps skip / epilog / pooling)
+        2: 2 * t + hidden * hidden * 4,    # ONE unit of the class since round 4: the stored BatchNorm-backward'd dS + the kept
+                                           # depthwise output (pgemm_tn_batched_kernel: 67 such units per step); the units left
+                                           # in wgrad_batched_v2_kernel (block 0's skip conv, 6 epilog slabs: 3t each, 12
+                                           # pooling units: 1.5t) are added by the caller (class_units_per_step)
         3: 3 * t,                          # read dYbn, Y; write dD
         4: (4 * t * 32 // 30) + t,         # fused data gradient + depthwise backward: read dYbn, Y, previous raw output; write
                                            # dYbn(prev); 32-row tiles yield 30 rows (the overlap is re-read); + the stored
@@ -513,8 +514,14 @@ def main():
         # of the epilog conv in ONE launch (each unit reads dZ, Y and the kept depthwise output once: 3t); with gradient
         # groups (N > 1) the same units are spread over 1 + groups launches
         # ... and the two attentive-pooling weight gradients as 12 units of 1.5t (one 128-wide operand)
-        units = (17 * 4 + 6 + 12 * 0.5) / max(per_step, 1) if (dom == 2 and per_step < 17 * 3) else 1.0
+        # class 2 = both weight-gradient kernels (72 % of its time is pgemm_tn_batched_kernel): per step 67 stored-operand units of
+        # 2t (51 sub-block layers + the skip convs of blocks > 0) + block 0's skip conv and the 6 epilog slabs at 3t (dZ, Y and the
+        # operand: BatchNorm backward on load) + 12 pooling units at 1.5t, spread over the class's launches of the step
+        units = 1.0
         own = int(kernel_own_bytes(dom, rows, 256, esz) * units)
+        if dom == 2:
+            t_ = rows * 256 * esz
+            own = int((67 * 2 * t_ + 7 * 3 * t_ + 12 * 1.5 * t_ + 86 * 256 * 256 * 4) / max(per_step, 1))
         attributed = int(kernel_attributed_bytes(dom, rows, 256, esz) * units)
         avg_s = (ms.value / 1e3) / max(cnt.value, 1)
         value = args.batch * world * args.steps / dt
@@ -557,7 +564,7 @@ def main():
                 "frac_of_cold_stream_ceiling": rnd(achieved / ceil["cold"], 4) if ceil["cold"] else None,
                 "moved_GBps": round(s_traffic / step_s / 1e9, 1) if s_traffic else None,
                 "dominant_kernel": {
-                    "class": PROF_CLASSES[dom], "name": PROF_KERNELS[dom], "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt.value,
+                    "class": PROF_CLASSES[dom], "name": " + ".join(PROF_KERNELS[dom]), "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt.value,
                     "sampled_every": stride,
                     "own_bytes_per_launch": own, "achieved_own_GBps": round(own / avg_s / 1e9, 1),
                     "attributed_8d_bytes_per_launch": attributed, "frac_attributed": round(attributed / avg_s / 1e9 / HBM_PEAK_GBS, 4),

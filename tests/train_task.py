@@ -34,8 +34,8 @@ class SpeakerTask:
         mod = 1.0 + 0.5 * torch.sin(2 * math.pi * t / 50.0 + phase)           # slow amplitude modulation, random phase
         return tmpl * mod * self.sig + torch.randn(B, N_MELS, T, generator=g) * 0.11 - 0.10
 
-    def batch(self, step, B, T):
-        g = torch.Generator().manual_seed(1000 + step)
+    def batch(self, step, B, T, stream=0):
+        g = torch.Generator().manual_seed(1000 + step + 1000003 * stream)
         y = torch.randint(0, self.z_train.shape[0], (B,), generator=g)
         return self.utterances(self.z_train[y], T, g), y
 
@@ -51,7 +51,7 @@ class SpeakerTask:
         return specs, spk
 
 
-def train_and_verify(task, precision, size="s", n_blocks=17, head="ce", steps=300, B=64, T=201, dropout=0.1, lr=1e-3, tail=20):
+def train_and_verify(task, precision, size="s", n_blocks=17, head="ce", steps=300, B=64, T=201, dropout=0.1, lr=1e-3, tail=20, stream=0):
     """``steps`` fused-Adam steps of the reference's step protocol (reference src/learn.py:88-135) on ``task``; returns the
     mean loss / training accuracy of the last ``tail`` steps and the verification metrics of the held-out speakers."""
     torch.manual_seed(0)
@@ -65,7 +65,7 @@ def train_and_verify(task, precision, size="s", n_blocks=17, head="ce", steps=30
     tr = Trainer(m, lr=lr)
     hist, accs = [], []
     for s in range(steps):
-        x, y = task.batch(s, B, T)
+        x, y = task.batch(s, B, T, stream)
         y = y.cuda()
         _, preds, l = tr.step(x.cuda(), y)
         hist.append(l)
@@ -75,5 +75,5 @@ def train_and_verify(task, precision, size="s", n_blocks=17, head="ce", steps=30
     specs, spk = task.heldout()
     ver, _, _ = metrics.verification_test(m, specs, spk, batch_size=36)
     finite = bool(torch.isfinite(m.flat_parameters()).all())
-    return {"precision": precision, "loss_first": sum(hist[:tail]) / tail, "loss_last": sum(hist[-tail:]) / tail,
+    return {"precision": precision, "stream": stream, "loss_first": sum(hist[:tail]) / tail, "loss_last": sum(hist[-tail:]) / tail,
             "acc_last": sum(accs[-tail:]) / tail, "eer": ver["test/eer"], "mindcf": ver["test/mindcf"], "params_finite": finite}

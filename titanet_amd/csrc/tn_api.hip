@@ -373,9 +373,12 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   p->ws_fixed_bytes = (b.off + 255) & ~(size_t)255;
   plan_layout_tail(p);
   {
-    // TN_OVERLAP=0 turns the side stream off (A/B switch, read at plan creation)
+    // OFF by default: measured round 5 (profiles/r05_ab_overlap.txt, same box, alternating): 9.01 ms with the side stream
+    // against 8.81 without — two persistent 256-workgroup grids do not share the chip, the late workgroups of whichever
+    // kernel found the CUs taken start when the other kernel's finish and run their whole tile list alone.  TN_OVERLAP=1 (read
+    // at plan creation) turns it on for A/B runs.
     const char* eo = getenv("TN_OVERLAP");
-    p->overlap = p->use_v2 && c.n_mega_blocks > 0 && !(eo && atoi(eo) == 0);
+    p->overlap = p->use_v2 && c.n_mega_blocks > 0 && eo && atoi(eo) != 0;
     if (p->overlap) {
       if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) { p->side = nullptr; p->overlap = false; }
       for (int i = 0; p->overlap && i < 4 * c.n_mega_blocks; ++i) {
@@ -742,7 +745,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   // side stream (tn_plan::overlap): the skip conv of a mega block runs beside its sub-block chain
   const bool ov = p->overlap && use_v2 && p->side != nullptr;
 
-  TN_CHECK_HIP(hipMemsetAsync(ws + p->zero_begin, 0, p->zero_bytes, st));
+  TN_CHECK_HIP(tn_zero_async(ws + p->zero_begin, p->zero_bytes, st));
   if (p->n_cast > 0) {
     hipLaunchKernelGGL(cast_params_kernel<AT>, dim3(64, p->n_cast), dim3(256), 0, st, (const CastDesc*)(ws + p->cast_table));
     if (p->n_swz) hipLaunchKernelGGL(swizzle256_kernel<0>, dim3(16, p->n_swz), dim3(256), 0, st, (const SwzDesc*)(ws + p->swz_table));

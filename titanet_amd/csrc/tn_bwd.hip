@@ -93,8 +93,8 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   auto bsum = [&](const BnRef& bn) -> float* { return (float*)(ws + p->bsums[bn.id]); };
   auto wt = [&](const WcRef& r) -> const void* { return ws + r.wt; };
 
-  TN_CHECK_HIP(hipMemsetAsync(grads, 0, (size_t)m->n_params * sizeof(float), st));
-  TN_CHECK_HIP(hipMemsetAsync(ws + p->bzero_begin, 0, p->bzero_bytes, st));
+  TN_CHECK_HIP(tn_zero_async(grads, (size_t)m->n_params * sizeof(float), st));
+  TN_CHECK_HIP(tn_zero_async(ws + p->bzero_begin, p->bzero_bytes, st));
   const int use_v2 = (p->masked && T < 64) ? 0 : p->use_v2;     // variable-length batches: as the forward
   if (p->masked && c.simple_pool) return TN_E_UNSUPPORTED;
   auto identity_rows = [&]() { BnAct a = identity_act(); a.rm = plan_row_mask(p); return a; };

@@ -55,6 +55,13 @@ __device__ __forceinline__ pg_i32x4_t pg_make_srd(const void* base, unsigned byt
   return r;
 }
 
+// LDS-DMA through a buffer descriptor (rows outside the tensor read as zeros: the bounds check)
+__device__ __forceinline__ void pg_dma16_buf(unsigned voff, pg_i32x4_t srd, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_addr) : "memory");
+}
+
 // what an absent bias / column scale reads in the deep-ring variants (N <= 3072; one copy per translation unit)
 static __device__ const float pg_const_zeros[3072] = {};
 // ... and what absent row exponents read: E8M0 127 = scale 1 in every byte
@@ -154,11 +161,16 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
       offB[q] = ((unsigned)rb * (unsigned)g.K) * ESZ + chunk * 16;
     }
   };
+  // DBG 16 (experiment): every workgroup walks K from its own starting step (rows of a K-major operand are a power-of-two
+  // stride apart: workgroups marching through K in lockstep ask the same L2 channels for every row at the same time)
+  const int krot = (DBG & 16) ? (v * 5) % KT : 0;
+  auto kmap = [&](int kt) { const int k2 = kt + krot; return k2 >= KT ? k2 - KT : k2; };
+  constexpr int POLA = (DBG & 32) ? 1 : 0, POLB = (DBG & 64) ? 1 : 0;      // experiments: nt on the A / W stream
   auto dma_a = [&](int q, int kt, int stage) {
-    if (q < NQA) tn_dma16(Ab + (size_t)offA[q] + kt * ROWB, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + (q * 8 + wave) * 1024)));
+    if (q < NQA) tn_dma16<POLA>(Ab + (size_t)offA[q] + kmap(kt) * ROWB, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + (q * 8 + wave) * 1024)));
   };
   auto dma_b = [&](int q, int kt, int stage) {
-    tn_dma16(Wb + (size_t)offB[q] + kt * ROWB, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + TILE_B + (q * 8 + wave) * 1024)));
+    tn_dma16<POLB>(Wb + (size_t)offB[q] + kmap(kt) * ROWB, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + TILE_B + (q * 8 + wave) * 1024)));
   };
   // ---- MFMA side: fragment byte offsets inside a tile (row i of a 32-row block, k-step ks)
   const int fi = lane & 31, fh = lane >> 5;
@@ -543,16 +555,187 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_kernel(GemmShape g, PGemmN
     }
   }
 }
+
+// ==========================================================================================
+// rwgemm_k512_v2_kernel (round 5): the same product with the A rows streamed by LDS-DMA into a RING of 32-row stages.
+// rwgemm_k512_kernel keeps ONE tile of register prefetch (64 KB per CU, requested in a burst at the top of a tile, consumed at
+// the top of the next): its own counters said 41 % of the wave time sits in s_waitcnt and the matrix pipe is 30 % busy — the
+// stream (2.9 - 3.1 TB/s of its own bytes), not the arithmetic, is the time.  Here the only per-lane state of the stream is the
+// address: a DMA instruction moves one whole A row (64 lanes x 16 B = 1 KB = 512 bf16) into LDS at base + row * 1040 (the
+// padded pitch makes the 16-byte fragment reads conflict-free without a swizzle: one instruction = one row), 4 instructions
+// per wave and stage, 3 stages (96 KB per CU) always in flight behind a counted vmcnt.  Every vector-memory instruction of the
+// loop is inline asm (see pgemm_nt_kernel): the in-order vmcnt queue of a wave holds, per iteration, 4 DMA instructions then 2
+// output stores, so "at most 14 outstanding" at the top of iteration i + 1 retires exactly the rows of stage i + 1.
+// Past its last tile a workgroup keeps requesting out-of-range rows (descriptor bounds check: zeros, no memory traffic): every
+// wait has the same count and no branch splits the stream.
+// ==========================================================================================
+#define RW2_R 32
+#define RW2_PITCH 1040       // bytes: 1 KB row + 16
+#define RW2_NS 4
+template <bool EPI>
+__global__ __launch_bounds__(512, 2) void rwgemm_k512_v2_kernel(GemmShape g, PGemmNtArgs pa, PGemmEpiArgs ea, int tiles_n, int ntiles) {
+  constexpr int STAGE_B = RW2_R * RW2_PITCH;      // 33280
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* Dt = reinterpret_cast<bf16_t*>(smem + RW2_NS * STAGE_B);      // [32][264] result rows
+  float* red = reinterpret_cast<float*>(smem);                           // [16][2][256] at the end (inside the ring)
+  const unsigned lds0 = (unsigned)(uintptr_t)(tn_lds_char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = gridDim.x, v = pg_virtual_id(blockIdx.x, G);
+  const int ct = v % tiles_n, first = v / tiles_n, stride = G / tiles_n;      // G is a multiple of tiles_n (launcher)
+  const int col0 = ct * 256;
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
+  const int* __restrict__ rowtiles = pa.rowtiles;
+  bf16x8_t wf[32];
+  {
+    const bf16_t* wr = W + (size_t)(col0 + wave * 32 + (lane & 31)) * RW_K + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) wf[ks] = *reinterpret_cast<const bf16x8_t*>(wr + ks * 16);
+  }
+  float bv[EPI ? 16 : 1];
+  if constexpr (EPI) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[4 * gq + r] = ea.bias ? ea.bias[col0 + wave * 32 + 8 * gq + 4 * half + r] : 0.f;
+  }
+  const pg_i32x4_t srdA = pg_make_srd(pa.A, (unsigned)((size_t)g.M * pa.lda * sizeof(bf16_t)));
+  const pg_i32x4_t srdY = pg_make_srd(ea.Y, (unsigned)((size_t)g.M * ea.ldy * sizeof(bf16_t)));
+  // a listed 256-row tile = 8 tiles here; tiles past the end map to row M (out of the descriptor's range)
+  auto tile_row0 = [&](int t) -> int {
+    if (t >= ntiles) return g.M;
+    return rowtiles ? tn_sload_i32(rowtiles, t >> 3) * 256 + (t & 7) * RW2_R : t * RW2_R;
+  };
+  // this wave's rows of a stage: wave, wave + 8, wave + 16, wave + 24
+  auto dma_tile = [&](int t, int stage) {
+    const int r0 = tile_row0(t);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = wave + 8 * q;
+      const unsigned voff = (unsigned)(r0 + row) * (unsigned)(pa.lda * 2) + (unsigned)lane * 16u;
+      pg_dma16_buf(voff, srdA, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + row * RW2_PITCH)));
+    }
+  };
+  const int sv = tid & 31, sr = tid >> 5;      // store phase: 8 columns, rows sr, sr + 16
+  float ssum[EPI ? 8 : 1], ssq[EPI ? 8 : 1];
+  if constexpr (EPI) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ssum[i] = 0.f; ssq[i] = 0.f; }
+  }
+  // the compiler-visible loads above (weights, bias) must have retired before the hand-counted queue starts — and the
+  // COMPILER must know it: it places its own vmcnt wait in front of the first use of a loaded register, which would be inside
+  // the loop (a vmcnt(31 - ks) in front of every MFMA, i.e. a drain of the DMA ring and of the output stores per tile).  An
+  // empty asm that reads every fragment here makes it wait for them here
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) asm volatile("" : "+v"(wf[ks]));
+  if constexpr (EPI) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(bv[i]));
+  }
+  int tile = first, it = 0, stage = 0;
+#pragma unroll 1
+  for (int d = 0; d < RW2_NS - 1; ++d) dma_tile(tile + d * stride, d);
+#pragma unroll 1
+  for (; tile < ntiles; tile += stride, ++it) {
+    // this wave's rows of the stage have landed (queue behind them: see the header comment)
+    if (it == 0) pg_wait<8>();
+    else if (it == 1) pg_wait<10>();
+    else if (it == 2) pg_wait<12>();
+    else pg_wait<14>();
+    pg_barrier();      // (A) everybody's rows; every wave is past the store phase of the previous tile (Dt) and past its MFMAs
+    {
+      const int ns = stage == 0 ? RW2_NS - 1 : stage - 1;      // the stage of the previous tile is free now
+      dma_tile(tile + (RW2_NS - 1) * stride, ns);
+    }
+    const char* st_ = smem + stage * STAGE_B;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const char* brow = st_ + (lane & 31) * RW2_PITCH + half * 16;
+    constexpr int PF = 8;
+    bf16x8_t bq[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) bq[d] = *reinterpret_cast<const bf16x8_t*>(brow + d * 32);
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+      const bf16x8_t b0 = bq[ks % PF];
+      if (ks + PF < 32) bq[ks % PF] = *reinterpret_cast<const bf16x8_t*>(brow + (ks + PF) * 32);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b0, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      uint2 w;
+      if constexpr (EPI) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[4 * gq + r] += bv[4 * gq + r];
+      }
+      w.x = f2bf_pk(acc[4 * gq], acc[4 * gq + 1]);
+      w.y = f2bf_pk(acc[4 * gq + 2], acc[4 * gq + 3]);
+      *reinterpret_cast<uint2*>(Dt + (lane & 31) * RW_DP + wave * 32 + 8 * gq + 4 * half) = w;
+    }
+    pg_barrier();      // (B)
+    const int r0 = tile_row0(tile);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int o = sr + 16 * q, gr = r0 + o;
+      typedef __attribute__((ext_vector_type(4))) unsigned int rw2_u32x4_t;
+      const rw2_u32x4_t u = *reinterpret_cast<const rw2_u32x4_t*>(Dt + o * RW_DP + sv * 8);
+      const unsigned voff = ((unsigned)gr * (unsigned)ea.ldy + (unsigned)(col0 + sv * 8)) * 2u;
+      asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(u), "v"(voff), "s"(srdY) : "memory");
+      if (EPI && ea.stats && gr < g.M) {
+        const uint32_t uw[4] = {u[0], u[1], u[2], u[3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float y0 = __uint_as_float(uw[i] << 16), y1 = __uint_as_float(uw[i] & 0xffff0000u);
+          ssum[2 * i] += y0; ssq[2 * i] = fmaf(y0, y0, ssq[2 * i]);
+          ssum[2 * i + 1] += y1; ssq[2 * i + 1] = fmaf(y1, y1, ssq[2 * i + 1]);
+        }
+      }
+    }
+    stage = stage + 1 == RW2_NS ? 0 : stage + 1;
+  }
+  pg_wait<0>();
+  if (EPI && ea.stats) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[(sr * 2 + 0) * 256 + sv * 8 + i] = ssum[i]; red[(sr * 2 + 1) * 256 + sv * 8 + i] = ssq[i]; }
+    __syncthreads();
+    {
+      const int which = tid >> 8, c = tid & 255;      // 512 threads: sums | sums of squares of the 256 columns
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += red[(k * 2 + which) * 256 + c];
+      if (first == 0 && ea.pad_rows != 0.f && ea.bias) {
+        const float b = bf2f((bf16_t)(f2bf_pk(ea.bias[col0 + c], 0.f) & 0xffffu));
+        s = which ? fmaf(-ea.pad_rows * b, b, s) : fmaf(-ea.pad_rows, b, s);
+      }
+      atomic_add_f32(ea.stats + (size_t)((blockIdx.x % TN_NREP) * 2 + which) * g.N + col0 + c, s);
+    }
+  }
+}
 // -1000: not this kernel's shape
-inline int launch_rwgemm_k512(const GemmShape& g, const PGemmNtArgs& pa, const PGemmEpiArgs& ea, hipStream_t st, int max_wgs) {
+// variant: 2 = the LDS-DMA ring kernel (falls through to 1 when its shape conditions fail), 1 = register prefetch
+inline int launch_rwgemm_k512(const GemmShape& g, const PGemmNtArgs& pa, const PGemmEpiArgs& ea, hipStream_t st, int max_wgs, int variant = 2) {
   if (g.K != RW_K || g.N % 256 || g.N <= 0 || g.N > 1024 || pa.lda % 8 || ea.ldy % 8 || ea.colscale || pa.rowexp) return -1000;
   if ((size_t)g.M * pa.lda * 2 >= ((size_t)1 << 31) || (size_t)g.M * ea.ldy * 2 >= ((size_t)1 << 31)) return -1000;      // 32-bit buffer offsets
   const int tiles_n = g.N / 256;
+  int grid = (max_wgs / (8 * tiles_n)) * 8 * tiles_n;   // multiple of 8 (XCD-contiguous order) and of the column tiles
+  if (grid <= 0) return -1000;
+  if (variant == 2) {
+    // LDS-DMA ring of 32-row stages (rwgemm_k512_v2_kernel); the DMA moves whole 1 KB rows: lda == 512 only
+    const int ntiles = pa.rowtiles ? pa.n_rowtiles * 8 : (g.M + RW2_R - 1) / RW2_R;
+    if (ntiles <= 0) return 0;
+    if (ntiles * tiles_n < 2 * max_wgs || pa.lda != RW_K) return -1000;
+    const size_t smem = (size_t)RW2_NS * RW2_R * RW2_PITCH + (size_t)RW2_R * RW_DP * sizeof(bf16_t);
+    auto kern = (ea.bias || ea.stats) ? rwgemm_k512_v2_kernel<true> : rwgemm_k512_v2_kernel<false>;
+    TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g, pa, ea, tiles_n, ntiles);
+    return (int)hipGetLastError();
+  }
   const int ntiles = pa.rowtiles ? pa.n_rowtiles * 4 : (g.M + RW_R - 1) / RW_R;
   if (ntiles <= 0) return 0;
   if (ntiles * tiles_n < max_wgs) return -1000;      // small problems: the tiled kernel
-  int grid = (max_wgs / (8 * tiles_n)) * 8 * tiles_n;   // multiple of 8 (XCD-contiguous order) and of the column tiles
-  if (grid <= 0) return -1000;
   const size_t smem = (size_t)(RW_R * RW_AP + RW_R * RW_DP) * sizeof(bf16_t);
   auto kern = (ea.bias || ea.stats) ? rwgemm_k512_kernel<true> : rwgemm_k512_kernel<false>;
   TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -635,11 +818,6 @@ inline int launch_pgemm_nt_f8(const GemmShape& g, const PGemmNtArgs& pa, const P
 // ==========================================================================================
 typedef __attribute__((ext_vector_type(4))) short pg_s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short pg_s16x8_t;
-__device__ __forceinline__ void pg_dma16_buf(unsigned voff, pg_i32x4_t srd, unsigned lds_addr) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_addr) : "memory");
-}
 __device__ __forceinline__ bf16x8_t pg_tr_frag(const char* p) {
   const pg_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) pg_s16x4_t*)(p));
   const pg_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) pg_s16x4_t*)(p + 4 * 512));

@@ -1520,7 +1520,11 @@ struct DgradDwArgs {
 // padding rows of X read as zeros (no tap-weight gradient through them), the data gradient is written as zero there.
 // P2 (round 4): two barriers per tile instead of three — the stencil of tile t and the transform of tile t + 1 share one phase
 // (raw X rows double-buffered), the MFMAs of tile t + 1 the other.
-template <int FL, bool MK = false, bool Z3 = false, bool P2 = false>
+// WGX (tuning harness only, tools/dgrad_dw_harness.hip): what the MATRIX-PIPE share of a fused pointwise weight gradient would
+// add to a tile — 16 more MFMAs per wave (the 256 x 256 x 32-row product d W += dS^T Q of the tile, split over 8 waves) fed by
+// transposing LDS fragment reads of the tile's rows, on two alternating accumulators (the real thing needs 128 accumulator
+// registers per lane, which this kernel does not have: a LOWER bound of the in-kernel cost)
+template <int FL, bool MK = false, bool Z3 = false, bool P2 = false, int WGX = 0>
 __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
   constexpr int KD = 3, NT = V2_NT;
   constexpr bool HAS_MASK = (FL & 7) != 0, HAS_ADD = (FL & 8) != 0;
@@ -1668,6 +1672,40 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
       }
     }
   };
+  f32x16_t wgx_acc[2];
+  if constexpr (WGX != 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { wgx_acc[0][r] = 0.f; wgx_acc[1][r] = 0.f; }
+  }
+  auto wgx = [&](const bf16_t* Xb) {
+    if constexpr (WGX != 0) {
+      typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+      auto trfrag = [&](const bf16_t* base, int pitch_b, int r0, int cblk) {
+        // rows r0 .. r0 + 15 x 32 channels of block cblk, transposed: lane (l & 31) -> channel, k = rows
+        const char* q = reinterpret_cast<const char*>(base) + (size_t)(r0 + (lane >> 4) * 4) * 0 + (size_t)(r0 + ((lane & 15) >> 2)) * pitch_b + (cblk * 32 + (lane >> 4) * 8 + (lane & 3) * 2) * 2;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q + 8 * pitch_b));
+        s16x8_t v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return __builtin_bit_cast(bf16x8_t, v);
+      };
+      // wave: output-channel blocks 2 (wave >> 1) .. + 1 of dS, input-channel blocks 4 (wave & 1) .. + 3 of the other operand
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        bf16x8_t af[2], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = trfrag(Pt, V2_AP * 2, kh * 16, 2 * (wave >> 1) + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = trfrag(Xb, V2_C * 2, kh * 16, 4 * (wave & 1) + j);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            wgx_acc[(i * 4 + j) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], wgx_acc[(i * 4 + j) & 1], 0, 0, 0);
+      }
+    }
+  };
   auto stencil = [&](int tile, const bf16_t* Xb) {
     const int g0 = tile * V6_OUT - 1;
     TileMask tm = {0, 0, 0};
@@ -1777,6 +1815,7 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
       transform(tile, Xs);
       __syncthreads();   // (2)
       mfma();
+      wgx(Xs);
       __syncthreads();   // (3)
       stencil(tile, Xs);
       if (Z3 && tile + G < a.ntiles) publish_g();     // nobody reads gus between barrier (2) and the next barrier (1)
@@ -1806,6 +1845,12 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
       __syncthreads();
       buf ^= 1;
     }
+  }
+  if constexpr (WGX != 0) {      // keep the probe's accumulators alive
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += wgx_acc[0][r] + wgx_acc[1][r];
+    if (t == 12345.678f) gb[0] += t;
   }
   // s2 was accumulated against the RAW x:  sum dA * xhat = rstd * sum dA*x - mean*rstd * sum dA
 #pragma unroll

@@ -42,6 +42,30 @@ int main(int argc, char** argv) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("%s<7> %s: %.2f us per launch (%.2f TB/s over 4 passes)\n", "dgrad_dw_v6", p2 ? "two barriers per tile" : "three barriers per tile", ms * 1e3f / 40, 4.0 * M * C * 2 / (ms * 1e-3 / 40) / 1e12);
   }
+  // round 5: the matrix-pipe share of a fused pointwise weight gradient (WGX probe: +16 MFMAs per wave and tile + their
+  // transposing fragment reads, no accumulator flush, no depthwise-output recompute) against the plain kernel, alternating
+  {
+    const size_t tiles = (size_t)(2 * V6_R * V2_AP + V6_R * V2_C) * sizeof(bf16_t);
+    const size_t red = (size_t)8 * 6 * V2_C * sizeof(float);
+    const size_t smem = (tiles > red ? tiles : red) + (size_t)10 * V2_C * sizeof(float);
+    a.ntiles = (a.M + V6_OUT - 1) / V6_OUT;
+    auto k0 = dgrad_dw_v6_kernel<7, false, false, false, 0>;
+    auto k1 = dgrad_dw_v6_kernel<7, false, false, false, 1>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    for (int rep = 0; rep < 3; ++rep)
+      for (int which = 0; which < 2; ++which) {
+        auto go = [&](int it) { const int s = it % NSET; a.dZ = dZ[s]; a.Y = Y[s]; a.X = X[s]; a.OUT = OUT[s];
+                                hipLaunchKernelGGL(which ? k1 : k0, dim3(256), dim3(V2_NT), smem, 0, a); };
+        for (int it = 0; it < 4; ++it) go(it);
+        CK(hipDeviceSynchronize());
+        hipEventRecord(e0, 0);
+        for (int it = 0; it < 51; ++it) go(it);
+        hipEventRecord(e1, 0); CK(hipEventSynchronize(e1));
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("dgrad_dw_v6<7> %s: %.2f us per launch\n", which ? "+ 16 weight-gradient MFMAs per wave and tile (WGX probe)" : "plain", ms * 1e3f / 51);
+      }
+  }
   // checksum of the two outputs on the same inputs
   a.dZ = dZ[0]; a.Y = Y[0]; a.X = X[0]; a.OUT = OUT[0]; launch_dgrad_dw_v6(a, 256, 0, false);
   a.OUT = OUT[1]; launch_dgrad_dw_v6(a, 256, 0, true);

@@ -107,6 +107,28 @@ int main(int argc, char** argv) {
     float us = timeit([&](int i) { pa.X = A[i % NSET]; ea.Y = Y[i % NSET]; launch_gemm<bf16_t, 2, 4, ProdPlain, EpiStore>(g, pa, ea, 0, 0); });
     printf("gemm_nt_kernel (generic)  : %8.2f us  %.3f PFLOP/s\n", us, flop / us / 1e9);
   }
+  if (K == 512 && N % 256 == 0) {
+    // the two resident-weight kernels side by side (variant 1: register prefetch, 2: LDS-DMA ring), forward (bias + statistics)
+    // and data-gradient (plain) forms; outputs compared bitwise
+    for (int epi = 0; epi < 2; ++epi) {
+      std::vector<unsigned short> y1((size_t)M * N), y2((size_t)M * N);
+      for (int var = 1; var <= 2; ++var) {
+        PGemmNtArgs pa{A[0], K};
+        PGemmEpiArgs ea{Y[0], N, epi ? bias : nullptr, epi ? stats_tmp : nullptr, nullptr};
+        CK(hipMemset(Y[0], 0, (size_t)M * N * 2));
+        int rc = launch_rwgemm_k512(g, pa, ea, 0, 256, var);
+        if (rc) { printf("rwgemm variant %d: rc %d\n", var, rc); continue; }
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy((var == 1 ? y1 : y2).data(), Y[0], y1.size() * 2, hipMemcpyDeviceToHost));
+        float us = timeit([&](int i) { pa.A = A[i % NSET]; ea.Y = Y[i % NSET]; launch_rwgemm_k512(g, pa, ea, 0, 256, var); });
+        printf("rwgemm_k512 variant %d %-28s: %8.2f us  %.3f PFLOP/s  %.2f TB/s of its own bytes\n", var, epi ? "(bias + statistics)" : "(plain)", us, flop / us / 1e9,
+               ((double)M * K * 2 + (double)M * N * 2) / us / 1e6);
+      }
+      size_t bad = 0;
+      for (size_t i = 0; i < y1.size(); ++i) bad += y1[i] != y2[i];
+      printf("  variant 2 vs variant 1: %zu of %zu output elements differ\n", bad, y1.size());
+    }
+  }
   for (int wgs : {256, 240}) {
     PGemmNtArgs pa{A[0], K};
     PGemmEpiArgs ea{Y[0], N, bias, stats, nullptr};
@@ -129,6 +151,12 @@ int main(int argc, char** argv) {
     DBGRUN(8, "no stores")
     DBGRUN(9, "no MFMA, no stores")
     DBGRUN(10, "no DMA, no stores")
+    DBGRUN(16, "K rotated per workgroup")
+    DBGRUN(32, "nt on the A stream")
+    DBGRUN(64, "nt on the W stream")
+    DBGRUN(48, "K rotated + nt on A")
+    DBGRUN(25, "stream only (no MFMA, no stores), K rotated")
+    DBGRUN(41, "stream only, nt on A")
   }
   return 0;
 }

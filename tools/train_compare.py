@@ -1,9 +1,10 @@
 """fp32 vs bf16 (and fp8 vs bf16 at L width) training on the synthetic speaker task of tests/train_task.py: loss / accuracy
-plateau and held-out verification EER per precision.  The `-m gpu` form with assertions is tests/test_train_compare_gpu.py;
-this script sweeps the task difficulty (`sig`) and prints the table.
+plateau and held-out verification EER per precision, with a second data stream per precision as the yardstick (how far two
+runs of the SAME precision end up from each other).  The `-m gpu` form with assertions is tests/test_train_compare_gpu.py.
 
-    python tools/train_compare.py [sig ...]
+    python tools/train_compare.py [--sig S] [--steps N] [--train K] [--held H] [--what s17,l2]
 """
+import argparse
 import json
 import os
 import sys
@@ -12,14 +13,26 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.train_task import SpeakerTask, train_and_verify  # noqa: E402
 
 if __name__ == "__main__":
-    sigs = [float(a) for a in sys.argv[1:]] or [0.02]
-    for sig in sigs:
-        task = SpeakerTask(sig=sig)
-        for kw in (dict(precision="fp32"), dict(precision="bf16"), dict(precision="bf16", head="arc"), dict(precision="fp32", head="arc")):
-            r = train_and_verify(task, **kw)
-            r.update({"sig": sig, "head": kw.get("head", "ce")})
-            print(json.dumps(r), flush=True)
-        for prec in ("bf16", "fp8"):
-            r = train_and_verify(task, precision=prec, size="l", n_blocks=2)
-            r.update({"sig": sig, "model": "L/2"})
-            print(json.dumps(r), flush=True)
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sig", type=float, nargs="+", default=[0.02])
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--train", type=int, default=32)
+    ap.add_argument("--held", type=int, default=12)
+    ap.add_argument("--what", default="s17,l2")
+    ap.add_argument("--heads", default="ce")
+    args = ap.parse_args()
+    for sig in args.sig:
+        task = SpeakerTask(n_train=args.train, n_heldout=args.held, sig=sig)
+        if "s17" in args.what:
+            for head in args.heads.split(","):
+                for prec in ("fp32", "bf16"):
+                    for stream in (0, 1):
+                        r = train_and_verify(task, precision=prec, head=head, steps=args.steps, stream=stream)
+                        r.update({"sig": sig, "head": head, "model": "S/17", "steps": args.steps, "train": args.train, "held": args.held})
+                        print(json.dumps(r), flush=True)
+        if "l2" in args.what:
+            for prec in ("bf16", "fp8"):
+                for stream in (0, 1):
+                    r = train_and_verify(task, precision=prec, size="l", n_blocks=2, steps=args.steps, stream=stream)
+                    r.update({"sig": sig, "model": "L/2", "steps": args.steps, "train": args.train, "held": args.held})
+                    print(json.dumps(r), flush=True)
