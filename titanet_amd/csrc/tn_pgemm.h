@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
   };
   // DBG 16 (experiment): every workgroup walks K from its own starting step (rows of a K-major operand are a power-of-two
   // stride apart: workgroups marching through K in lockstep ask the same L2 channels for every row at the same time)
-  const int krot = (DBG & 16) ? (v * 5) % KT : 0;
+  const int krot = (DBG & 16) ? ((v / tiles_n) * 5) % KT : 0;      // (the column tiles of one row tile keep one phase: they share the A rows through L2)
   auto kmap = [&](int kt) { const int k2 = kt + krot; return k2 >= KT ? k2 - KT : k2; };
   constexpr int POLA = (DBG & 32) ? 1 : 0, POLB = (DBG & 64) ? 1 : 0;      // experiments: nt on the A / W stream
   auto dma_a = [&](int q, int kt, int stage) {
@@ -572,15 +572,22 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_kernel(GemmShape g, PGemmN
 #define RW2_R 32
 #define RW2_PITCH 1040       // bytes: 1 KB row + 16
 #define RW2_NS 4
+#define RW2_OP 80            // pitch (bytes) of a wave's private 32 x 32-channel output block
+#ifdef RW_STAMPS
+static __device__ unsigned long long rw_dbg[4];      // tuning harness: cycles in wait + barrier / MFMA loop / output, summed over waves
+#endif
+// Output without a workgroup barrier: a wave's 32 rows x 32 channels go through a PRIVATE 2.5 KB block of LDS (written in the
+// accumulator layout, read back as 16-byte row pieces: 4 lanes cover the 64 contiguous bytes of a row), so the only barrier of
+// a tile is the one that hands the ring stage over.  Two accumulators (even / odd k-steps): no MFMA waits for the one before it.
 template <bool EPI>
 __global__ __launch_bounds__(512, 2) void rwgemm_k512_v2_kernel(GemmShape g, PGemmNtArgs pa, PGemmEpiArgs ea, int tiles_n, int ntiles) {
   constexpr int STAGE_B = RW2_R * RW2_PITCH;      // 33280
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* Dt = reinterpret_cast<bf16_t*>(smem + RW2_NS * STAGE_B);      // [32][264] result rows
   float* red = reinterpret_cast<float*>(smem);                           // [16][2][256] at the end (inside the ring)
   const unsigned lds0 = (unsigned)(uintptr_t)(tn_lds_char*)smem;
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* ob = smem + RW2_NS * STAGE_B + wave * (RW2_R * RW2_OP);         // this wave's output block
   const int G = gridDim.x, v = pg_virtual_id(blockIdx.x, G);
   const int ct = v % tiles_n, first = v / tiles_n, stride = G / tiles_n;      // G is a multiple of tiles_n (launcher)
   const int col0 = ct * 256;
@@ -616,7 +623,8 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_v2_kernel(GemmShape g, PGe
       pg_dma16_buf(voff, srdA, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + row * RW2_PITCH)));
     }
   };
-  const int sv = tid & 31, sr = tid >> 5;      // store phase: 8 columns, rows sr, sr + 16
+  // output pieces of this lane: (row orow + 16 q, 16-byte piece opc of the wave's 64-byte row segment)
+  const int orow = lane >> 2, opc = lane & 3;
   float ssum[EPI ? 8 : 1], ssq[EPI ? 8 : 1];
   if constexpr (EPI) {
 #pragma unroll
@@ -633,25 +641,34 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_v2_kernel(GemmShape g, PGe
 #pragma unroll
     for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(bv[i]));
   }
+#ifdef RW_STAMPS
+  unsigned long long d_wait = 0, d_mfma = 0, d_out = 0;
+#endif
   int tile = first, it = 0, stage = 0;
 #pragma unroll 1
   for (int d = 0; d < RW2_NS - 1; ++d) dma_tile(tile + d * stride, d);
 #pragma unroll 1
   for (; tile < ntiles; tile += stride, ++it) {
+#ifdef RW_STAMPS
+    const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
     // this wave's rows of the stage have landed (queue behind them: see the header comment)
     if (it == 0) pg_wait<8>();
     else if (it == 1) pg_wait<10>();
     else if (it == 2) pg_wait<12>();
     else pg_wait<14>();
-    pg_barrier();      // (A) everybody's rows; every wave is past the store phase of the previous tile (Dt) and past its MFMAs
+    pg_barrier();      // everybody's rows have landed; every wave is past its MFMAs of the previous tile
     {
       const int ns = stage == 0 ? RW2_NS - 1 : stage - 1;      // the stage of the previous tile is free now
       dma_tile(tile + (RW2_NS - 1) * stride, ns);
     }
+#ifdef RW_STAMPS
+    const unsigned long long t1 = __builtin_readcyclecounter();
+#endif
     const char* st_ = smem + stage * STAGE_B;
-    f32x16_t acc;
+    f32x16_t acc, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
     const char* brow = st_ + (lane & 31) * RW2_PITCH + half * 16;
     constexpr int PF = 8;
     bf16x8_t bq[PF];
@@ -661,27 +678,29 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_v2_kernel(GemmShape g, PGe
     for (int ks = 0; ks < 32; ++ks) {
       const bf16x8_t b0 = bq[ks % PF];
       if (ks + PF < 32) bq[ks % PF] = *reinterpret_cast<const bf16x8_t*>(brow + (ks + PF) * 32);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b0, acc, 0, 0, 0);
+      if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b0, acc1, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b0, acc, 0, 0, 0);
     }
+#ifdef RW_STAMPS
+    const unsigned long long t2 = __builtin_readcyclecounter();
+#endif
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       uint2 w;
-      if constexpr (EPI) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[4 * gq + r] += bv[4 * gq + r];
-      }
+      for (int r = 0; r < 4; ++r) acc[4 * gq + r] += acc1[4 * gq + r] + (EPI ? bv[4 * gq + r] : 0.f);
       w.x = f2bf_pk(acc[4 * gq], acc[4 * gq + 1]);
       w.y = f2bf_pk(acc[4 * gq + 2], acc[4 * gq + 3]);
-      *reinterpret_cast<uint2*>(Dt + (lane & 31) * RW_DP + wave * 32 + 8 * gq + 4 * half) = w;
+      *reinterpret_cast<uint2*>(ob + (lane & 31) * RW2_OP + (8 * gq + 4 * half) * 2) = w;
     }
-    pg_barrier();      // (B)
+    // (the block is private to the wave: the compiler's lgkmcnt wait orders the reads below behind the writes above)
     const int r0 = tile_row0(tile);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int o = sr + 16 * q, gr = r0 + o;
+      const int o = orow + 16 * q, gr = r0 + o;
       typedef __attribute__((ext_vector_type(4))) unsigned int rw2_u32x4_t;
-      const rw2_u32x4_t u = *reinterpret_cast<const rw2_u32x4_t*>(Dt + o * RW_DP + sv * 8);
-      const unsigned voff = ((unsigned)gr * (unsigned)ea.ldy + (unsigned)(col0 + sv * 8)) * 2u;
+      const rw2_u32x4_t u = *reinterpret_cast<const rw2_u32x4_t*>(ob + o * RW2_OP + opc * 16);
+      const unsigned voff = ((unsigned)gr * (unsigned)ea.ldy + (unsigned)(col0 + wave * 32 + opc * 8)) * 2u;
       asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(u), "v"(voff), "s"(srdY) : "memory");
       if (EPI && ea.stats && gr < g.M) {
         const uint32_t uw[4] = {u[0], u[1], u[2], u[3]};
@@ -694,12 +713,23 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_v2_kernel(GemmShape g, PGe
       }
     }
     stage = stage + 1 == RW2_NS ? 0 : stage + 1;
+#ifdef RW_STAMPS
+    const unsigned long long t3 = __builtin_readcyclecounter();
+    d_wait += t1 - t0; d_mfma += t2 - t1; d_out += t3 - t2;
+#endif
   }
   pg_wait<0>();
+#ifdef RW_STAMPS
+  if (lane == 0) { atomicAdd(&rw_dbg[0], d_wait); atomicAdd(&rw_dbg[1], d_mfma); atomicAdd(&rw_dbg[2], d_out); atomicAdd(&rw_dbg[3], (unsigned long long)it); }
+#endif
   if (EPI && ea.stats) {
     __syncthreads();
+    {
+      // columns of this lane: wave * 32 + opc * 8 + i; 16 lanes of the wave (orow) hold partial sums of the same columns
+      const int sv = wave * 4 + opc, sr = orow;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { red[(sr * 2 + 0) * 256 + sv * 8 + i] = ssum[i]; red[(sr * 2 + 1) * 256 + sv * 8 + i] = ssq[i]; }
+      for (int i = 0; i < 8; ++i) { red[(sr * 2 + 0) * 256 + sv * 8 + i] = ssum[i]; red[(sr * 2 + 1) * 256 + sv * 8 + i] = ssq[i]; }
+    }
     __syncthreads();
     {
       const int which = tid >> 8, c = tid & 255;      // 512 threads: sums | sums of squares of the 256 columns
@@ -727,7 +757,7 @@ inline int launch_rwgemm_k512(const GemmShape& g, const PGemmNtArgs& pa, const P
     const int ntiles = pa.rowtiles ? pa.n_rowtiles * 8 : (g.M + RW2_R - 1) / RW2_R;
     if (ntiles <= 0) return 0;
     if (ntiles * tiles_n < 2 * max_wgs || pa.lda != RW_K) return -1000;
-    const size_t smem = (size_t)RW2_NS * RW2_R * RW2_PITCH + (size_t)RW2_R * RW_DP * sizeof(bf16_t);
+    const size_t smem = (size_t)RW2_NS * RW2_R * RW2_PITCH + (size_t)8 * RW2_R * RW2_OP;
     auto kern = (ea.bias || ea.stats) ? rwgemm_k512_v2_kernel<true> : rwgemm_k512_v2_kernel<false>;
     TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g, pa, ea, tiles_n, ntiles);

@@ -123,6 +123,18 @@ int main(int argc, char** argv) {
         float us = timeit([&](int i) { pa.A = A[i % NSET]; ea.Y = Y[i % NSET]; launch_rwgemm_k512(g, pa, ea, 0, 256, var); });
         printf("rwgemm_k512 variant %d %-28s: %8.2f us  %.3f PFLOP/s  %.2f TB/s of its own bytes\n", var, epi ? "(bias + statistics)" : "(plain)", us, flop / us / 1e9,
                ((double)M * K * 2 + (double)M * N * 2) / us / 1e6);
+#ifdef RW_STAMPS
+        if (var == 2) {
+          unsigned long long z[4] = {0, 0, 0, 0}, d[4];
+          CK(hipMemcpyToSymbol(HIP_SYMBOL(rw_dbg), z, sizeof(z)));
+          launch_rwgemm_k512(g, pa, ea, 0, 256, 2);
+          CK(hipDeviceSynchronize());
+          CK(hipMemcpyFromSymbol(d, HIP_SYMBOL(rw_dbg), sizeof(d)));
+          const double tiles = (double)d[3];      // tile iterations summed over waves
+          printf("    stamps per wave and tile (cycles of the 100 MHz counter x ...): wait + barrier %.1f, MFMA loop %.1f, output %.1f  (%.0f wave-tiles)\n",
+                 d[0] / tiles, d[1] / tiles, d[2] / tiles, tiles);
+        }
+#endif
       }
       size_t bad = 0;
       for (size_t i = 0; i < y1.size(); ++i) bad += y1[i] != y2[i];
