@@ -167,3 +167,63 @@ def test_full_depth_s17_bf16_vs_fp32_plan_at_trained_weights():
     assert len(last_blk) >= 4
     for k, v in last_blk.items():
         assert v < 0.25, (k, v)                   # (measured 0.04 - 0.12, the trained state varies run to run; a mis-scaled slab: >= 0.5)
+
+
+def test_deep_m10_fp8_plan_vs_fp32_plan_at_trained_weights():
+    """the fp8 data gradient was only checked on 2-block nets.  TitaNet-M at its full depth (10 mega blocks, hidden
+    512, 7 taps: 30 pointwise layers whose forward GEMM and data gradient run on the f8f6f4 MFMA, 10 skip connections likewise),
+    train mode, dropout 0.1, weights after 250 fp32 Adam steps: the fp8 plan and the bf16 plan against the fp32 plan (the parity
+    path) on the same batch and dropout stream.  The bf16 plan's distance is the yardstick (what reduced-precision storage costs
+    at this depth); the fp8 plan must stay within 3x of it block by block and keep a whole-gradient cosine above 0.9."""
+    from titanet_amd.trainer import Trainer
+    NB = 10
+    case = dict(cfg=dict(n_mels=80, n_mega_blocks=NB, hidden=512, enc_out=1536, emb=192, kernel=7, attn_hidden=128),
+                batch=64, frames=120, n_classes=NCLS, seed=35)
+    m32 = build(case, "ce", precision="fp32", dropout=P).train()
+    m32._seed_base, m32._step = 20240919, 0
+    tr = Trainer(m32, lr=1e-3)
+    first = None
+    for step in range(250):
+        x, y = _task(64, 120, 3000 + step % 8)
+        lv = tr.step(x.cuda(), y.cuda())[2]
+        if step == 0:
+            first = float(lv)
+    last = float(lv)
+    assert last < 0.5 * first, (first, last)
+    sd_trained = {k: v.detach().cpu().clone() for k, v in m32.state_dict().items()}
+    del tr, m32
+    torch.cuda.empty_cache()
+    B, T = 64, 256
+    x, y = _task(B, T, 6161)
+
+    def run(prec):
+        m = build(dict(case, batch=B, frames=T), "ce", precision=prec, dropout=P).train()
+        m.load_state_dict(sd_trained)
+        m._seed_base, m._step = SEED, 0
+        emb, _, lv = m(x.cuda(), speakers=y.cuda())
+        blocks = [m.debug_fetch(f"block_out:{i}", (B, 512, T)).cpu() for i in range(NB)]
+        lv.backward()
+        torch.cuda.synchronize()
+        out = (blocks, emb.detach().cpu().numpy(), float(lv), {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters()})
+        del m
+        torch.cuda.empty_cache()
+        return out
+
+    def dist(a, b):
+        errs = [float((p - q).norm() / q.norm()) for p, q in zip(a[0], b[0])]
+        ga = np.concatenate([a[3][k].ravel() for k in b[3]]); gb = np.concatenate([b[3][k].ravel() for k in b[3]])
+        cos = float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb)))
+        return errs, rel_err(a[1], b[1]), cos
+
+    ref, low, f8 = run("fp32"), run("bf16"), run("fp8")
+    b_errs, b_emb, b_cos = dist(low, ref)
+    f_errs, f_emb, f_cos = dist(f8, ref)
+    print(f"M/10 trained ({first:.3f} -> {last:.4f}): loss fp32 {ref[2]:.4f} bf16 {low[2]:.4f} fp8 {f8[2]:.4f}\n  block outputs bf16-vs-fp32", [f"{e:.4f}" for e in b_errs],
+          "\n  block outputs fp8-vs-fp32 ", [f"{e:.4f}" for e in f_errs],
+          f"\n  embeddings bf16 {b_emb:.2e} fp8 {f_emb:.2e}; whole-gradient cosine bf16 {b_cos:.5f} fp8 {f_cos:.5f}")
+    assert all(np.isfinite(v).all() for v in f8[3].values())
+    assert abs(f8[2] - ref[2]) < 5e-2 * max(1.0, abs(ref[2]))
+    for i in range(NB):
+        assert f_errs[i] < 3.0 * b_errs[i] + 3e-2, (i, f_errs[i], b_errs[i])
+    assert f_emb < 3.0 * b_emb + 2e-2, (f_emb, b_emb)
+    assert f_cos > 0.9 and 1.0 - f_cos < 4.0 * (1.0 - b_cos) + 2e-2, (f_cos, b_cos)

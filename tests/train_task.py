@@ -25,19 +25,22 @@ class SpeakerTask:
         self.z_held = torch.randn(n_heldout, LATENT, generator=g)
         self.sig = sig
 
-    def utterances(self, z, T, g):
-        """z: [B, LATENT] -> [B, N_MELS, T] float32"""
+    def utterances(self, z, T, g, device="cpu"):
+        """z: [B, LATENT] -> [B, N_MELS, T] float32 (on `device`, drawn from generator `g` of that device)"""
         B = z.shape[0]
-        tmpl = (z @ self.U.t()).unsqueeze(2)                                   # [B, 80, 1]
-        t = torch.arange(T, dtype=torch.float32).view(1, 1, T)
-        phase = torch.rand(B, 1, 1, generator=g) * 2 * math.pi
+        tmpl = (z @ self.U.t()).unsqueeze(2).to(device)                        # [B, 80, 1]
+        t = torch.arange(T, dtype=torch.float32, device=device).view(1, 1, T)
+        phase = torch.rand(B, 1, 1, generator=g, device=device) * 2 * math.pi
         mod = 1.0 + 0.5 * torch.sin(2 * math.pi * t / 50.0 + phase)           # slow amplitude modulation, random phase
-        return tmpl * mod * self.sig + torch.randn(B, N_MELS, T, generator=g) * 0.11 - 0.10
+        return tmpl * mod * self.sig + torch.randn(B, N_MELS, T, generator=g, device=device) * 0.11 - 0.10
 
-    def batch(self, step, B, T, stream=0):
-        g = torch.Generator().manual_seed(1000 + step + 1000003 * stream)
-        y = torch.randint(0, self.z_train.shape[0], (B,), generator=g)
-        return self.utterances(self.z_train[y], T, g), y
+    def batch(self, step, B, T, stream=0, device="cuda"):
+        """the training batch of `step` on data stream `stream`: drawn ON the device (a host-side randn of 1 M values per step
+        would be most of a 1200-step run's wall time); labels from a host generator"""
+        gh = torch.Generator().manual_seed(1000 + step + 1000003 * stream)
+        y = torch.randint(0, self.z_train.shape[0], (B,), generator=gh)
+        g = torch.Generator(device=device).manual_seed(1000 + step + 1000003 * stream)
+        return self.utterances(self.z_train[y], T, g, device), y
 
     def heldout(self, per_speaker=6, seed=77):
         """variable-length utterances of speakers the training never saw (list of [80, T_i]), speaker ids"""
@@ -67,7 +70,7 @@ def train_and_verify(task, precision, size="s", n_blocks=17, head="ce", steps=30
     for s in range(steps):
         x, y = task.batch(s, B, T, stream)
         y = y.cuda()
-        _, preds, l = tr.step(x.cuda(), y)
+        _, preds, l = tr.step(x, y)
         hist.append(l)
         accs.append((preds == y).float().mean())
     hist = [float(v) for v in hist]
