@@ -442,6 +442,58 @@ __device__ __forceinline__ void st_ch(bf16_t* p, const float (&v)[CH]) {
 }
 
 // ------------------------------------------------------------------------------------------
+// A chain of NK MFMAs (32x32x16 bf16) whose A fragments live in registers and whose B fragments are 16-byte LDS reads at
+// b_addr + ks * STEP_B, HAND-SCHEDULED: hipcc sinks every fragment read to just in front of its MFMA
+// (ds_read, lgkmcnt(0), MFMA: an exposed LDS round trip, ~4 MFMA slots, per 32-cycle instruction — in every GEMM phase of the
+// hidden-256 kernels, round 5), whatever the source order says.  Here the reads are inline asm, D of them in flight, and the
+// waits are counted (LDS operations of a wave retire in order).  Precondition: no LDS operation of this wave is outstanding
+// on entry (the callers come from a barrier, which hipcc precedes with lgkmcnt(0)); on exit all reads have been waited for.
+// The wait statement names the fragment as "+v" and is followed by sched_barrier(0): hipcc otherwise hoists the register-only
+// MFMA over an inline-asm wait (cdna_hip_programming.md, pitfall 18).
+// ------------------------------------------------------------------------------------------
+// General form: NK k-steps x NB row blocks of B fragments (LDS address b_addr + n * BLK_B + ks * STEP_B, read j = ks * NB + n),
+// every fragment feeding NA MFMAs (channel blocks): acc[a * NB + n] += wf[a * NK + ks] x b(ks, n).  wf / acc point at register
+// arrays (every index is a compile-time constant after inlining).
+template <int J, int NK, int NB, int NA, int D, int STEP_B, int BLK_B>
+__device__ __forceinline__ void tn_mfma_sched_step(const bf16x8_t* wf, unsigned b_addr, bf16x8_t (&bq)[D], f32x16_t* acc) {
+  constexpr int NR = NK * NB;
+  if constexpr (J < NR) {
+    constexpr int W = (NR - 1 - J) < (D - 1) ? (NR - 1 - J) : (D - 1);
+    constexpr int ks = J / NB, n = J % NB;
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bq[J % D]) : "n"(W));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) acc[a * NB + n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a * NK + ks], bq[J % D], acc[a * NB + n], 0, 0, 0);
+    if constexpr (J + D < NR) {
+      constexpr int j2 = J + D;
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[J % D]) : "v"(b_addr), "n"((j2 % NB) * BLK_B + (j2 / NB) * STEP_B));
+    }
+    tn_mfma_sched_step<J + 1, NK, NB, NA, D, STEP_B, BLK_B>(wf, b_addr, bq, acc);
+  }
+}
+template <int J, int NB, int D, int STEP_B, int BLK_B>
+__device__ __forceinline__ void tn_mfma_sched_fill(unsigned b_addr, bf16x8_t (&bq)[D]) {
+  if constexpr (J < D) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[J]) : "v"(b_addr), "n"((J % NB) * BLK_B + (J / NB) * STEP_B));
+    tn_mfma_sched_fill<J + 1, NB, D, STEP_B, BLK_B>(b_addr, bq);
+  }
+}
+template <int NK, int NB, int NA, int D, int STEP_B, int BLK_B>
+__device__ __forceinline__ void tn_mfma_sched_lds(const bf16x8_t* wf, const void* b_lds, f32x16_t* acc) {
+  static_assert(D <= NK * NB && (NB - 1) * BLK_B + (NK - 1) * STEP_B < 65536, "fragment offsets are 16-bit immediates");
+  const unsigned b_addr = (unsigned)(uintptr_t)(const tn_lds_char*)b_lds;
+  bf16x8_t bq[D];
+  tn_mfma_sched_fill<0, NB, D, STEP_B, BLK_B>(b_addr, bq);
+  tn_mfma_sched_step<0, NK, NB, NA, D, STEP_B, BLK_B>(wf, b_addr, bq, acc);
+  __builtin_amdgcn_sched_barrier(0);
+}
+// one row block, one channel block (the data-gradient phase of dgrad_dw_v6)
+template <int NK, int D, int STEP_B>
+__device__ __forceinline__ void tn_mfma_chain_lds(const bf16x8_t (&wf)[NK], const void* b_lds, f32x16_t& acc) {
+  tn_mfma_sched_lds<NK, 1, 1, D, STEP_B, 0>(&wf[0], b_lds, &acc);
+}
+
+// ------------------------------------------------------------------------------------------
 // Zero fill of a large region on the stream.  hipMemsetAsync runs the runtime's generic fill kernel (measured ~95 us per
 // call on the 50 - 100 MB gradient buffers of TitaNet-M / -L: 0.3 ms of every step); this is a plain full-chip 16-byte store
 // loop (~20 us for 100 MB).  Small or unaligned regions go to hipMemsetAsync.

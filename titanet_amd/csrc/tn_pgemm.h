@@ -599,11 +599,13 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_v2_kernel(GemmShape g, PGe
 #pragma unroll
     for (int ks = 0; ks < 32; ++ks) wf[ks] = *reinterpret_cast<const bf16x8_t*>(wr + ks * 16);
   }
-  // bias of the workgroup's 256 columns in LDS (behind the output blocks): a lane fetches its 16 values late in every tile
-  // (16 registers for the last quarter of the MFMA loop instead of 16 for the whole kernel: the EPI variant spilled)
-  float* bias_l = reinterpret_cast<float*>(smem + RW2_NS * STAGE_B + 8 * RW2_R * RW2_OP);
-  if (tid < 256) bias_l[tid] = (EPI && ea.bias) ? ea.bias[col0 + tid] : 0.f;
-  __syncthreads();
+  float bv[EPI ? 16 : 1];
+  if constexpr (EPI) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[4 * gq + r] = ea.bias ? ea.bias[col0 + wave * 32 + 8 * gq + 4 * half + r] : 0.f;
+  }
   const pg_i32x4_t srdA = pg_make_srd(pa.A, (unsigned)((size_t)g.M * pa.lda * sizeof(bf16_t)));
   const pg_i32x4_t srdY = pg_make_srd(ea.Y, (unsigned)((size_t)g.M * ea.ldy * sizeof(bf16_t)));
   // a listed 256-row tile = 8 tiles here; tiles past the end map to row M (out of the descriptor's range)
@@ -635,36 +637,13 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_v2_kernel(GemmShape g, PGe
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int ks = 0; ks < 32; ++ks) asm volatile("" : "+v"(wf[ks]));
+  if constexpr (EPI) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(bv[i]));
+  }
 #ifdef RW_STAMPS
   unsigned long long d_wait = 0, d_mfma = 0, d_out = 0;
 #endif
-  typedef __attribute__((ext_vector_type(4))) unsigned int rw2_u32x4_t;
-  typedef __attribute__((ext_vector_type(2))) unsigned int rw2_u32x2_t;
-  rw2_u32x2_t pw[4];                                   // the previous tile's results, packed
-#pragma unroll
-  for (int gq = 0; gq < 4; ++gq) { pw[gq][0] = 0u; pw[gq][1] = 0u; }
-  int prev_r0 = g.M;                                   // ... and its first row (M: none yet)
-  const unsigned ob_a = lds0 + (unsigned)(RW2_NS * STAGE_B + wave * (RW2_R * RW2_OP));
-  const unsigned obw_a = ob_a + (unsigned)((lane & 31) * RW2_OP + half * 8);      // accumulator layout: + 16 gq
-  const unsigned obr_a = ob_a + (unsigned)(orow * RW2_OP + opc * 16);             // row pieces: + 16 rows * q
-  const unsigned bias_a = lds0 + (unsigned)(RW2_NS * STAGE_B + 8 * RW2_R * RW2_OP + (wave * 32 + half * 4) * 4);      // + 32 gq bytes: columns 8 gq + 4 half ..
-  auto store_prev = [&](const rw2_u32x4_t (&u)[2]) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int gr = prev_r0 + orow + 16 * q;
-      const unsigned voff = ((unsigned)gr * (unsigned)ea.ldy + (unsigned)(col0 + wave * 32 + opc * 8)) * 2u;
-      asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(u[q]), "v"(voff), "s"(srdY) : "memory");
-      if (EPI && ea.stats && gr < g.M) {
-        const uint32_t uw[4] = {u[q][0], u[q][1], u[q][2], u[q][3]};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float y0 = __uint_as_float(uw[i] << 16), y1 = __uint_as_float(uw[i] & 0xffff0000u);
-          ssum[2 * i] += y0; ssq[2 * i] = fmaf(y0, y0, ssq[2 * i]);
-          ssum[2 * i + 1] += y1; ssq[2 * i + 1] = fmaf(y1, y1, ssq[2 * i + 1]);
-        }
-      }
-    }
-  };
   int tile = first, it = 0, stage = 0;
 #pragma unroll 1
   for (int d = 0; d < RW2_NS - 1; ++d) dma_tile(tile + d * stride, d);
@@ -686,175 +665,58 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_v2_kernel(GemmShape g, PGe
 #ifdef RW_STAMPS
     const unsigned long long t1 = __builtin_readcyclecounter();
 #endif
+    const char* st_ = smem + stage * STAGE_B;
     f32x16_t acc, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
-    // ---- the tile's 32 MFMAs, HAND-SCHEDULED (generated: tools/gen_rw2_loop.py).  Left to hipcc, every fragment read sinks to
-    // just in front of its MFMA (read, read, lgkmcnt(1), MFMA, lgkmcnt(0), MFMA: an exposed LDS round trip per pair of 32-cycle
-    // instructions, whatever the source order or sched_group_barrier says).  Here every LDS operation is inline asm and the
-    // waits are counted (LDS operations of a wave retire in order): fragment reads run 8 k-steps ahead of their MFMAs, and the
-    // output of the PREVIOUS tile (packed in pw) leaves in between — written to the wave's private block behind k-step 2, read
-    // back as row pieces behind k-step 12, stored behind k-step 23 (+ the statistics): the matrix pipe no longer idles through an
-    // output phase.  it == 0 has nothing to write: its stores go out of the descriptor's range (dropped), so that every
-    // iteration puts the same 4 + 2 operations into the vmcnt queue.
-    // (a wait statement names the register it guards as "+v" and is followed by sched_barrier(0): hipcc otherwise hoists the
-    //  register-only MFMA over an asm wait, cdna_hip_programming.md pitfall 18)
-    bf16x8_t bq[8];
-    rw2_u32x4_t uo[2];
-    const unsigned brow_a = lds0 + (unsigned)(stage * STAGE_B + (lane & 31) * RW2_PITCH + half * 16);
-#define RW2_RD(dst, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(brow_a), "n"(OFF))
-#define RW2_WR(src, OFF) asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(obw_a), "v"(src), "n"(OFF) : "memory")
-#define RW2_RDO(dst, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(obr_a), "n"(OFF) : "memory")
-#define RW2_WAIT(N, r) do { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(N)); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define RW2_WAIT2(N, r0_, r1_) do { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(r0_), "+v"(r1_) : "n"(N)); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define RW2_STORE_PREV() store_prev(uo)
-// (the bias reads are issued in the plain variant too — into registers nobody uses — so that both variants have ONE sequence
-//  of LDS operations and one set of wait counts)
-#define RW2_RDB(dst, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(bias_a), "n"(OFF))
-#define RW2_WAITB() do { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bvq[0]), "+v"(bvq[1]), "+v"(bvq[2]), "+v"(bvq[3])); __builtin_amdgcn_sched_barrier(0); } while (0)
-    f32x4_t bvq[4];
-    RW2_RD(bq[0], 0);
-    RW2_RD(bq[1], 32);
-    RW2_RD(bq[2], 64);
-    RW2_RD(bq[3], 96);
-    RW2_RD(bq[4], 128);
-    RW2_RD(bq[5], 160);
-    RW2_RD(bq[6], 192);
-    RW2_RD(bq[7], 224);
-    RW2_WAIT(7, bq[0]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], bq[0], acc, 0, 0, 0);
-    RW2_RD(bq[0], 256);
-    RW2_WAIT(7, bq[1]);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], bq[1], acc1, 0, 0, 0);
-    RW2_RD(bq[1], 288);
-    RW2_WAIT(7, bq[2]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2], bq[2], acc, 0, 0, 0);
-    RW2_RD(bq[2], 320);
-    RW2_WR(pw[0], 0);
-    RW2_WR(pw[1], 16);
-    RW2_WR(pw[2], 32);
-    RW2_WR(pw[3], 48);
-    RW2_WAIT(11, bq[3]);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[3], bq[3], acc1, 0, 0, 0);
-    RW2_RD(bq[3], 352);
-    RW2_WAIT(11, bq[4]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[4], bq[4], acc, 0, 0, 0);
-    RW2_RD(bq[4], 384);
-    RW2_WAIT(11, bq[5]);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[5], bq[5], acc1, 0, 0, 0);
-    RW2_RD(bq[5], 416);
-    RW2_WAIT(11, bq[6]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[6], bq[6], acc, 0, 0, 0);
-    RW2_RD(bq[6], 448);
-    RW2_WAIT(11, bq[7]);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[7], bq[7], acc1, 0, 0, 0);
-    RW2_RD(bq[7], 480);
-    RW2_WAIT(11, bq[0]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[8], bq[0], acc, 0, 0, 0);
-    RW2_RD(bq[0], 512);
-    RW2_WAIT(11, bq[1]);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[9], bq[1], acc1, 0, 0, 0);
-    RW2_RD(bq[1], 544);
-    RW2_WAIT(11, bq[2]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[10], bq[2], acc, 0, 0, 0);
-    RW2_RD(bq[2], 576);
-    RW2_WAIT(7, bq[3]);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[11], bq[3], acc1, 0, 0, 0);
-    RW2_RD(bq[3], 608);
-    RW2_WAIT(7, bq[4]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[12], bq[4], acc, 0, 0, 0);
-    RW2_RD(bq[4], 640);
-    RW2_RDO(uo[0], 0*RW2_OP);
-    RW2_RDO(uo[1], 16*RW2_OP);
-    RW2_WAIT(9, bq[5]);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[13], bq[5], acc1, 0, 0, 0);
-    RW2_RD(bq[5], 672);
-    RW2_WAIT(9, bq[6]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[14], bq[6], acc, 0, 0, 0);
-    RW2_RD(bq[6], 704);
-    RW2_WAIT(9, bq[7]);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[15], bq[7], acc1, 0, 0, 0);
-    RW2_RD(bq[7], 736);
-    RW2_WAIT(9, bq[0]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[16], bq[0], acc, 0, 0, 0);
-    RW2_RD(bq[0], 768);
-    RW2_WAIT(9, bq[1]);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[17], bq[1], acc1, 0, 0, 0);
-    RW2_RD(bq[1], 800);
-    RW2_WAIT(9, bq[2]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[18], bq[2], acc, 0, 0, 0);
-    RW2_RD(bq[2], 832);
-    RW2_WAIT(9, bq[3]);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[19], bq[3], acc1, 0, 0, 0);
-    RW2_RD(bq[3], 864);
-    RW2_WAIT(9, bq[4]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[20], bq[4], acc, 0, 0, 0);
-    RW2_RD(bq[4], 896);
-    RW2_WAIT(7, bq[5]);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[21], bq[5], acc1, 0, 0, 0);
-    RW2_RD(bq[5], 928);
-    RW2_WAIT(7, bq[6]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[22], bq[6], acc, 0, 0, 0);
-    RW2_RD(bq[6], 960);
-    RW2_WAIT(7, bq[7]);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[23], bq[7], acc1, 0, 0, 0);
-    RW2_RD(bq[7], 992);
-    RW2_WAIT2(11, uo[0], uo[1]);
-    RW2_STORE_PREV();
-    RW2_RDB(bvq[0], 0);
-    RW2_RDB(bvq[1], 32);
-    RW2_RDB(bvq[2], 64);
-    RW2_RDB(bvq[3], 96);
-    RW2_WAIT(11, bq[0]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[24], bq[0], acc, 0, 0, 0);
-    RW2_WAIT(10, bq[1]);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[25], bq[1], acc1, 0, 0, 0);
-    RW2_WAIT(9, bq[2]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[26], bq[2], acc, 0, 0, 0);
-    RW2_WAIT(8, bq[3]);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[27], bq[3], acc1, 0, 0, 0);
-    RW2_WAIT(7, bq[4]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[28], bq[4], acc, 0, 0, 0);
-    RW2_WAIT(6, bq[5]);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[29], bq[5], acc1, 0, 0, 0);
-    RW2_WAIT(5, bq[6]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[30], bq[6], acc, 0, 0, 0);
-    RW2_WAIT(4, bq[7]);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[31], bq[7], acc1, 0, 0, 0);
-    RW2_WAITB();      // (count 0: everything of the tile has landed)
-#undef RW2_RDB
-#undef RW2_WAITB
-#undef RW2_RD
-#undef RW2_WR
-#undef RW2_RDO
-#undef RW2_WAIT
-#undef RW2_WAIT2
-#undef RW2_STORE_PREV
+    const char* brow = st_ + (lane & 31) * RW2_PITCH + half * 16;
+    constexpr int PF = 8;
+    bf16x8_t bq[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) bq[d] = *reinterpret_cast<const bf16x8_t*>(brow + d * 32);
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+      const bf16x8_t b0 = bq[ks % PF];
+      if (ks + PF < 32) bq[ks % PF] = *reinterpret_cast<const bf16x8_t*>(brow + (ks + PF) * 32);
+      if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b0, acc1, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b0, acc, 0, 0, 0);
+    }
 #ifdef RW_STAMPS
     const unsigned long long t2 = __builtin_readcyclecounter();
 #endif
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
+      uint2 w;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[4 * gq + r] += acc1[4 * gq + r] + (EPI ? bvq[gq][r] : 0.f);
-      pw[gq][0] = f2bf_pk(acc[4 * gq], acc[4 * gq + 1]);
-      pw[gq][1] = f2bf_pk(acc[4 * gq + 2], acc[4 * gq + 3]);
+      for (int r = 0; r < 4; ++r) acc[4 * gq + r] += acc1[4 * gq + r] + (EPI ? bv[4 * gq + r] : 0.f);
+      w.x = f2bf_pk(acc[4 * gq], acc[4 * gq + 1]);
+      w.y = f2bf_pk(acc[4 * gq + 2], acc[4 * gq + 3]);
+      *reinterpret_cast<uint2*>(ob + (lane & 31) * RW2_OP + (8 * gq + 4 * half) * 2) = w;
     }
-    prev_r0 = tile_row0(tile);
+    // (the block is private to the wave: the compiler's lgkmcnt wait orders the reads below behind the writes above)
+    const int r0 = tile_row0(tile);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int o = orow + 16 * q, gr = r0 + o;
+      typedef __attribute__((ext_vector_type(4))) unsigned int rw2_u32x4_t;
+      const rw2_u32x4_t u = *reinterpret_cast<const rw2_u32x4_t*>(ob + o * RW2_OP + opc * 16);
+      const unsigned voff = ((unsigned)gr * (unsigned)ea.ldy + (unsigned)(col0 + wave * 32 + opc * 8)) * 2u;
+      asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(u), "v"(voff), "s"(srdY) : "memory");
+      if (EPI && ea.stats && gr < g.M) {
+        const uint32_t uw[4] = {u[0], u[1], u[2], u[3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float y0 = __uint_as_float(uw[i] << 16), y1 = __uint_as_float(uw[i] & 0xffff0000u);
+          ssum[2 * i] += y0; ssq[2 * i] = fmaf(y0, y0, ssq[2 * i]);
+          ssum[2 * i + 1] += y1; ssq[2 * i + 1] = fmaf(y1, y1, ssq[2 * i + 1]);
+        }
+      }
+    }
     stage = stage + 1 == RW2_NS ? 0 : stage + 1;
 #ifdef RW_STAMPS
     const unsigned long long t3 = __builtin_readcyclecounter();
     d_wait += t1 - t0; d_mfma += t2 - t1; d_out += t3 - t2;
 #endif
-  }
-  // the last tile's output (plain LDS accesses: every hand-counted operation above has been waited for)
-  {
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<rw2_u32x2_t*>(ob + (lane & 31) * RW2_OP + half * 8 + 16 * gq) = pw[gq];
-    rw2_u32x4_t ul[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) ul[q] = *reinterpret_cast<const rw2_u32x4_t*>(ob + (orow + 16 * q) * RW2_OP + opc * 16);
-    store_prev(ul);
   }
   pg_wait<0>();
 #ifdef RW_STAMPS
@@ -890,12 +752,16 @@ inline int launch_rwgemm_k512(const GemmShape& g, const PGemmNtArgs& pa, const P
   const int tiles_n = g.N / 256;
   int grid = (max_wgs / (8 * tiles_n)) * 8 * tiles_n;   // multiple of 8 (XCD-contiguous order) and of the column tiles
   if (grid <= 0) return -1000;
+  {
+    static const int forced = [] { const char* e = getenv("TN_RW_VARIANT"); return e ? atoi(e) : 0; }();      // (debug switch)
+    if (forced) variant = forced;
+  }
   if (variant == 2) {
     // LDS-DMA ring of 32-row stages (rwgemm_k512_v2_kernel); the DMA moves whole 1 KB rows: lda == 512 only
     const int ntiles = pa.rowtiles ? pa.n_rowtiles * 8 : (g.M + RW2_R - 1) / RW2_R;
     if (ntiles <= 0) return 0;
     if (ntiles * tiles_n < 2 * max_wgs || pa.lda != RW_K) return -1000;
-    const size_t smem = (size_t)RW2_NS * RW2_R * RW2_PITCH + (size_t)8 * RW2_R * RW2_OP + 256 * sizeof(float);
+    const size_t smem = (size_t)RW2_NS * RW2_R * RW2_PITCH + (size_t)8 * RW2_R * RW2_OP;
     auto kern = (ea.bias || ea.stats) ? rwgemm_k512_v2_kernel<true> : rwgemm_k512_v2_kernel<false>;
     TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g, pa, ea, tiles_n, ntiles);
@@ -969,7 +835,8 @@ inline int launch_pgemm_nt(const GemmShape& g, const PGemmNtArgs& pa, const PGem
   // K-major operand are 2 KB apart, and 256 workgroups marching through K in lockstep ask for the same 64-byte column of every
   // row at the same time — 210 -> 194 us at 76800 x 1024 x 1024, the operand stream alone 133 -> 128, profiles/r05_pgemm_harness_1024_b.txt;
   // at K = 512 the rotation loses, 52 -> 70 us).  Changes the summation order over K, not the arithmetic.
-  if (g.K >= 1024) return launch_pgemm_nt_t<16>(g, pa, ea, st, max_wgs);
+  static const bool krot_off = [] { const char* e = getenv("TN_KROT"); return e && atoi(e) == 0; }();      // (debug switch)
+  if (g.K >= 1024 && !krot_off) return launch_pgemm_nt_t<16>(g, pa, ea, st, max_wgs);
   return launch_pgemm_nt_t<0>(g, pa, ea, st, max_wgs);
 }
 // e4m3 x e4m3 (pa.A and g.W are byte matrices, pa.lda in bytes = elements)

@@ -1524,7 +1524,10 @@ struct DgradDwArgs {
 // add to a tile — 16 more MFMAs per wave (the 256 x 256 x 32-row product d W += dS^T Q of the tile, split over 8 waves) fed by
 // transposing LDS fragment reads of the tile's rows, on two alternating accumulators (the real thing needs 128 accumulator
 // registers per lane, which this kernel does not have: a LOWER bound of the in-kernel cost)
-template <int FL, bool MK = false, bool Z3 = false, bool P2 = false, int WGX = 0>
+// MD (tuning harness only): fragment reads in flight in a HAND-SCHEDULED MFMA phase (tn_common.h: tn_mfma_chain_lds) instead of the
+// compiler's read-wait-MFMA: bit-identical, 38.3 -> 36.5 - 37.7 us in the harness, nothing in the step (the other wave of the SIMD
+// already covers the exposed LDS round trips): profiles/r05_dgrad_dw_md.txt.  0 = the compiler's own schedule
+template <int FL, bool MK = false, bool Z3 = false, bool P2 = false, int WGX = 0, int MD = 0>
 __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
   constexpr int KD = 3, NT = V2_NT;
   constexpr bool HAS_MASK = (FL & 7) != 0, HAS_ADD = (FL & 8) != 0;
@@ -1661,8 +1664,12 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const bf16_t* brow = Pt + (lane & 31) * V2_AP + half * 8;
+      if constexpr (MD > 0) {
+        tn_mfma_chain_lds<16, MD, 32>(wf, brow, acc);
+      } else {
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], *reinterpret_cast<const bf16x8_t*>(brow + ks * 16), acc, 0, 0, 0);
+        for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], *reinterpret_cast<const bf16x8_t*>(brow + ks * 16), acc, 0, 0, 0);
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         uint2 w;

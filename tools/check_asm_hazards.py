@@ -31,12 +31,14 @@ def check_asm(text):
     findings = []
     func = None
     pending = {}          # register -> line of the asm load filling it
+    lds_ops = []          # inline-asm LDS operations in program order: set of destination registers (empty for writes), or
+                          # None once retired — they retire IN ORDER, so an asm `s_waitcnt lgkmcnt(N)` retires all but the last N
     in_asm = False
     for n, line in enumerate(text.split("\n"), 1):
         s = line.strip()
         m = re.match(r"^(_Z\w+):", line)
         if m:
-            func, pending = m.group(1), {}
+            func, pending, lds_ops = m.group(1), {}, []
             continue
         if s.startswith(";;#ASMSTART"):
             in_asm = True
@@ -54,10 +56,32 @@ def check_asm(text):
             if m and "lds" not in code:
                 for r in regs_of(m.group(1)):
                     pending[r] = n
+            # hand-counted LDS pipelines (tn_mfma_sched_lds, rwgemm_k512_v2_kernel)
+            m = re.match(r"s_waitcnt\s+lgkmcnt\((\d+)\)", code)
+            if m:
+                keep = int(m.group(1))
+                live = [i for i, o in enumerate(lds_ops) if o is not None]
+                for i in (live[:-keep] if keep else live):
+                    lds_ops[i] = None
+            m = re.match(r"ds_read\w*\s+(v\d+|v\[\d+:\d+\])\s*,", code)
+            if m:
+                lds_ops.append((regs_of(m.group(1)), n))
+            elif re.match(r"ds_write", code):
+                lds_ops.append((set(), n))
             continue
         if code.startswith("s_endpgm"):
-            pending = {}
+            pending, lds_ops = {}, []
             continue
+        if any(o is not None and o[0] for o in lds_ops):
+            if re.match(r"s_waitcnt\s+.*lgkmcnt\(0\)", code):
+                lds_ops = []
+            else:
+                ops = code.split(None, 1)
+                used = regs_of(ops[1]) if len(ops) > 1 else set()
+                inflight = set().union(*[o[0] for o in lds_ops if o is not None])
+                hit = used & inflight
+                if hit:
+                    findings.append((func, n, code + "   [in-flight inline-asm ds_read]", sorted(hit)))
         if pending:
             if re.match(r"s_waitcnt\s+vmcnt\(0\)", code):
                 pending = {}
@@ -71,6 +95,12 @@ def check_asm(text):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1].endswith(".s"):      # an ISA listing made elsewhere (tuning harnesses)
+        f = check_asm(open(sys.argv[1]).read())
+        print(f"{sys.argv[1]}: {len(f)} reads of in-flight asm-load registers")
+        for func, n, code, regs in f[:40]:
+            print(f"   {func[:60]} line {n}: {code}   (v{regs})")
+        sys.exit(1 if f else 0)
     srcs = [os.path.basename(a) for a in sys.argv[1:]] or SOURCES
     from concurrent.futures import ThreadPoolExecutor
 

@@ -49,22 +49,35 @@ int main(int argc, char** argv) {
     const size_t red = (size_t)8 * 6 * V2_C * sizeof(float);
     const size_t smem = (tiles > red ? tiles : red) + (size_t)10 * V2_C * sizeof(float);
     a.ntiles = (a.M + V6_OUT - 1) / V6_OUT;
-    auto k0 = dgrad_dw_v6_kernel<7, false, false, false, 0>;
-    auto k1 = dgrad_dw_v6_kernel<7, false, false, false, 1>;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    typedef void (*kern_t)(DgradDwArgs);
+    kern_t ks_[5] = {dgrad_dw_v6_kernel<7, false, false, false, 0, 0>, dgrad_dw_v6_kernel<7, false, false, false, 0, 4>,
+                     dgrad_dw_v6_kernel<7, false, false, false, 0, 3>, dgrad_dw_v6_kernel<7, false, false, false, 0, 6>,
+                     dgrad_dw_v6_kernel<7, false, false, false, 1, 0>};
+    const char* names[5] = {"compiler-scheduled MFMA phase", "hand-scheduled, 4 fragment reads in flight", "hand-scheduled, 3 in flight",
+                            "hand-scheduled, 6 in flight", "+ 16 weight-gradient MFMAs per wave and tile (WGX probe)"};
+    for (auto k : ks_) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     for (int rep = 0; rep < 3; ++rep)
-      for (int which = 0; which < 2; ++which) {
+      for (int which = 0; which < 5; ++which) {
         auto go = [&](int it) { const int s = it % NSET; a.dZ = dZ[s]; a.Y = Y[s]; a.X = X[s]; a.OUT = OUT[s];
-                                hipLaunchKernelGGL(which ? k1 : k0, dim3(256), dim3(V2_NT), smem, 0, a); };
+                                hipLaunchKernelGGL(ks_[which], dim3(256), dim3(V2_NT), smem, 0, a); };
         for (int it = 0; it < 4; ++it) go(it);
         CK(hipDeviceSynchronize());
         hipEventRecord(e0, 0);
         for (int it = 0; it < 51; ++it) go(it);
         hipEventRecord(e1, 0); CK(hipEventSynchronize(e1));
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("dgrad_dw_v6<7> %s: %.2f us per launch\n", which ? "+ 16 weight-gradient MFMAs per wave and tile (WGX probe)" : "plain", ms * 1e3f / 51);
+        printf("dgrad_dw_v6<7> %s: %.2f us per launch\n", names[which], ms * 1e3f / 51);
       }
+    // same inputs, compiler-scheduled vs hand-scheduled: bitwise (same MFMA order)
+    {
+      std::vector<unsigned short> o0((size_t)M * C), o1((size_t)M * C);
+      a.dZ = dZ[0]; a.Y = Y[0]; a.X = X[0]; a.OUT = OUT[2]; hipLaunchKernelGGL(ks_[0], dim3(256), dim3(V2_NT), smem, 0, a);
+      a.OUT = OUT[3]; hipLaunchKernelGGL(ks_[1], dim3(256), dim3(V2_NT), smem, 0, a);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(o0.data(), OUT[2], o0.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(o1.data(), OUT[3], o1.size() * 2, hipMemcpyDeviceToHost));
+      size_t diff = 0; for (size_t i = 0; i < o0.size(); ++i) diff += o0[i] != o1[i];
+      printf("hand-scheduled vs compiler-scheduled MFMA phase on the same inputs: %zu of %zu elements differ\n", diff, o0.size());
+    }
   }
   // checksum of the two outputs on the same inputs
   a.dZ = dZ[0]; a.Y = Y[0]; a.X = X[0]; a.OUT = OUT[0]; launch_dgrad_dw_v6(a, 256, 0, false);

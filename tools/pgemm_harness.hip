@@ -136,9 +136,16 @@ int main(int argc, char** argv) {
         }
 #endif
       }
-      size_t bad = 0;
-      for (size_t i = 0; i < y1.size(); ++i) bad += y1[i] != y2[i];
-      printf("  variant 2 vs variant 1: %zu of %zu output elements differ\n", bad, y1.size());
+      size_t bad = 0; double maxd = 0, maxv = 0; size_t big = 0;
+      for (size_t i = 0; i < y1.size(); ++i) {
+        bad += y1[i] != y2[i];
+        uint32_t a = (uint32_t)y1[i] << 16, b = (uint32_t)y2[i] << 16; float fa, fb; memcpy(&fa, &a, 4); memcpy(&fb, &b, 4);
+        const double d = fabs((double)fa - fb);
+        if (d > maxd) maxd = d;
+        if (fabs(fa) > maxv) maxv = fabs(fa);
+        big += d > 0.02 * (fabs(fa) + 1.0);
+      }
+      printf("  variant 2 vs variant 1: %zu of %zu output elements differ, max abs diff %.4g (max |y| %.3g), %zu beyond 2 %%\n", bad, y1.size(), maxd, maxv, big);
     }
   }
   for (int wgs : {256, 240}) {
