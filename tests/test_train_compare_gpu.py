@@ -12,7 +12,7 @@ Bounds: loss within 10 % relative, accuracy within 2 points, EER wi
 1.5 x the spread between the two streams of ONE precision when that yardstick is larger (two fp32 runs on different noise
 end 12 % apart in loss and 2.3 points apart in accuracy after 1200 steps, profiles/r05_train_compare_sweep2.txt: a bound
 tighter than the experiment's own repeatability would test the noise, not the precision).
-The same for the fp8 plan against the bf16 plan at TitaNet-L width (2 mega blocks).
+The same for the fp8 plan against the bf16 plan at TitaNet-L width (2 mega blocks) and for TitaNet-M at its full depth (10).
 """
 import json
 import os
@@ -70,9 +70,12 @@ def test_bf16_trains_like_fp32_at_full_depth():
     _compare(a, b, f"TitaNet-S/17 ce: fp32 vs bf16, {STEPS} steps, 2 data streams each")
 
 
-def test_fp8_trains_like_bf16_at_l_width():
+@pytest.mark.parametrize("size,n_blocks", [("l", 2), ("m", 10)])
+def test_fp8_trains_like_bf16(size, n_blocks):
+    """L width, 2 blocks (the review's case) and TitaNet-M at its full depth of 10 blocks (the fp8 data gradient at
+    depth; a single forward of that plan sits 17 % from the fp32 plan at block 10, tests/test_trained_parity_gpu.py)."""
     task = SpeakerTask(n_train=128, n_heldout=32, sig=0.012)
-    kw = dict(size="l", n_blocks=2, head="ce", steps=STEPS, tail=TAIL)
+    kw = dict(size=size, n_blocks=n_blocks, head="ce", steps=STEPS, tail=TAIL)
     a = [train_and_verify(task, "bf16", stream=s, **kw) for s in (0, 1)]
     b = [train_and_verify(task, "fp8", stream=s, **kw) for s in (0, 1)]
-    _compare(a, b, f"TitaNet-L/2 ce: bf16 vs fp8, {STEPS} steps, 2 data streams each")
+    _compare(a, b, f"TitaNet-{size.upper()}/{n_blocks} ce: bf16 vs fp8, {STEPS} steps, 2 data streams each")

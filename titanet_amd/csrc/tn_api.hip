@@ -852,6 +852,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
             memset(&fa, 0, sizeof(fa));
             fa.X = (const bf16_t*)cur; fa.act = acur; fa.wdw = params + sb.wdw; fa.bdw = params + sb.bdw;
             fa.Q = (bf16_t*)(ws + bw.Q[j]); fa.Q8 = q8; fa.M = M; fa.T = T; fa.C = H;
+            if (p->masked && p->skip_pad_tiles && p->n_rowtiles > 0) { fa.rowtiles = (const int*)(ws + p->rowtiles); fa.n_rowtiles = p->n_rowtiles; }
             rc = launch_dw_fwd_slab(fa, c.kernel, st);
             if (rc > 0) return rc;
             q_clean = rc == 0;
@@ -934,9 +935,12 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       if (rc2 == -1000) {
         const int rpb = 64;
         auto kcomb = acur.rm.len ? combine_fwd_kernel<AT, true> : combine_fwd_kernel<AT, false>;
-        hipLaunchKernelGGL(kcomb, dim3((M + rpb - 1) / rpb), dim3(256), (size_t)4 * H * sizeof(float), st,
+        // (variable-length batches on plans whose kernels tolerate stale rows in padding-only tiles: only the listed tiles)
+        const bool listed = p->masked && p->skip_pad_tiles && p->n_rowtiles > 0 && acur.rm.len;
+        hipLaunchKernelGGL(kcomb, dim3(listed ? p->n_rowtiles * (256 / rpb) : (M + rpb - 1) / rpb), dim3(256), (size_t)4 * H * sizeof(float), st,
                            (const AT*)(ws + bw.S), acts, (const AT*)cur, acur, (const float*)(ws + bw.g), (AT*)(ws + bw.OUT), M,
-                           T, H, rpb, thr, key, ik, (const uint32_t*)(ws + p->step_state) + 2);
+                           T, H, rpb, thr, key, ik, (const uint32_t*)(ws + p->step_state) + 2,
+                           listed ? (const int*)(ws + p->rowtiles) : (const int*)nullptr);
       }
     }
     xin = ws + bw.OUT;

@@ -115,12 +115,12 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     // f8rows (fp8 plans, hidden x hidden layers): the pass also writes dS as e4m3 rows + row exponents, the data gradient below
     // reads those
     const bool f8 = f8rows.q != nullptr;
-    if (!ds_ready) rc = launch_bn_bwd_apply((bf16_t*)(ws + dz), (const bf16_t*)(ws + y), make_bnbwd(p, bn, M, training), M, Cout, st,
-                                            p->fp8_bwd_emu && Cout == H, f8rows);
-    if (rc) return rc;
-    DBG("pipe dS", dz, (size_t)M * Cout);
     const bool listed = p->masked && p->n_rowtiles > 0;
     const int* rowtiles = listed ? (const int*)(ws + p->rowtiles) : nullptr;
+    if (!ds_ready) rc = launch_bn_bwd_apply((bf16_t*)(ws + dz), (const bf16_t*)(ws + y), make_bnbwd(p, bn, M, training), M, Cout, st,
+                                            p->fp8_bwd_emu && Cout == H, f8rows, rowtiles, listed ? p->n_rowtiles : 0);
+    if (rc) return rc;
+    DBG("pipe dS", dz, (size_t)M * Cout);
     if (f8) {
       // dX = (dS8 2^e) * (W^T8 s[ci]): e4m3 x e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4, row exponents as its A block scale,
       // the weight scales in the epilogue
@@ -659,6 +659,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         sa.dD = (const bf16_t*)da.dD; sa.X = (const bf16_t*)da.XRAW; sa.actX = da.actX; sa.ADD = (const bf16_t*)da.ADD;
         sa.OUT = (bf16_t*)da.OUT; sa.wdw = da.wdw; sa.g_wdw = da.g_wdw; sa.g_bdw = da.g_bdw; sa.bsumsX = da.bsumsX;
         sa.M = M; sa.T = T; sa.C = H;
+        if (p->masked && p->skip_pad_tiles && p->n_rowtiles > 0) { sa.rowtiles = (const int*)(ws + p->rowtiles); sa.n_rowtiles = p->n_rowtiles; }
         ProfScope ps(p, TN_PROF_BWD_DW, st);
         rc = c.kernel == 7 ? launch_dw_bwd_slab<7>(sa, 256, st) : launch_dw_bwd_slab<11>(sa, 256, st);
         if (rc > 0) return rc;

@@ -1297,23 +1297,30 @@ __global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const float* __restr
 // MODE 2 (fp8 plans, hidden 512 / 1024): dS additionally as e4m3 bytes with one power-of-two scale per row + the E8M0 exponent
 // bytes (Fp8Rows, tn_common.h) — the operand of the data gradient on the f8f6f4 MFMA; the bf16 dS stays for the weight gradient
 // (a contraction over rows: per-row scales do not factor out of it).
+// rowtiles (variable-length batches): the 256-row tiles with valid frames (PGemmNtArgs::rowtiles) — the pass then walks only
+// those; null = all M rows.
 template <int MODE>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ dZ, const bf16_t* __restrict__ Y, BnBwd bn, int M, int C, Fp8Rows f8) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ dZ, const bf16_t* __restrict__ Y, BnBwd bn, int M, int C, Fp8Rows f8,
+                                                           const int* __restrict__ rowtiles, int n_rowtiles) {
   constexpr bool EMU8 = MODE == 1, OUT8 = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) float pg_k[];      // k0, k1, k2 : [3][C]
   __shared__ float wmax[4];
   for (int c = threadIdx.x; c < C; c += 256) bn_bwd_coefs(bn, C, c, pg_k[c], pg_k[C + c], pg_k[2 * C + c]);
   __syncthreads();
   const int VC = C / 8;
-  const size_t nvec = (size_t)M * VC;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
-    const int c0 = (int)(i % VC) * 8;
+  const size_t nvec = (size_t)(rowtiles ? n_rowtiles * 256 : M) * VC;
+  for (size_t iv = (size_t)blockIdx.x * 256 + threadIdx.x; iv < nvec; iv += (size_t)gridDim.x * 256) {
+    const int c0 = (int)(iv % VC) * 8;
+    const uint32_t vr = (uint32_t)(iv / VC);
+    const uint32_t row = rowtiles ? (uint32_t)rowtiles[vr >> 8] * 256u + (vr & 255u) : vr;
+    const bool oob = row >= (uint32_t)M;                 // the last listed tile may reach past the tensor
+    const size_t i = (size_t)row * VC + (size_t)(iv % VC);      // vector index in the tensor
     float z[8], y[8];
-    const bool padrow = bn.rm.len && !tn_row_valid(bn.rm, (uint32_t)(i / VC));     // padding rows carry no gradient (uniform per row)
+    const bool padrow = oob || (bn.rm.len && !tn_row_valid(bn.rm, row));     // padding rows carry no gradient (uniform per row)
     if (MODE == 0 && padrow) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) z[u] = 0.f;
-      store8(dZ + i * 8, z);
+      if (!oob) store8(dZ + i * 8, z);
       continue;
     }
     if (!padrow) {
@@ -1326,7 +1333,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ 
       for (int u = 0; u < 8; ++u) z[u] = 0.f;
     }
     if (EMU8 || OUT8) {
-      // (every thread of the workgroup is in this iteration: M * VC is a multiple of 256, launch_bn_bwd_apply)
+      // (every thread of the workgroup is in this iteration: the row count x VC is a multiple of 256, launch_bn_bwd_apply)
       float m = 0.f;
 #pragma unroll
       for (int u = 0; u < 8; ++u) m = fmaxf(m, fabsf(z[u]));
@@ -1340,24 +1347,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ 
       }
       const float sc = tn_e4m3_row_scale(m);
       if (EMU8) tn_e4m3_roundtrip8(z, sc, 1.f / sc);
-      if (OUT8) {
+      if (OUT8 && !oob) {
         *reinterpret_cast<uint2*>(f8.q + i * 8) = tn_e4m3_pack8(z, 1.f / sc);
-        if (c0 == 0) f8.rowexp[tn_rowexp_pos(i / VC)] = tn_e8m0_of_pow2(sc);
+        if (c0 == 0) f8.rowexp[tn_rowexp_pos(row)] = tn_e8m0_of_pow2(sc);
       }
     }
-    store8(dZ + i * 8, z);
+    if (!oob) store8(dZ + i * 8, z);
   }
 }
 // emu8: the e4m3 round trip in place (experiment);  f8: also write the fp8 operand (q != null)
-inline int launch_bn_bwd_apply(bf16_t* dZ, const bf16_t* Y, const BnBwd& bn, int M, int C, hipStream_t st, bool emu8 = false, Fp8Rows f8 = Fp8Rows{nullptr, nullptr}) {
+inline int launch_bn_bwd_apply(bf16_t* dZ, const bf16_t* Y, const BnBwd& bn, int M, int C, hipStream_t st, bool emu8 = false, Fp8Rows f8 = Fp8Rows{nullptr, nullptr},
+                               const int* rowtiles = nullptr, int n_rowtiles = 0) {
   if (C % 8 || C > 4096) return TN_E_UNSUPPORTED;
+  if (!bn.rm.len || n_rowtiles <= 0) { rowtiles = nullptr; n_rowtiles = 0; }
   const bool rows_ok = (C == 512 || C == 1024) && ((size_t)M * (C / 8)) % 256 == 0;
   if (f8.q && !rows_ok) return TN_E_UNSUPPORTED;
   if (f8.q)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C, f8);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C, f8, rowtiles, n_rowtiles);
   else if (emu8 && !bn.rm.len && rows_ok)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C, f8);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C, f8, rowtiles, n_rowtiles);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C, f8);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C, f8, rowtiles, n_rowtiles);
   return (int)hipGetLastError();
 }

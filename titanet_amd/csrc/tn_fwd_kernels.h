@@ -197,6 +197,10 @@ struct DwFwdSlabArgs {
   bf16_t* Q;           // [M][C]
   uint8_t* Q8;         // [M][C] e4m3 copy for the fp8 pointwise GEMM (TN_PREC_FP8; needs 4 channels per lane) or null
   int M, T, C, ntiles;
+  // variable-length batches: the 256-row tiles that hold at least one valid frame (PGemmNtArgs::rowtiles) or null = all rows.
+  // A padding-only tile is not walked at all: its rows keep what they held, which nobody reads (the pipelined GEMMs skip the
+  // same tiles, every other consumer masks padding rows on load)
+  const int* rowtiles; int n_rowtiles;
 };
 // MK: variable-length batch (a.act.rm.len), a compile-time flag: the fixed-length instantiation carries none of it
 template <int KD, int FL, int CH, bool MK = false>
@@ -222,8 +226,10 @@ __global__ __launch_bounds__(512, 2) void dw_fwd_slab_kernel(DwFwdSlabArgs a) {
     for (int k = 0; k < KD; ++k) cst[(3 + k) * 256 + tid] = a.wdw[(size_t)(cb + tid) * KD + k];
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // compiler-visible loads done before the first DMA
+  // first output row of a 64-row tile (a listed 256-row tile = 4 of them)
+  auto tile_row0 = [&](int tile) -> int { return (MK && a.rowtiles) ? tn_sload_i32(a.rowtiles, tile >> 2) * 256 + (tile & 3) * 64 : tile * 64; };
   auto dma_tile = [&](int tile, int buf) {
-    const int raw0 = tile * 64 - PADR;
+    const int raw0 = tile_row0(tile) - PADR;
 #pragma unroll
     for (int i = 0; i < (ROWS / 2 + 7) / 8; ++i) {
       const int r = 2 * (wave + 8 * i);
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void dw_fwd_slab_kernel(DwFwdSlabArgs a) {
     __builtin_amdgcn_s_barrier();
     if (tile + stride < a.ntiles) dma_tile(tile + stride, buf ^ 1);
     const bf16_t* Xs = reinterpret_cast<const bf16_t*>(smem + buf * TILE_B);
-    const int out0 = tile * 64, raw0 = out0 - PADR;
+    const int out0 = tile_row0(tile), raw0 = out0 - PADR;
     const int l0 = strip * RS;
     const int g_first = raw0 + l0, g_last = g_first + KD + RS - 2;
     // variable-length batches (a.act.rm.len): frames >= len[b] are padding — they read as zeros and are WRITTEN as zeros (the
@@ -343,7 +349,9 @@ inline int launch_dw_fwd_slab_t(DwFwdSlabArgs a, int grid, hipStream_t st) {
 // -1000: no specialisation (caller runs dw_fwd_kernel)
 inline int launch_dw_fwd_slab(DwFwdSlabArgs a, int KD, hipStream_t st) {
   if (a.C % 256 != 0) return -1000;
-  a.ntiles = (a.M + 63) / 64;
+  if (!a.act.rm.len) { a.rowtiles = nullptr; a.n_rowtiles = 0; }
+  a.ntiles = a.rowtiles ? a.n_rowtiles * 4 : (a.M + 63) / 64;
+  if (a.ntiles <= 0) return 0;
   const int nslab = a.C / 256;
   int per = 256 / nslab;
   if (per < 1) per = 1;
@@ -513,7 +521,10 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(const AT* __restrict__
                                                           const AT* __restrict__ Y3, BnAct act3,
                                                           const float* __restrict__ gate, AT* __restrict__ OUT, int M,
                                                           int T, int C, int rows_per_block, uint32_t drop_thr,
-                                                          uint32_t drop_key, float inv_keep, const uint32_t* key_add) {
+                                                          uint32_t drop_key, float inv_keep, const uint32_t* key_add,
+                                                          const int* __restrict__ rowtiles = nullptr) {
+  // rowtiles (variable-length batches, rows_per_block divides 256): the 256-row tiles with valid frames; the grid covers only
+  // those (padding-only tiles keep what they held: nobody reads them, tn_pgemm.h PGemmNtArgs::rowtiles)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* scS = reinterpret_cast<float*>(smem);
   float* shS = scS + C;
@@ -527,7 +538,11 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(const AT* __restrict__
   }
   __syncthreads();
   const int CV = C / 8;
-  const int r_begin = blockIdx.x * rows_per_block;
+  int r_begin = blockIdx.x * rows_per_block;
+  if (MK && rowtiles) {
+    const int per = 256 / rows_per_block;
+    r_begin = rowtiles[blockIdx.x / per] * 256 + (blockIdx.x % per) * rows_per_block;
+  }
   const int r_end = min(M, r_begin + rows_per_block);
   const uint32_t okey = key_add ? drop_key + *key_add : drop_key;
   if (NT % CV == 0) {
@@ -540,6 +555,12 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(const AT* __restrict__
     for (int row = r_begin + tid / CV; row < r_end; row += rstep) {
       const int b = row / T;
       float s[8], y[8], g[8], o[8];
+      if (MK && !tn_row_valid(act3.rm, (uint32_t)row)) {      // padding rows are stored as zeros, nothing is read for them
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = 0.f;
+        store8(OUT + (size_t)row * C + c0, o);
+        continue;
+      }
       load8(S + (size_t)row * C + c0, s);
       load8(Y3 + (size_t)row * C + c0, y);
       load8(gate + (size_t)b * C + c0, g);

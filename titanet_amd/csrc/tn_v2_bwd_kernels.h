@@ -1081,6 +1081,7 @@ struct DwBwdSlabArgs {
   float* g_bdw;        // [C]
   float* bsumsX;       // [TN_NREP][2][C] or null
   int M, T, C, ntiles;
+  const int* rowtiles; int n_rowtiles;      // as DwFwdSlabArgs: the 256-row tiles with valid frames (variable-length batches) or null
 };
 // CH = channels per lane: 4 (one wave per strip of 8 output rows; K = 7: 82 -> 73 us per TitaNet-M layer, one dropout hash per 2 lanes
 // instead of 4) or 2 (two waves per strip of 16 rows: half the window /
@@ -1121,8 +1122,9 @@ __global__ __launch_bounds__(512, 2) void dw_bwd_slab_kernel(DwBwdSlabArgs a) {
   // (a wave issues NPIECE or NPIECE - 1 pieces; the wait for the addend rows counts NPIECE - 1 of them, see tn_wait_add)
   constexpr int NPIECE = (ROWS / 2 + 7) / 8, MINPIECE = (ROWS / 2) / 8;
   static_assert(MINPIECE == NPIECE - 1 || MINPIECE == NPIECE, "pieces per wave");
+  auto tile_row0 = [&](int tile) -> int { return (MK && a.rowtiles) ? tn_sload_i32(a.rowtiles, tile >> 2) * 256 + (tile & 3) * 64 : tile * 64; };
   auto dma_tile = [&](int tile, int buf) {
-    const int raw0 = tile * 64 - PADR;
+    const int raw0 = tile_row0(tile) - PADR;
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
       const int r = 2 * (wave + 8 * i);
@@ -1156,7 +1158,7 @@ __global__ __launch_bounds__(512, 2) void dw_bwd_slab_kernel(DwBwdSlabArgs a) {
   for (int tile = first; tile < a.ntiles; tile += stride, buf ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this tile's DMA (and the previous tile's stores)
     __builtin_amdgcn_s_barrier();                              // every wave's part landed; the other buffer is free again
-    const int out0 = tile * 64, raw0 = out0 - PADR;
+    const int out0 = tile_row0(tile), raw0 = out0 - PADR;
     const int l0 = strip * RS;                                 // LDS row of the strip's first window row
     // skip-path addend rows of the strip.  A load hipcc counts would be waited for with vmcnt(its later loads), and the
     // DMA instructions issued below — which hipcc does not see — would then have to retire first (in-order counter): the
@@ -1332,7 +1334,9 @@ inline int launch_dw_bwd_slab_t(DwBwdSlabArgs a, int grid, hipStream_t st) {
 template <int KD>
 inline int launch_dw_bwd_slab(DwBwdSlabArgs a, int max_wgs, hipStream_t st) {
   if (a.C % V2_C != 0) return -1000;
-  a.ntiles = (a.M + 63) / 64;
+  if (!a.actX.rm.len) { a.rowtiles = nullptr; a.n_rowtiles = 0; }
+  a.ntiles = a.rowtiles ? a.n_rowtiles * 4 : (a.M + 63) / 64;
+  if (a.ntiles <= 0) return 0;
   const int nslab = a.C / V2_C;
   int per = max_wgs / nslab;
   if (per < 1) per = 1;
