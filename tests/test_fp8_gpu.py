@@ -102,3 +102,47 @@ def test_fp8_data_gradient_vs_bf16_data_gradient(hidden, kernel, masked, monkeyp
     print(f"H={hidden} masked={masked}: fp8 vs bf16 data gradient: cosine {cos:.5f}, worst large tensors {worst}")
     assert cos > 0.998 and worst[0][1] < 8e-2
     assert not np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("hidden,kernel,masked", [(1024, 11, False), (512, 7, False), (512, 7, True)])
+def test_fp8_weight_gradient_vs_bf16_weight_gradient(hidden, kernel, masked, monkeypatch):
+    """Round 5: the sub-block pointwise WEIGHT gradients of an fp8 plan run on the f8f6f4 MFMA too (tn_pgemm.h:
+    pgemm_tn_f8_batched_kernel): e4m3 dS scaled per column by the previous backward's column maxima (delayed scaling; the
+    scale is the MFMA's own block-scale operand), the kept e4m3 depthwise outputs, byte-transposing LDS reads.  A plan's FIRST
+    backward has no maxima yet and runs the bf16 contraction, so the same step is run twice on one plan (same weights, batch and
+    dropout stream) and the SECOND gradient is compared with the same plan under TN_FP8_WGRAD=0 (bf16 weight gradients, read
+    at plan creation): whole-gradient cosine > 0.998, every large tensor within 8e-2 — and the pointwise weight gradients are
+    not identical, i.e. the fp8 contraction did run."""
+    case = _case(hidden, kernel, blocks=2, batch=16, frames=128)
+    x, y = case_inputs(case, torch.float32)
+    lengths = None
+    if masked:
+        g = torch.Generator().manual_seed(5)
+        lengths = torch.randint(20, 129, (16,), generator=g)
+        lengths[3] = 128
+    grads = {}
+    for tag, env in (("fp8", None), ("bf16", "0")):
+        if env is None:
+            monkeypatch.delenv("TN_FP8_WGRAD", raising=False)
+        else:
+            monkeypatch.setenv("TN_FP8_WGRAD", env)
+        m = build(case, "ce", precision="fp8").train()
+        for rep in range(2):
+            m.zero_grad(set_to_none=False)
+            m._seed_base, m._step = 11, 0
+            emb, preds, lv = m(x.cuda(), speakers=y.cuda(), lengths=lengths)
+            lv.backward()
+        torch.cuda.synchronize()
+        grads[tag] = {k: p.grad.detach().float().cpu().numpy().copy() for k, p in m.named_parameters()}
+        assert all(np.isfinite(v).all() for v in grads[tag].values())
+    monkeypatch.delenv("TN_FP8_WGRAD", raising=False)
+    a = np.concatenate([grads["fp8"][k].ravel() for k in grads["bf16"]])
+    b = np.concatenate([grads["bf16"][k].ravel() for k in grads["bf16"]])
+    cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+    per = {k: rel_err(grads["fp8"][k], v) for k, v in grads["bf16"].items() if v.size >= 16384}
+    worst = sorted(per.items(), key=lambda kv: -kv[1])[:3]
+    pw = [k for k in grads["bf16"] if k.endswith("conv_block.0.conv.1.weight")]
+    print(f"H={hidden} masked={masked}: fp8 vs bf16 weight gradient: cosine {cos:.5f}, worst large tensors {worst}; "
+          f"pointwise weights {[(k.split('mega_blocks.')[1][:14], round(per[k], 4)) for k in pw]}")
+    assert cos > 0.998 and worst[0][1] < 8e-2
+    assert any(not np.array_equal(grads["fp8"][k], grads["bf16"][k]) for k in pw)

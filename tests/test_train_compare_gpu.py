@@ -75,7 +75,8 @@ def test_fp8_trains_like_bf16(size, n_blocks):
     """L width, 2 blocks (the review's case) and TitaNet-M at its full depth of 10 blocks (the fp8 data gradient at
     depth; a single forward of that plan sits 17 % from the fp32 plan at block 10, tests/test_trained_parity_gpu.py)."""
     task = SpeakerTask(n_train=128, n_heldout=32, sig=0.012)
-    kw = dict(size=size, n_blocks=n_blocks, head="ce", steps=STEPS, tail=TAIL)
+    steps = STEPS if n_blocks <= 2 else 500          # (the 10-block runs cost 45 ms per 10 steps: 500 steps reach the plateau)
+    kw = dict(size=size, n_blocks=n_blocks, head="ce", steps=steps, tail=TAIL)
     a = [train_and_verify(task, "bf16", stream=s, **kw) for s in (0, 1)]
     b = [train_and_verify(task, "fp8", stream=s, **kw) for s in (0, 1)]
-    _compare(a, b, f"TitaNet-{size.upper()}/{n_blocks} ce: bf16 vs fp8, {STEPS} steps, 2 data streams each")
+    _compare(a, b, f"TitaNet-{size.upper()}/{n_blocks} ce: bf16 vs fp8, {steps} steps, 2 data streams each")

@@ -226,6 +226,16 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     p->wg2_count = b.take(sizeof(int) * (size_t)(c.n_mega_blocks * (c.n_sub_blocks + 1) * hs * hs + (D / 256 + 1) * hs + 2 * (D / 256) + 1));
   }
   p->dw_gacc = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * TN_NREP * (c.kernel + 1) * H * sizeof(float));
+  {
+    // fp8 weight gradient: this step's column maxima of |dS| per sub-block layer (zeroed with the region)
+    const char* ew = getenv("TN_FP8_WGRAD");
+    p->fp8_wgrad = p->fp8_bwd && !(ew && atoi(ew) == 0);
+    if (p->fp8_wgrad) {
+      p->blk.resize(c.n_mega_blocks);
+      for (int i = 0; i < c.n_mega_blocks; ++i)
+        for (int j = 0; j < c.n_sub_blocks; ++j) p->blk[i].amax_cur.push_back(b.take(H * sizeof(float)));
+    }
+  }
   if (p->tail_parts > 1) p->dgate_acc = b.take((size_t)c.n_mega_blocks * batch * H * sizeof(float));
   if (p->tail_parts > 1 && precision == TN_PREC_BF16) p->se_bacc = b.take((size_t)batch * 4 * H * sizeof(float));
   p->bzero_bytes = ((b.off + 255) & ~(size_t)255) - p->bzero_begin;
@@ -280,6 +290,15 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     for (auto& bw : p->blk)
       for (int j = 0; j < c.n_sub_blocks; ++j) { bw.w8.push_back(b.take(H * H)); bw.w8s.push_back(b.take(H * sizeof(float))); }
     p->fp8_table = b.take(sizeof(Fp8CastDesc) * (size_t)std::max(1, c.n_mega_blocks * (2 * c.n_sub_blocks + 1)));
+    if (p->fp8_wgrad) {
+      for (auto& bw : p->blk)
+        for (int j = 0; j < c.n_sub_blocks; ++j) { bw.Q8.push_back(b.take(M * H)); bw.dS8c.push_back(b.take(M * H)); bw.cexp.push_back(b.take(H)); }
+      // (one contiguous run, like amax_cur: the end of backward rolls this step's maxima over with one copy)
+      for (auto& bw : p->blk)
+        for (int j = 0; j < c.n_sub_blocks; ++j) bw.amax_prev.push_back(b.take(H * sizeof(float)));
+      p->tn_f8_table = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * 64);      // >= sizeof(PGemmTnF8Desc) each (checked at upload)
+      p->tn_skip_table = b.take((size_t)c.n_mega_blocks * 64);
+    }
     if (p->fp8_bwd) {
       p->ds8 = b.take(M * H);
       p->dsexp = b.take(((size_t)(M + 255) / 256) * 256);
@@ -638,6 +657,7 @@ extern "C" int tn_plan_bind(tn_plan* p, float* params, float* grads, float* bnbu
     TN_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     p->bucket_events.push_back(e);
   }
+  p->fp8_hist_valid = false;      // (a freshly bound workspace holds no column maxima: the next backward records them, tn_bwd.hip)
   p->bound = true;
   return 0;
 }
@@ -844,7 +864,8 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
         } else if (p->split_dw && p->save_q) {
           // wide models: the depthwise output is produced once by a streaming kernel (it is kept for the weight gradients
           // anyway) and the pointwise GEMM reads it as a plain operand
-          uint8_t* q8 = (p->fp8 && sizeof(AT) == 2) ? (uint8_t*)(ws + p->q8) : nullptr;
+          // (fp8 weight gradient: the e4m3 depthwise output is KEPT per layer — it is the contraction's second operand)
+          uint8_t* q8 = (p->fp8 && sizeof(AT) == 2) ? (uint8_t*)(ws + ((p->fp8_wgrad && training && !bw.Q8.empty()) ? bw.Q8[j] : p->q8)) : nullptr;
           rc = -1000;
           bool q_clean = false;          // the slab kernel stores zeros on padding rows (what the pipelined GEMMs' pad_rows needs)
           if (sizeof(AT) == 2 && p->wide_dw_bwd) {
@@ -852,6 +873,9 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
             memset(&fa, 0, sizeof(fa));
             fa.X = (const bf16_t*)cur; fa.act = acur; fa.wdw = params + sb.wdw; fa.bdw = params + sb.bdw;
             fa.Q = (bf16_t*)(ws + bw.Q[j]); fa.Q8 = q8; fa.M = M; fa.T = T; fa.C = H;
+            // fp8 weight gradient with column maxima on record: the backward will contract the e4m3 copy — the bf16 one (2 of
+            // the 3 bytes this pass writes per element) is not stored (a fallback to the generic producer below stores both)
+            if (p->fp8_wgrad && p->fp8_hist_valid && training && q8 && !bw.Q8.empty()) fa.Q = nullptr;
             if (p->masked && p->skip_pad_tiles && p->n_rowtiles > 0) { fa.rowtiles = (const int*)(ws + p->rowtiles); fa.n_rowtiles = p->n_rowtiles; }
             rc = launch_dw_fwd_slab(fa, c.kernel, st);
             if (rc > 0) return rc;

@@ -108,7 +108,8 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   // incoming gradient from the tail's dZ before the skip path's in-place pass overwrote that)
   auto pipe_layer = [&](size_t dz, size_t y, const BnRef& bn, int Cout, const WcRef& wc, int Cin, size_t dx_out, const void* q, bool q_plain,
                         const BnAct& qact, int64_t wgrad_off, bool ds_ready = false, bool defer_tn = false,
-                        Fp8Rows f8rows = Fp8Rows{nullptr, nullptr}, size_t w8t = 0, size_t w8ts = 0) -> int {
+                        Fp8Rows f8rows = Fp8Rows{nullptr, nullptr}, size_t w8t = 0, size_t w8ts = 0,
+                        Fp8Cols fcols = Fp8Cols{nullptr, nullptr, nullptr, nullptr}) -> int {
     DBG("pipe dZ in", dz, (size_t)M * Cout); DBG("pipe Y", y, (size_t)M * Cout);
     DBGF("pipe bsums", ws + p->bsums[bn.id], TN_NREP * 2 * Cout); DBGF("pipe fstats", ws + p->stats[bn.id], TN_NREP * 2 * Cout);
     int rc = 0;
@@ -118,7 +119,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     const bool listed = p->masked && p->n_rowtiles > 0;
     const int* rowtiles = listed ? (const int*)(ws + p->rowtiles) : nullptr;
     if (!ds_ready) rc = launch_bn_bwd_apply((bf16_t*)(ws + dz), (const bf16_t*)(ws + y), make_bnbwd(p, bn, M, training), M, Cout, st,
-                                            p->fp8_bwd_emu && Cout == H, f8rows, rowtiles, listed ? p->n_rowtiles : 0);
+                                            p->fp8_bwd_emu && Cout == H, f8rows, rowtiles, listed ? p->n_rowtiles : 0, fcols);
     if (rc) return rc;
     DBG("pipe dS", dz, (size_t)M * Cout);
     if (f8) {
@@ -151,6 +152,15 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   // wide models: the pointwise weight gradients of the mega blocks in ONE pipelined launch per gradient bucket
   // (pgemm_tn_batched_kernel: ~2 atomic flushes per workgroup and step instead of one per layer)
   const bool tn_batched = pipe && p->tn_table != 0 && !p->v2_tn;
+  // fp8 weight gradient (round 5): the sub-block layers' contraction on the f8f6f4 MFMA from the per-column-scaled e4m3 dS the
+  // BatchNorm-backward passes write beside their other outputs, and the kept e4m3 depthwise outputs.  Delayed scaling: a plan's
+  // first backward has no column maxima yet — it runs the bf16 contraction and only RECORDS them
+  const bool f8_wgrad = tn_batched && p->fp8_wgrad && p->tn_f8_table != 0 && training;
+  const bool f8_wgrad_now = f8_wgrad && p->fp8_hist_valid;
+  auto fcols_of = [&](const BlockWs& bw_, int j) -> Fp8Cols {
+    if (!f8_wgrad || bw_.dS8c.empty()) return Fp8Cols{nullptr, nullptr, nullptr, nullptr};
+    return Fp8Cols{(uint8_t*)(ws + bw_.dS8c[j]), (const float*)(ws + bw_.amax_prev[j]), (float*)(ws + bw_.amax_cur[j]), (uint8_t*)(ws + bw_.cexp[j])};
+  };
   // table layout (plan_upload_bwd_tables): blocks from the last down, per block the skip conv (blocks > 0), then the
   // sub-blocks from the last down
   // (the first block's skip conv joins when its input — the activated prolog output — is kept as a stored operand, p->a0)
@@ -200,6 +210,22 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     if (v2_bwd && has_blocks)
       hipLaunchKernelGGL(dw_grad_finalize_kernel, dim3((bk.blk_hi - bk.blk_lo + 1) * nsub), dim3(256), 0, st,
                          (const DwGradOut*)(ws + p->dw_table) + (size_t)bk.blk_lo * nsub, c.kernel);
+    if (tn_batched && has_blocks && f8_wgrad_now) {
+      // the skip convs (bf16 operands) and the sub-block layers (e4m3 operands) as two launches; tables in backward order
+      const bool listed = p->masked && p->n_rowtiles > 0;
+      const int* rt = listed ? (const int*)(ws + p->rowtiles) : nullptr;
+      auto has_skip = [&](int blk) { return (blk > 0 || p->a0) ? 1 : 0; };
+      int sfirst = 0, scount = 0;
+      for (int k2 = nb - 1; k2 > bk.blk_hi; --k2) sfirst += has_skip(k2);
+      for (int k2 = bk.blk_hi; k2 >= bk.blk_lo; --k2) scount += has_skip(k2);
+      ProfScope ps(p, TN_PROF_BWD_WGRAD, st);
+      int rc = launch_pgemm_tn_batched((const PGemmTnDesc*)(ws + p->tn_skip_table) + sfirst, scount, M, (H / 256) * (H / 256), rt,
+                                       listed ? p->n_rowtiles : 0, st, 256, H);
+      if (rc) { rc_fin = rc; return; }
+      rc = launch_pgemm_tn_f8_batched((const PGemmTnF8Desc*)(ws + p->tn_f8_table) + (size_t)(nb - 1 - bk.blk_hi) * nsub,
+                                      (bk.blk_hi - bk.blk_lo + 1) * nsub, M, (H / 256) * (H / 256), rt, listed ? p->n_rowtiles : 0, st, 256, H);
+      if (rc) { rc_fin = rc; return; }
+    } else
     if (tn_batched && has_blocks) {
       const int first = tn_offset(bk.blk_hi), count = tn_offset(bk.blk_lo) + tn_entries(bk.blk_lo) - first;
       const bool listed = p->masked && p->n_rowtiles > 0;
@@ -466,7 +492,8 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
                                       make_bnbwd(p, mb.sub[nsub - 1].bn, M, training), act3, (const float*)(ws + p->se_gu),
                                       (bf16_t*)(ws + bw.dY[nsub - 1]), M, H, T, st,
                                       (p->fp8_bwd && !bw.w8t.empty()) ? Fp8Rows{(uint8_t*)(ws + p->ds8), (uint8_t*)(ws + p->dsexp)}
-                                                                     : Fp8Rows{nullptr, nullptr});
+                                                                     : Fp8Rows{nullptr, nullptr},
+                                      fcols_of(bw, nsub - 1));
           if (rc) return rc;
         }
       } else {
@@ -621,7 +648,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         const bool f8 = p->fp8_bwd && !bw.w8t.empty();
         int rc = pipe_layer(bw.dY[j], bw.Y[j], sb.bn, H, bw.wpw[j], H, p->dD, ws + bw.Q[j], true, identity_act(), sb.wpw,
                             z3, tn_batched, f8 ? Fp8Rows{(uint8_t*)(ws + p->ds8), (uint8_t*)(ws + p->dsexp)} : Fp8Rows{nullptr, nullptr},
-                            f8 ? bw.w8t[j] : 0, f8 ? bw.w8ts[j] : 0);
+                            f8 ? bw.w8t[j] : 0, f8 ? bw.w8ts[j] : 0, f8 ? fcols_of(bw, j) : Fp8Cols{nullptr, nullptr, nullptr, nullptr});
         if (rc) return rc;
       } else {
         GemmShape g{M, H, H, wt(bw.wpw[j])};
@@ -696,6 +723,11 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   // weight gradients (v2: all of the bucket's layers in one balanced launch), sums -> BatchNorm / bias / SE gradients
   finalize_bucket((int)p->buckets.size() - 1);
   if (rc_fin) return rc_fin;
+  if (f8_wgrad && nb > 0 && !p->blk[0].amax_cur.empty()) {
+    // this step's column maxima become the next step's scales (one contiguous run per side, plan layout)
+    TN_CHECK_HIP(hipMemcpyAsync(ws + p->blk[0].amax_prev[0], ws + p->blk[0].amax_cur[0], (size_t)nb * nsub * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+    p->fp8_hist_valid = true;
+  }
   return (int)hipGetLastError();
 }
 
@@ -769,6 +801,23 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
     if (sizeof(PGemmTnDesc) > 64) return TN_E_STATE;
     if (!td.empty())
       TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->tn_table, td.data(), td.size() * sizeof(PGemmTnDesc), hipMemcpyHostToDevice, st));
+    std::vector<PGemmTnDesc> tsk;
+    std::vector<PGemmTnF8Desc> tf8;
+    if (p->fp8_wgrad && p->tn_f8_table && !p->v2_tn) {
+      // fp8 weight gradient: the skip convs alone (bf16 operands) and the sub-block layers (e4m3 operands), backward order
+      if (sizeof(PGemmTnF8Desc) > 64) return TN_E_STATE;
+      for (int i = c.n_mega_blocks - 1; i >= 0; --i) {
+        const BlockWs& bw = p->blk[i];
+        if (i > 0 || p->a0)
+          tsk.push_back(PGemmTnDesc{(const bf16_t*)(p->ws + bw.dZk), (const bf16_t*)(p->ws + (i > 0 ? p->blk[i - 1].OUT : p->a0)),
+                                    p->grads + m->blocks[i].wskip, H, H, H, H / 256});
+        for (int j = nsub - 1; j >= 0; --j)
+          tf8.push_back(PGemmTnF8Desc{(const uint8_t*)(p->ws + bw.dS8c[j]), (const uint8_t*)(p->ws + bw.Q8[j]), p->grads + m->blocks[i].sub[j].wpw,
+                                      (const uint8_t*)(p->ws + bw.cexp[j]), H, H, H, H / 256});
+      }
+      if (!tsk.empty()) TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->tn_skip_table, tsk.data(), tsk.size() * sizeof(PGemmTnDesc), hipMemcpyHostToDevice, st));
+      if (!tf8.empty()) TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->tn_f8_table, tf8.data(), tf8.size() * sizeof(PGemmTnF8Desc), hipMemcpyHostToDevice, st));
+    }
     TN_CHECK_HIP(hipStreamSynchronize(st));
   }
   if (p->use_v2 && p->wg2_layers > 0) {

@@ -1301,13 +1301,27 @@ __global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const float* __restr
 // those; null = all M rows.
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ dZ, const bf16_t* __restrict__ Y, BnBwd bn, int M, int C, Fp8Rows f8,
-                                                           const int* __restrict__ rowtiles, int n_rowtiles) {
+                                                           const int* __restrict__ rowtiles, int n_rowtiles, Fp8Cols fc) {
   constexpr bool EMU8 = MODE == 1, OUT8 = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) float pg_k[];      // k0, k1, k2 : [3][C]
   __shared__ float wmax[4];
+  __shared__ float cmax[OUT8 ? 256 * 8 : 1];                        // per-thread column maxima (fp8 weight gradient)
   for (int c = threadIdx.x; c < C; c += 256) bn_bwd_coefs(bn, C, c, pg_k[c], pg_k[C + c], pg_k[2 * C + c]);
   __syncthreads();
   const int VC = C / 8;
+  // fp8 weight gradient: a thread keeps ONE set of 8 columns for the whole loop (the grid stride is a multiple of VC): their
+  // scales from the previous step's maxima, and this step's maxima
+  const bool cols = OUT8 && fc.q != nullptr;
+  const int cfix = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % VC) * 8;
+  float csc[8], cmx[8];
+  if (OUT8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { csc[u] = cols ? tn_e4m3_col_scale(fc.amax_prev[cfix + u]) : 1.f; cmx[u] = 0.f; }
+    if (cols && blockIdx.x == 0 && threadIdx.x < VC) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) fc.cexp[cfix + u] = (uint8_t)(254u - ((__float_as_uint(csc[u]) >> 23) & 0xffu));      // E8M0 of 1 / scale
+    }
+  }
   const size_t nvec = (size_t)(rowtiles ? n_rowtiles * 256 : M) * VC;
   for (size_t iv = (size_t)blockIdx.x * 256 + threadIdx.x; iv < nvec; iv += (size_t)gridDim.x * 256) {
     const int c0 = (int)(iv % VC) * 8;
@@ -1350,23 +1364,41 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ 
       if (OUT8 && !oob) {
         *reinterpret_cast<uint2*>(f8.q + i * 8) = tn_e4m3_pack8(z, 1.f / sc);
         if (c0 == 0) f8.rowexp[tn_rowexp_pos(row)] = tn_e8m0_of_pow2(sc);
+        if (cols) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) cmx[u] = fmaxf(cmx[u], fabsf(z[u]));
+          *reinterpret_cast<uint2*>(fc.q + i * 8) = tn_e4m3_pack8_cols(z, csc);
+        }
       }
     }
     if (!oob) store8(dZ + i * 8, z);
   }
+  if (OUT8) {
+    if (cols) {      // workgroup-uniform
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cmax[threadIdx.x * 8 + u] = cmx[u];
+      __syncthreads();
+      // thread t holds columns 8 (t % VC) ..: column c lives in threads (c / 8) + k VC, k < 256 / VC
+      for (int c = threadIdx.x; c < C; c += 256) {
+        float m = 0.f;
+        for (int k = 0; k < 256 / VC; ++k) m = fmaxf(m, cmax[(k * VC + c / 8) * 8 + (c & 7)]);
+        if (m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(fc.amax_cur) + c, __float_as_uint(m));
+      }
+    }
+  }
 }
 // emu8: the e4m3 round trip in place (experiment);  f8: also write the fp8 operand (q != null)
 inline int launch_bn_bwd_apply(bf16_t* dZ, const bf16_t* Y, const BnBwd& bn, int M, int C, hipStream_t st, bool emu8 = false, Fp8Rows f8 = Fp8Rows{nullptr, nullptr},
-                               const int* rowtiles = nullptr, int n_rowtiles = 0) {
+                               const int* rowtiles = nullptr, int n_rowtiles = 0, Fp8Cols fc = Fp8Cols{nullptr, nullptr, nullptr, nullptr}) {
   if (C % 8 || C > 4096) return TN_E_UNSUPPORTED;
   if (!bn.rm.len || n_rowtiles <= 0) { rowtiles = nullptr; n_rowtiles = 0; }
   const bool rows_ok = (C == 512 || C == 1024) && ((size_t)M * (C / 8)) % 256 == 0;
   if (f8.q && !rows_ok) return TN_E_UNSUPPORTED;
   if (f8.q)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C, f8, rowtiles, n_rowtiles);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C, f8, rowtiles, n_rowtiles, fc);
   else if (emu8 && !bn.rm.len && rows_ok)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C, f8, rowtiles, n_rowtiles);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C, f8, rowtiles, n_rowtiles, fc);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C, f8, rowtiles, n_rowtiles);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C, f8, rowtiles, n_rowtiles, fc);
   return (int)hipGetLastError();
 }

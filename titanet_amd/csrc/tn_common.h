@@ -321,6 +321,33 @@ __device__ __forceinline__ uint2 tn_e4m3_pack8(const float v[8], float inv_s) {
 // the E8M0 byte of a power-of-two scale (its biased float exponent)
 __device__ __forceinline__ uint8_t tn_e8m0_of_pow2(float sc) { return (uint8_t)((__float_as_uint(sc) >> 23) & 0xffu); }
 struct Fp8Rows { uint8_t* q; uint8_t* rowexp; };      // [M][C] e4m3 bytes, [ceil(M / 256) * 256] exponent bytes (tn_rowexp_pos); or nulls
+// fp8 weight gradient (round 5): dS as e4m3 bytes with ONE power-of-two scale per COLUMN (a contraction over the rows only lets a
+// per-column scale factor out).  Delayed scaling: the scale of column c comes from the maximum of |dS[:, c]| of the PREVIOUS
+// backward of this plan (amax_prev), aimed at 56 = 448 / 8 (three bits of headroom for growth from one step to the next; values
+// beyond are clamped to +-448); the pass that writes the bytes also takes this step's maxima (amax_cur, zeroed by the caller,
+// atomicMax on the float bits) and the E8M0 byte per column that undoes the scale (cexp: the A block-scale operand of
+// pgemm_tn_f8_batched_kernel).  q == null: off.
+struct Fp8Cols { uint8_t* q; const float* amax_prev; float* amax_cur; uint8_t* cexp; };
+// power-of-two scale for a column whose previous maximum was amax: 2^floor(log2(56 / amax)), exponent within +-60; 1 without history
+__device__ __forceinline__ float tn_e4m3_col_scale(float amax) {
+  if (!(amax > 0.f)) return 1.f;
+  const float r = 56.f / amax;
+  int e = (int)((__float_as_uint(r) >> 23) & 0xffu) - 127;
+  e = e < -60 ? -60 : (e > 60 ? 60 : e);
+  return __uint_as_float((uint32_t)(e + 127) << 23);
+}
+// e4m3 bytes of 8 values times s, clamped to the finite range (an out-of-range input of the converter is a NaN byte)
+__device__ __forceinline__ uint2 tn_e4m3_pack8_cols(const float v[8], const float s[8]) {
+  float w[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) w[u] = __builtin_amdgcn_fmed3f(v[u] * s[u], -448.f, 448.f);
+  uint2 o = make_uint2(0u, 0u);
+  o.x = __builtin_amdgcn_cvt_pk_fp8_f32(w[0], w[1], o.x, false);
+  o.x = __builtin_amdgcn_cvt_pk_fp8_f32(w[2], w[3], o.x, true);
+  o.y = __builtin_amdgcn_cvt_pk_fp8_f32(w[4], w[5], o.y, false);
+  o.y = __builtin_amdgcn_cvt_pk_fp8_f32(w[6], w[7], o.y, true);
+  return o;
+}
 
 #define TN_CHECK_HIP(expr)                          \
   do {                                              \

@@ -194,7 +194,7 @@ struct DwFwdSlabArgs {
   const bf16_t* X; BnAct act;
   const float* wdw;    // [C][KD]
   const float* bdw;    // [C]
-  bf16_t* Q;           // [M][C]
+  bf16_t* Q;           // [M][C], or null when only Q8 is wanted
   uint8_t* Q8;         // [M][C] e4m3 copy for the fp8 pointwise GEMM (TN_PREC_FP8; needs 4 channels per lane) or null
   int M, T, C, ntiles;
   // variable-length batches: the 256-row tiles that hold at least one valid frame (PGemmNtArgs::rowtiles) or null = all rows.
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void dw_fwd_slab_kernel(DwFwdSlabArgs a) {
 #pragma unroll
       for (int o = 0; o < RS; ++o) {
         const int gr = out0 + l0 + o;
-        st_ch<CH>(a.Q + (size_t)gr * a.C + cb + cl, z);
+        if (a.Q) st_ch<CH>(a.Q + (size_t)gr * a.C + cb + cl, z);
         if (CH == 4 && a.Q8) *reinterpret_cast<uint32_t*>(a.Q8 + (size_t)gr * a.C + cb + cl) = 0u;
       }
     } else
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void dw_fwd_slab_kernel(DwFwdSlabArgs a) {
           }
         }
         if (fast || gr < a.M) {
-          st_ch<CH>(a.Q + (size_t)gr * a.C + cb + cl, q);
+          if (a.Q) st_ch<CH>(a.Q + (size_t)gr * a.C + cb + cl, q);      // (null: only the e4m3 copy is kept, fp8 weight gradient)
           if (CH == 4 && a.Q8) *reinterpret_cast<uint32_t*>(a.Q8 + (size_t)gr * a.C + cb + cl) = f2fp8x4(q[0], q[1], q[CH - 2], q[CH - 1]);
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -72,6 +72,10 @@ struct BlockWs {
   std::vector<size_t> w8, w8s;   // TN_PREC_FP8: e4m3 pointwise weights [H][H] and their per-row scales [H] (float)
   std::vector<size_t> w8t, w8ts; // fp8 data gradient: e4m3 rows of W^T [ci][co] and their per-input-channel scales [H]
   size_t w8t_skip = 0, w8ts_skip = 0;   // ... of the skip connection's 1x1 conv
+  // fp8 weight gradient (round 5, tn_plan::fp8_wgrad): per sub-block layer the kept e4m3 depthwise output, the e4m3 copy of dS
+  // scaled per COLUMN, the E8M0 byte per column the contraction undoes, and the column maxima of |dS| (previous step: persistent;
+  // this step: inside the region zeroed at the start of every backward)
+  std::vector<size_t> Q8, dS8c, cexp, amax_prev, amax_cur;
   WcRef wskip;
   // backward (float): SE pre-activation grads
   size_t dpre2, dpre1, dgate;
@@ -110,6 +114,11 @@ struct tn_plan {
   size_t ds8s = 0, dsexps = 0;          // ... and of the skip connection's layer (its dS is made while the last sub-block's is still pending)
   size_t ds8 = 0, dsexp = 0;            // ... their A operand: e4m3 dS [M][H] bytes + row exponent bytes (one layer at a time)
   size_t q8 = 0, fp8_table = 0;         // e4m3 copy of the current depthwise output [M][H] bytes; weight-cast descriptors
+  bool fp8_wgrad = false;               // fp8 plans on the pipelined path: the sub-block pointwise weight gradients on the f8f6f4 MFMA
+                                        // (pgemm_tn_f8_batched_kernel); delayed per-column scales: the FIRST backward of a plan has no
+                                        // history and runs the bf16 contraction (fp8_hist_valid)
+  bool fp8_hist_valid = false;
+  size_t tn_f8_table = 0, tn_skip_table = 0;   // PGemmTnF8Desc of the sub-block layers / PGemmTnDesc of the skip convs alone (backward order)
   int n_fp8 = 0;
   bool split_dw = false;                // wide models: depthwise producer as its own streaming kernel (forward)
   bool save_q = false;                  // forward stores the depthwise outputs (bf16 v2 path with batched weight gradients)

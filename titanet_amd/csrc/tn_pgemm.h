@@ -1035,6 +1035,185 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_batched_kernel(const PGemmTnD
     pos += n;
   }
 }
+// ==========================================================================================
+// fp8 weight gradient (round 5): OUT[o][c] += sum over rows r of  (P8[r][o] 2^-e[o]) * Q8[r][c]
+//   P8: the BatchNorm-backward'd gradient dS as e4m3 bytes scaled by ONE power of two per COLUMN o (the contraction runs over
+//       the rows, so only a per-column scale factors out of it; bn_bwd_apply writes it with the previous step's column maxima),
+//   Q8: the layer's kept depthwise output as e4m3 bytes (unit scale: what the fp8 forward GEMM already reads),
+//   cexp: one E8M0 byte per column of P8 = the scale 2^-e[o] to undo, passed to v_mfma_scale_f32_32x32x64_f8f6f4 as the A
+//       block scale (a lane's output row IS a column of P8, so the per-column scale costs nothing: both 32-k blocks of a lane
+//       carry the same byte).
+// K steps of 64 rows: tiles [64 rows][256 bytes] (16 KB per operand and stage, the ring of pg_tn_segment), read with the
+// byte-transposing LDS read.  ds_read_b64_tr_b8 (probed, tools/tr8_probe.hip, profiles/r05_tr8_probe.txt): in every group of 16
+// lanes, lane l receives byte (l & 7) of the 8-byte pieces addressed by lanes 2 j + (l >> 3), j = 0..7 — so with lane m of a
+// group pointing at row (m >> 1), columns 8 (m & 1) .. + 7, lane l gets column l of rows 0..7: 16 columns x 8 rows per group,
+// four instructions (rows 8 t ..) for the 32 rows of a lane's k-half, the same row order for both operands (which is all a
+// dot product needs).  Swizzle (source side of the DMA, undone by the reads): 32-byte chunk ^= row & 7 — the 8 rows x 32 bytes a
+// half-wave touches per instruction then cover all 64 banks once.
+// ==========================================================================================
+typedef __attribute__((ext_vector_type(8))) int pg_i32x8_t;
+typedef __attribute__((ext_vector_type(2))) int pg_i32x2_t;
+__device__ __forceinline__ pg_i32x8_t pg_tr8_frag(const char* p) {
+  pg_i32x8_t f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const pg_i32x2_t v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) pg_i32x2_t*)(p + t * 2048));
+    f[2 * t] = v[0]; f[2 * t + 1] = v[1];
+  }
+  return f;
+}
+struct PGemmTnF8Desc {
+  const uint8_t* P; const uint8_t* Q; float* out; const uint8_t* cexp;      // cexp[ldp]: E8M0 byte per column of P
+  int ldp, ldq, ldo, tiles_q;       // row strides in bytes (= elements); tiles_p * tiles_q == U for every descriptor of a launch
+};
+template <int NSTAGE>
+__device__ __forceinline__ void pg_tn_segment_f8(const PGemmTnF8Desc& a, int rows, const int* __restrict__ rowtiles, int n_rowtiles,
+                                                 int tp, int tq, int s0, int nsteps, char* smem) {
+  constexpr int AHEAD = NSTAGE - 1, TILE_B = 16384, STAGE_B = 2 * TILE_B, GRP = 4;
+  const unsigned lds0 = (unsigned)(uintptr_t)(tn_lds_char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wa = wave >> 2, wb = wave & 3;
+  const pg_i32x4_t psrd = pg_make_srd(a.P, (unsigned)((size_t)rows * a.ldp));
+  const pg_i32x4_t qsrd = pg_make_srd(a.Q, (unsigned)((size_t)rows * a.ldq));
+  // DMA: instruction q of this wave fills tile rows (q*8 + wave)*4 + (lane >> 4), 16-byte chunk lane & 15 of that row
+  unsigned voffP[2], voffQ[2], baseP[2], baseQ[2];
+  auto step_row = [&](int s) { return rowtiles ? tn_sload_i32(rowtiles, s >> 2) * 256 + (s & 3) * 64 : s * 64; };
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int r = (q * 8 + wave) * 4 + (lane >> 4);
+    const int chunk = (lane & 15) ^ ((r & 7) << 1);
+    baseP[q] = (unsigned)((size_t)r * a.ldp + tp * 256 + chunk * 16);
+    baseQ[q] = (unsigned)((size_t)r * a.ldq + tq * 256 + chunk * 16);
+  }
+  {
+    const unsigned row0 = (unsigned)step_row(s0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { voffP[q] = baseP[q] + row0 * (unsigned)a.ldp; voffQ[q] = baseQ[q] + row0 * (unsigned)a.ldq; }
+  }
+  const unsigned stepP = 64u * (unsigned)a.ldp, stepQ = 64u * (unsigned)a.ldq;
+  int istage = 0, sreq = s0;
+  auto dma_p = [&](int q) { pg_dma16_buf(voffP[q], psrd, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + istage * STAGE_B + (q * 8 + wave) * 1024))); };
+  auto dma_q = [&](int q) { pg_dma16_buf(voffQ[q], qsrd, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + istage * STAGE_B + TILE_B + (q * 8 + wave) * 1024))); };
+  auto advance_issue = [&]() {
+    ++sreq;
+    if (rowtiles && (sreq & 3) == 0) {
+      const unsigned row0 = (sreq >> 2) < n_rowtiles ? (unsigned)step_row(sreq) : (unsigned)rows + 256u;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { voffP[q] = baseP[q] + row0 * (unsigned)a.ldp; voffQ[q] = baseQ[q] + row0 * (unsigned)a.ldq; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { voffP[q] += stepP; voffQ[q] += stepQ; }      // past the last row: zeros (bounds check)
+    }
+    istage = istage + 1 == NSTAGE ? 0 : istage + 1;
+  };
+  // fragments: lane L -> group g = L >> 4 (k-half g >> 1, column half g & 1), m = L & 15: piece (row 32 (g >> 1) + (m >> 1) [+ 8 t],
+  // columns 16 (g & 1) + 8 (m & 1) .. + 7) of the 32-column block; rw = m >> 1 = row & 7 drives the swizzle
+  const int m16 = lane & 15, g1 = (lane >> 4) & 1, half = lane >> 5, rw = m16 >> 1;
+  const int lbase = (half * 32 + rw) * 256 + 16 * g1 + 8 * (m16 & 1);
+  int aoff[4], boff[2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) aoff[mi] = lbase + ((((wa * 4 + mi)) ^ rw) << 5);
+#pragma unroll
+  for (int nj = 0; nj < 2; ++nj) boff[nj] = TILE_B + lbase + ((((wb * 2 + nj)) ^ rw) << 5);
+  // A block scales: byte mi of the dword = the E8M0 byte of P column tp * 256 + wa * 128 + mi * 32 + (lane & 31)
+  int xa = 0;
+  {
+    const uint8_t* ce = a.cexp + tp * 256 + wa * 128 + (lane & 31);
+    xa = (int)ce[0] | ((int)ce[32] << 8) | ((int)ce[64] << 16) | ((int)ce[96] << 24);
+  }
+  constexpr int SC1 = 0x7f7f7f7f;
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the exponent bytes above: compiler-visible loads, before the counted queue)
+  asm volatile("" : "+v"(xa));
+#pragma unroll 1
+  for (int d = 0; d < AHEAD; ++d) {
+    dma_p(0); dma_q(0); dma_p(1); dma_q(1);
+    advance_issue();
+  }
+  pg_wait<(AHEAD - 1) * GRP>();
+  pg_barrier();
+  int cstage = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    const char* st = smem + cstage * STAGE_B;
+    pg_i32x8_t bfr[2];
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) bfr[nj] = pg_tr8_frag(st + boff[nj]);
+    dma_p(0); dma_q(0); dma_p(1); dma_q(1);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const pg_i32x8_t af = pg_tr8_frag(st + aoff[mi]);
+      auto mm = [&](auto sel) {
+        constexpr int S = decltype(sel)::value;
+        acc[mi][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af, bfr[0], acc[mi][0], 0, 0, S, xa, 0, SC1);
+        acc[mi][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af, bfr[1], acc[mi][1], 0, 0, S, xa, 0, SC1);
+      };
+      if (mi == 0) mm(std::integral_constant<int, 0>{});
+      else if (mi == 1) mm(std::integral_constant<int, 1>{});
+      else if (mi == 2) mm(std::integral_constant<int, 2>{});
+      else mm(std::integral_constant<int, 3>{});
+    }
+    advance_issue();
+    cstage = cstage + 1 == NSTAGE ? 0 : cstage + 1;
+    pg_wait<(AHEAD - 1) * GRP>();
+    pg_barrier();
+  }
+  pg_wait<0>();
+  float* out = a.out + (size_t)(tp * 256 + wa * 128) * a.ldo + tq * 256 + wb * 64 + (lane & 31);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        atomic_add_f32(out + (size_t)(mi * 32 + cd_row(r, lane)) * a.ldo + nj * 32, acc[mi][nj][r]);
+}
+template <int DUMMY>
+__global__ __launch_bounds__(512, 2) void pgemm_tn_f8_batched_kernel(const PGemmTnF8Desc* __restrict__ descs, int n_descs, int rows, int U,
+                                                                      int steps_per_group, const int* rowtiles, int n_rowtiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int G = gridDim.x, v = pg_virtual_id(blockIdx.x, G);
+  const int group = v / U, unit = v - group * U;
+  const int nsteps = rowtiles ? n_rowtiles * 4 : (rows + 63) / 64;
+  const long total = (long)n_descs * nsteps;
+  long pos = (long)group * steps_per_group;
+  long end = pos + steps_per_group;
+  end = end < total ? end : total;
+  while (pos < end) {
+    const int d = (int)(pos / nsteps), s0 = (int)(pos - (long)d * nsteps);
+    const long left = end - pos;
+    const int n = (int)(left < (long)(nsteps - s0) ? left : (long)(nsteps - s0));
+    PGemmTnF8Desc a = descs[d];
+    pg_barrier();                       // the previous segment's last fragment reads are done before its ring is refilled
+    pg_tn_segment_f8<5>(a, rows, rowtiles, n_rowtiles, unit / a.tiles_q, unit % a.tiles_q, s0, n, smem);
+    pos += n;
+  }
+}
+inline int launch_pgemm_tn_f8_batched(const PGemmTnF8Desc* descs_dev, int n_descs, int rows, int U, const int* rowtiles, int n_rowtiles, hipStream_t st,
+                                      int max_wgs = 256, int ld_max = 1024) {
+  if (n_descs <= 0) return 0;
+  if (U <= 0 || U > max_wgs || rows <= 0 || ld_max % 16) return TN_E_UNSUPPORTED;
+  if ((long)(rows + 512) * ld_max >= (1L << 32)) return TN_E_UNSUPPORTED;
+  const int nsteps = rowtiles ? n_rowtiles * 4 : (rows + 63) / 64;
+  if (nsteps <= 0) return 0;
+  const long total = (long)n_descs * nsteps;
+  int groups = max_wgs / U;
+  if ((long)groups > total) groups = (int)total;
+  const int spg = (int)((total + groups - 1) / groups);
+  groups = (int)((total + spg - 1) / spg);
+  const int grid = groups * U;
+  auto kern = pgemm_tn_f8_batched_kernel<0>;
+  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 163840, st, descs_dev, n_descs, rows, U, spg, rowtiles, n_rowtiles);
+  return (int)hipGetLastError();
+}
+
 // ld_max: the widest row stride (elements) among the descriptors' operands — they live in device memory, so the 32-bit
 // buffer-offset limit of the kernel is checked against what the caller says it put there
 inline int launch_pgemm_tn_batched(const PGemmTnDesc* descs_dev, int n_descs, int rows, int U, const int* rowtiles, int n_rowtiles, hipStream_t st,

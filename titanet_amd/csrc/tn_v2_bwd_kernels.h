@@ -780,10 +780,11 @@ inline int launch_combine_bwd1_v3(const CombineBwd1V3Args& aa, int B, int C, hip
 template <bool DROP3, int CH, bool OUT8>
 __global__ __launch_bounds__(256) void bn_bwd_apply_z3_kernel(const bf16_t* __restrict__ dZ, const bf16_t* __restrict__ Y, BnBwd bn, BnAct act3,
                                                               const float* __restrict__ gu, bf16_t* __restrict__ dS, int T, int chunk,
-                                                              const int* __restrict__ len, Fp8Rows f8) {
+                                                              const int* __restrict__ len, Fp8Rows f8, Fp8Cols fc) {
   constexpr int VC = CH / 8, RG = 256 / VC;       // channel vectors per row, row groups per workgroup
   __shared__ __attribute__((aligned(16))) float pg_k[5 * CH];      // k0, k1, k2, sc3, sh3
   __shared__ float wmax[4][4];
+  __shared__ float cmax[OUT8 ? 256 * 8 : 1];      // per-thread column maxima (fp8 weight gradient, Fp8Cols)
   for (int c = threadIdx.x; c < CH; c += 256) {
     bn_bwd_coefs(bn, CH, c, pg_k[c], pg_k[CH + c], pg_k[2 * CH + c]);
     bn_scale_shift(act3, CH, c, pg_k[3 * CH + c], pg_k[4 * CH + c]);
@@ -798,6 +799,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_z3_kernel(const bf16_t* __re
   }
   load8(gu + (size_t)b * 2 * CH + c0, ga);
   load8(gu + (size_t)b * 2 * CH + CH + c0, ub);
+  const bool cols = OUT8 && fc.q != nullptr;
+  float csc[8], cmx[8];
+  if (OUT8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { csc[u] = cols ? tn_e4m3_col_scale(fc.amax_prev[c0 + u]) : 1.f; cmx[u] = 0.f; }
+    if (cols && blockIdx.x == 0 && blockIdx.y == 0 && rg == 0) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) fc.cexp[c0 + u] = (uint8_t)(254u - ((__float_as_uint(csc[u]) >> 23) & 0xffu));      // E8M0 of 1 / scale
+    }
+  }
   const int t0 = blockIdx.x * chunk, t_end = min(T, t0 + chunk);
   const int t1 = len ? min(t_end, len[b]) : t_end;       // padding frames of a variable-length batch: dS = 0 (written below)
   if (len) {
@@ -808,6 +819,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_z3_kernel(const bf16_t* __re
       if (OUT8) {
         *reinterpret_cast<uint2*>(f8.q + row * CH + c0) = make_uint2(0u, 0u);
         if (c0 == 0) f8.rowexp[tn_rowexp_pos(row)] = (uint8_t)127;
+        if (cols) *reinterpret_cast<uint2*>(fc.q + row * CH + c0) = make_uint2(0u, 0u);
       }
     }
   }
@@ -874,28 +886,47 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_z3_kernel(const bf16_t* __re
           const float sc = tn_e4m3_row_scale(mxq[q]);
           *reinterpret_cast<uint2*>(f8.q + row * CH + c0) = tn_e4m3_pack8(zq[q], 1.f / sc);
           if (c0 == 0) f8.rowexp[tn_rowexp_pos(row)] = tn_e8m0_of_pow2(sc);
+          if (cols) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cmx[u] = fmaxf(cmx[u], fabsf(zq[q][u]));
+            *reinterpret_cast<uint2*>(fc.q + row * CH + c0) = tn_e4m3_pack8_cols(zq[q], csc);
+          }
         }
+      }
+    }
+  }
+  if (OUT8) {
+    if (cols) {      // workgroup-uniform
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cmax[threadIdx.x * 8 + u] = cmx[u];
+      __syncthreads();
+      for (int c = threadIdx.x; c < CH; c += 256) {
+        float m = 0.f;
+        for (int k = 0; k < RG; ++k) m = fmaxf(m, cmax[(k * VC + c / 8) * 8 + (c & 7)]);
+        if (m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(fc.amax_cur) + c, __float_as_uint(m));
       }
     }
   }
 }
 template <int CH>
 inline int launch_bn_bwd_apply_z3_c(const bf16_t* dZ, const bf16_t* Y, const BnBwd& bn, const BnAct& act3, const float* gu, bf16_t* dS, int M,
-                                    int T, hipStream_t st, Fp8Rows f8) {
+                                    int T, hipStream_t st, Fp8Rows f8, Fp8Cols fc) {
   const int chunk = 64;
   const dim3 grid((T + chunk - 1) / chunk, M / T);
   const bool d3 = act3.drop_thr != 0;
-#define TN_Z3(D, O) hipLaunchKernelGGL((bn_bwd_apply_z3_kernel<D, CH, O>), grid, dim3(256), 0, st, dZ, Y, bn, act3, gu, dS, T, chunk, bn.rm.len, f8)
+#define TN_Z3(D, O) hipLaunchKernelGGL((bn_bwd_apply_z3_kernel<D, CH, O>), grid, dim3(256), 0, st, dZ, Y, bn, act3, gu, dS, T, chunk, bn.rm.len, f8, fc)
   if (f8.q) { if (d3) TN_Z3(true, true); else TN_Z3(false, true); }
   else { if (d3) TN_Z3(true, false); else TN_Z3(false, false); }
 #undef TN_Z3
   return (int)hipGetLastError();
 }
 inline int launch_bn_bwd_apply_z3(const bf16_t* dZ, const bf16_t* Y, const BnBwd& bn, const BnAct& act3, const float* gu, bf16_t* dS, int M,
-                                  int C, int T, hipStream_t st, Fp8Rows f8 = Fp8Rows{nullptr, nullptr}) {
+                                  int C, int T, hipStream_t st, Fp8Rows f8 = Fp8Rows{nullptr, nullptr},
+                                  Fp8Cols fc = Fp8Cols{nullptr, nullptr, nullptr, nullptr}) {
   if (act3.mode == 0 || !act3.relu || M % T) return TN_E_UNSUPPORTED;
-  if (C == 512) return launch_bn_bwd_apply_z3_c<512>(dZ, Y, bn, act3, gu, dS, M, T, st, f8);
-  if (C == 1024) return launch_bn_bwd_apply_z3_c<1024>(dZ, Y, bn, act3, gu, dS, M, T, st, f8);
+  if (!f8.q) fc.q = nullptr;
+  if (C == 512) return launch_bn_bwd_apply_z3_c<512>(dZ, Y, bn, act3, gu, dS, M, T, st, f8, fc);
+  if (C == 1024) return launch_bn_bwd_apply_z3_c<1024>(dZ, Y, bn, act3, gu, dS, M, T, st, f8, fc);
   return TN_E_UNSUPPORTED;
 }
 
