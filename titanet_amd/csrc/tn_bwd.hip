@@ -109,7 +109,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   auto pipe_layer = [&](size_t dz, size_t y, const BnRef& bn, int Cout, const WcRef& wc, int Cin, size_t dx_out, const void* q, bool q_plain,
                         const BnAct& qact, int64_t wgrad_off, bool ds_ready = false, bool defer_tn = false,
                         Fp8Rows f8rows = Fp8Rows{nullptr, nullptr}, size_t w8t = 0, size_t w8ts = 0,
-                        Fp8Cols fcols = Fp8Cols{nullptr, nullptr, nullptr, nullptr}) -> int {
+                        Fp8Cols fcols = Fp8Cols{nullptr, nullptr, nullptr, nullptr, 0}) -> int {
     DBG("pipe dZ in", dz, (size_t)M * Cout); DBG("pipe Y", y, (size_t)M * Cout);
     DBGF("pipe bsums", ws + p->bsums[bn.id], TN_NREP * 2 * Cout); DBGF("pipe fstats", ws + p->stats[bn.id], TN_NREP * 2 * Cout);
     int rc = 0;
@@ -158,8 +158,11 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   const bool f8_wgrad = tn_batched && p->fp8_wgrad && p->tn_f8_table != 0 && training;
   const bool f8_wgrad_now = f8_wgrad && p->fp8_hist_valid;
   auto fcols_of = [&](const BlockWs& bw_, int j) -> Fp8Cols {
-    if (!f8_wgrad || bw_.dS8c.empty()) return Fp8Cols{nullptr, nullptr, nullptr, nullptr};
-    return Fp8Cols{(uint8_t*)(ws + bw_.dS8c[j]), (const float*)(ws + bw_.amax_prev[j]), (float*)(ws + bw_.amax_cur[j]), (uint8_t*)(ws + bw_.cexp[j])};
+    if (!f8_wgrad || bw_.dS8c.empty()) return Fp8Cols{nullptr, nullptr, nullptr, nullptr, 0};
+    // (skip_bf16: with the maxima on record the data gradient reads the row-scaled copy and the weight gradient the column-scaled
+    //  one — the in-place pass then stores no bf16 dS at all: 2 of the 4 bytes it writes per element)
+    return Fp8Cols{(uint8_t*)(ws + bw_.dS8c[j]), (const float*)(ws + bw_.amax_prev[j]), (float*)(ws + bw_.amax_cur[j]), (uint8_t*)(ws + bw_.cexp[j]),
+                   f8_wgrad_now ? 1 : 0};
   };
   // table layout (plan_upload_bwd_tables): blocks from the last down, per block the skip conv (blocks > 0), then the
   // sub-blocks from the last down
@@ -648,7 +651,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         const bool f8 = p->fp8_bwd && !bw.w8t.empty();
         int rc = pipe_layer(bw.dY[j], bw.Y[j], sb.bn, H, bw.wpw[j], H, p->dD, ws + bw.Q[j], true, identity_act(), sb.wpw,
                             z3, tn_batched, f8 ? Fp8Rows{(uint8_t*)(ws + p->ds8), (uint8_t*)(ws + p->dsexp)} : Fp8Rows{nullptr, nullptr},
-                            f8 ? bw.w8t[j] : 0, f8 ? bw.w8ts[j] : 0, f8 ? fcols_of(bw, j) : Fp8Cols{nullptr, nullptr, nullptr, nullptr});
+                            f8 ? bw.w8t[j] : 0, f8 ? bw.w8ts[j] : 0, f8 ? fcols_of(bw, j) : Fp8Cols{nullptr, nullptr, nullptr, nullptr, 0});
         if (rc) return rc;
       } else {
         GemmShape g{M, H, H, wt(bw.wpw[j])};

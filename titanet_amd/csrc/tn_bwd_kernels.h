@@ -1371,7 +1371,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ 
         }
       }
     }
-    if (!oob) store8(dZ + i * 8, z);
+    if (!oob && !(OUT8 && cols && fc.skip_bf16)) store8(dZ + i * 8, z);
   }
   if (OUT8) {
     if (cols) {      // workgroup-uniform
@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ 
 }
 // emu8: the e4m3 round trip in place (experiment);  f8: also write the fp8 operand (q != null)
 inline int launch_bn_bwd_apply(bf16_t* dZ, const bf16_t* Y, const BnBwd& bn, int M, int C, hipStream_t st, bool emu8 = false, Fp8Rows f8 = Fp8Rows{nullptr, nullptr},
-                               const int* rowtiles = nullptr, int n_rowtiles = 0, Fp8Cols fc = Fp8Cols{nullptr, nullptr, nullptr, nullptr}) {
+                               const int* rowtiles = nullptr, int n_rowtiles = 0, Fp8Cols fc = Fp8Cols{nullptr, nullptr, nullptr, nullptr, 0}) {
   if (C % 8 || C > 4096) return TN_E_UNSUPPORTED;
   if (!bn.rm.len || n_rowtiles <= 0) { rowtiles = nullptr; n_rowtiles = 0; }
   const bool rows_ok = (C == 512 || C == 1024) && ((size_t)M * (C / 8)) % 256 == 0;

@@ -327,7 +327,7 @@ struct Fp8Rows { uint8_t* q; uint8_t* rowexp; };      // [M][C] e4m3 bytes, [cei
 // beyond are clamped to +-448); the pass that writes the bytes also takes this step's maxima (amax_cur, zeroed by the caller,
 // atomicMax on the float bits) and the E8M0 byte per column that undoes the scale (cexp: the A block-scale operand of
 // pgemm_tn_f8_batched_kernel).  q == null: off.
-struct Fp8Cols { uint8_t* q; const float* amax_prev; float* amax_cur; uint8_t* cexp; };
+struct Fp8Cols { uint8_t* q; const float* amax_prev; float* amax_cur; uint8_t* cexp; int skip_bf16; };      // skip_bf16: both fp8 copies are the only ones read — the bf16 dS is not stored
 // power-of-two scale for a column whose previous maximum was amax: 2^floor(log2(56 / amax)), exponent within +-60; 1 without history
 __device__ __forceinline__ float tn_e4m3_col_scale(float amax) {
   if (!(amax > 0.f)) return 1.f;

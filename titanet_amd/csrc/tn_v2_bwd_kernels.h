@@ -922,7 +922,7 @@ inline int launch_bn_bwd_apply_z3_c(const bf16_t* dZ, const bf16_t* Y, const BnB
 }
 inline int launch_bn_bwd_apply_z3(const bf16_t* dZ, const bf16_t* Y, const BnBwd& bn, const BnAct& act3, const float* gu, bf16_t* dS, int M,
                                   int C, int T, hipStream_t st, Fp8Rows f8 = Fp8Rows{nullptr, nullptr},
-                                  Fp8Cols fc = Fp8Cols{nullptr, nullptr, nullptr, nullptr}) {
+                                  Fp8Cols fc = Fp8Cols{nullptr, nullptr, nullptr, nullptr, 0}) {
   if (act3.mode == 0 || !act3.relu || M % T) return TN_E_UNSUPPORTED;
   if (!f8.q) fc.q = nullptr;
   if (C == 512) return launch_bn_bwd_apply_z3_c<512>(dZ, Y, bn, act3, gu, dS, M, T, st, f8, fc);
