@@ -43,9 +43,12 @@ extern "C" {
                                       output channel (unit block scales);
                             backward  (hidden 512 / 1024) the data gradients dS * W of the sub-blocks and of the skip
                                       connections: dS rows as e4m3 with one power-of-two scale per row, passed as the MFMA's
-                                      own block-scale operand; W^T rows with one scale per input channel.
-                          Storage, statistics, the weight gradients, the depthwise / SE arithmetic and the 1536-wide decoder
-                          GEMMs are the bf16 plan's. */
+                                      own block-scale operand; W^T rows with one scale per input channel;
+                                      the WEIGHT gradients dS^T * Q of the sub-blocks: dS as e4m3 with one power-of-two scale per
+                                      COLUMN (delayed scaling: the column maxima of the plan's previous backward; its first
+                                      backward runs this product in bf16 and records them), the kept e4m3 depthwise outputs.
+                          Storage, statistics, the skip connections' weight gradients, the depthwise / SE arithmetic and the
+                          1536-wide decoder GEMMs are the bf16 plan's. */
 #define TN_PREC_FP8_FWD 3 /* TN_PREC_FP8 with the whole backward pass in bf16 (forward GEMMs only on the fp8 matrix cores) */
 
 #define TN_LOSS_NONE 0
