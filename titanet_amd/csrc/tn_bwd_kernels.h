@@ -1299,90 +1299,116 @@ __global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const float* __restr
 // (a contraction over rows: per-row scales do not factor out of it).
 // rowtiles (variable-length batches): the 256-row tiles with valid frames (PGemmNtArgs::rowtiles) — the pass then walks only
 // those; null = all M rows.
-template <int MODE>
+// NV (round 5): 8-channel vectors per thread (vector v of lane l: channels 8 l + v * C / NV ..).  NV = 2 at 1024 channels with
+// fp8 outputs: a row is then ONE wave and the row maximum a wave reduction (with one vector per thread it crossed two waves
+// through LDS between two workgroup barriers — per row).
+template <int MODE, int NV = 1>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ dZ, const bf16_t* __restrict__ Y, BnBwd bn, int M, int C, Fp8Rows f8,
                                                            const int* __restrict__ rowtiles, int n_rowtiles, Fp8Cols fc) {
   constexpr bool EMU8 = MODE == 1, OUT8 = MODE == 2;
-  extern __shared__ __attribute__((aligned(16))) float pg_k[];      // k0, k1, k2 : [3][C]
+  extern __shared__ __attribute__((aligned(16))) float pg_k[];      // k0, k1, k2 : [3][C]  (+ the column scales [C] with OUT8)
   __shared__ float wmax[4];
-  __shared__ float cmax[OUT8 ? 256 * 8 : 1];                        // per-thread column maxima (fp8 weight gradient)
-  for (int c = threadIdx.x; c < C; c += 256) bn_bwd_coefs(bn, C, c, pg_k[c], pg_k[C + c], pg_k[2 * C + c]);
-  __syncthreads();
-  const int VC = C / 8;
-  // fp8 weight gradient: a thread keeps ONE set of 8 columns for the whole loop (the grid stride is a multiple of VC): their
-  // scales from the previous step's maxima, and this step's maxima
+  __shared__ float cmax[OUT8 ? 256 * 8 * NV : 1];                   // per-thread column maxima (fp8 weight gradient)
   const bool cols = OUT8 && fc.q != nullptr;
-  const int cfix = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % VC) * 8;
-  float csc[8], cmx[8];
-  if (OUT8) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { csc[u] = cols ? tn_e4m3_col_scale(fc.amax_prev[cfix + u]) : 1.f; cmx[u] = 0.f; }
-    if (cols && blockIdx.x == 0 && threadIdx.x < VC) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) fc.cexp[cfix + u] = (uint8_t)(254u - ((__float_as_uint(csc[u]) >> 23) & 0xffu));      // E8M0 of 1 / scale
+  float* csc_l = pg_k + 3 * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    bn_bwd_coefs(bn, C, c, pg_k[c], pg_k[C + c], pg_k[2 * C + c]);
+    if (OUT8) {
+      // fp8 weight gradient: the column's scale from the previous step's maximum, and the E8M0 byte that undoes it
+      const float sc_ = cols ? tn_e4m3_col_scale(fc.amax_prev[c]) : 1.f;
+      csc_l[c] = sc_;
+      if (cols && blockIdx.x == 0) fc.cexp[c] = (uint8_t)(254u - ((__float_as_uint(sc_) >> 23) & 0xffu));
     }
   }
-  const size_t nvec = (size_t)(rowtiles ? n_rowtiles * 256 : M) * VC;
-  for (size_t iv = (size_t)blockIdx.x * 256 + threadIdx.x; iv < nvec; iv += (size_t)gridDim.x * 256) {
-    const int c0 = (int)(iv % VC) * 8;
+  __syncthreads();
+  const int VC = C / 8 / NV;                 // threads per row
+  const int VS = VC * 8;                     // channel distance between a thread's vectors
+  // a thread keeps ONE set of columns for the whole loop (the grid stride is a multiple of VC): this step's maxima of them
+  float cmx[NV][8];
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) cmx[v][u] = 0.f;
+  const size_t nslot = (size_t)(rowtiles ? n_rowtiles * 256 : M) * VC;
+  for (size_t iv = (size_t)blockIdx.x * 256 + threadIdx.x; iv < nslot; iv += (size_t)gridDim.x * 256) {
+    const int cl = (int)(iv % VC) * 8;
     const uint32_t vr = (uint32_t)(iv / VC);
     const uint32_t row = rowtiles ? (uint32_t)rowtiles[vr >> 8] * 256u + (vr & 255u) : vr;
     const bool oob = row >= (uint32_t)M;                 // the last listed tile may reach past the tensor
-    const size_t i = (size_t)row * VC + (size_t)(iv % VC);      // vector index in the tensor
-    float z[8], y[8];
     const bool padrow = oob || (bn.rm.len && !tn_row_valid(bn.rm, row));     // padding rows carry no gradient (uniform per row)
+    float z[NV][8];
     if (MODE == 0 && padrow) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) z[u] = 0.f;
-      if (!oob) store8(dZ + i * 8, z);
+      for (int v = 0; v < NV; ++v) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) z[v][u] = 0.f;
+        if (!oob) store8(dZ + (size_t)row * C + cl + v * VS, z[v]);
+      }
       continue;
     }
-    if (!padrow) {
-      load8(dZ + i * 8, z);
-      load8(Y + i * 8, y);
+    float m = 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) z[u] = fmaf(pg_k[c0 + u], z[u], fmaf(pg_k[C + c0 + u], y[u], pg_k[2 * C + c0 + u]));
-    } else {
+    for (int v = 0; v < NV; ++v) {
+      const int c0 = cl + v * VS;
+      if (!padrow) {
+        float y[8];
+        load8(dZ + (size_t)row * C + c0, z[v]);
+        load8(Y + (size_t)row * C + c0, y);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) z[u] = 0.f;
+        for (int u = 0; u < 8; ++u) z[v][u] = fmaf(pg_k[c0 + u], z[v][u], fmaf(pg_k[C + c0 + u], y[u], pg_k[2 * C + c0 + u]));
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) z[v][u] = 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m = fmaxf(m, fabsf(z[v][u]));
     }
     if (EMU8 || OUT8) {
-      // (every thread of the workgroup is in this iteration: the row count x VC is a multiple of 256, launch_bn_bwd_apply)
-      float m = 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) m = fmaxf(m, fabsf(z[u]));
       m = wave_max(m);
-      if (VC == 128) {                      // hidden 1024: a row is two waves
-        const int w = threadIdx.x >> 6;
+      if (VC == 128) {                      // a row is two waves (every thread of the workgroup is in this iteration: the slot
+        const int w = threadIdx.x >> 6;     // count is a multiple of 256, launch_bn_bwd_apply)
         wmax[w] = m;
         __syncthreads();
         m = fmaxf(m, wmax[w ^ 1]);
         __syncthreads();
       }
       const float sc = tn_e4m3_row_scale(m);
-      if (EMU8) tn_e4m3_roundtrip8(z, sc, 1.f / sc);
-      if (OUT8 && !oob) {
-        *reinterpret_cast<uint2*>(f8.q + i * 8) = tn_e4m3_pack8(z, 1.f / sc);
-        if (c0 == 0) f8.rowexp[tn_rowexp_pos(row)] = tn_e8m0_of_pow2(sc);
-        if (cols) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u) cmx[u] = fmaxf(cmx[u], fabsf(z[u]));
-          *reinterpret_cast<uint2*>(fc.q + i * 8) = tn_e4m3_pack8_cols(z, csc);
+      for (int v = 0; v < NV; ++v) {
+        const int c0 = cl + v * VS;
+        if (EMU8) tn_e4m3_roundtrip8(z[v], sc, 1.f / sc);
+        if (OUT8 && !oob) {
+          *reinterpret_cast<uint2*>(f8.q + (size_t)row * C + c0) = tn_e4m3_pack8(z[v], 1.f / sc);
+          if (cols) {
+            float cs8[8];
+            *reinterpret_cast<float4*>(cs8) = *reinterpret_cast<const float4*>(csc_l + c0);
+            *reinterpret_cast<float4*>(cs8 + 4) = *reinterpret_cast<const float4*>(csc_l + c0 + 4);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cmx[v][u] = fmaxf(cmx[v][u], fabsf(z[v][u]));
+            *reinterpret_cast<uint2*>(fc.q + (size_t)row * C + c0) = tn_e4m3_pack8_cols(z[v], cs8);
+          }
         }
       }
+      if (OUT8 && !oob && cl == 0) f8.rowexp[tn_rowexp_pos(row)] = tn_e8m0_of_pow2(sc);
     }
-    if (!oob && !(OUT8 && cols && fc.skip_bf16)) store8(dZ + i * 8, z);
+    if (!oob && !(OUT8 && cols && fc.skip_bf16)) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) store8(dZ + (size_t)row * C + cl + v * VS, z[v]);
+    }
   }
   if (OUT8) {
     if (cols) {      // workgroup-uniform
 #pragma unroll
-      for (int u = 0; u < 8; ++u) cmax[threadIdx.x * 8 + u] = cmx[u];
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cmax[(threadIdx.x * NV + v) * 8 + u] = cmx[v][u];
       __syncthreads();
-      // thread t holds columns 8 (t % VC) ..: column c lives in threads (c / 8) + k VC, k < 256 / VC
+      // column c = vector v (c / VS) of the row's thread (c % VS) / 8, held by the threads k VC + that one, k < 256 / VC
       for (int c = threadIdx.x; c < C; c += 256) {
-        float m = 0.f;
-        for (int k = 0; k < 256 / VC; ++k) m = fmaxf(m, cmax[(k * VC + c / 8) * 8 + (c & 7)]);
-        if (m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(fc.amax_cur) + c, __float_as_uint(m));
+        const int v = c / VS, ln = (c % VS) / 8;
+        float mm = 0.f;
+        for (int k = 0; k < 256 / VC; ++k) mm = fmaxf(mm, cmax[((k * VC + ln) * NV + v) * 8 + (c & 7)]);
+        if (mm > 0.f) atomicMax(reinterpret_cast<unsigned int*>(fc.amax_cur) + c, __float_as_uint(mm));
       }
     }
   }
@@ -1394,11 +1420,14 @@ inline int launch_bn_bwd_apply(bf16_t* dZ, const bf16_t* Y, const BnBwd& bn, int
   if (!bn.rm.len || n_rowtiles <= 0) { rowtiles = nullptr; n_rowtiles = 0; }
   const bool rows_ok = (C == 512 || C == 1024) && ((size_t)M * (C / 8)) % 256 == 0;
   if (f8.q && !rows_ok) return TN_E_UNSUPPORTED;
-  if (f8.q)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C, f8, rowtiles, n_rowtiles, fc);
+  const size_t smem = (size_t)(f8.q ? 4 : 3) * C * sizeof(float);
+  if (f8.q && C == 1024)      // one wave per row: two vectors per thread
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<2, 2>), dim3(2048), dim3(256), smem, st, dZ, Y, bn, M, C, f8, rowtiles, n_rowtiles, fc);
+  else if (f8.q)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<2, 1>), dim3(2048), dim3(256), smem, st, dZ, Y, bn, M, C, f8, rowtiles, n_rowtiles, fc);
   else if (emu8 && !bn.rm.len && rows_ok)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C, f8, rowtiles, n_rowtiles, fc);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<1, 1>), dim3(2048), dim3(256), smem, st, dZ, Y, bn, M, C, f8, rowtiles, n_rowtiles, fc);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(2048), dim3(256), (size_t)3 * C * sizeof(float), st, dZ, Y, bn, M, C, f8, rowtiles, n_rowtiles, fc);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<0, 1>), dim3(2048), dim3(256), smem, st, dZ, Y, bn, M, C, f8, rowtiles, n_rowtiles, fc);
   return (int)hipGetLastError();
 }

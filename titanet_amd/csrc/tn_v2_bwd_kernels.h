@@ -777,99 +777,125 @@ inline int launch_combine_bwd1_v3(const CombineBwd1V3Args& aa, int B, int C, hip
 // utterance's ga / ub — in registers and walks the chunk's rows (a flat grid-stride loop re-read ga / ub, 64 bytes of
 // float32 per 16 bytes of gradient, for every vector: 79 us against 47 for the plain pass at hidden 512).
 // OUT8 (fp8 plans): dS also as e4m3 bytes with one power-of-two scale per row + the exponent bytes (Fp8Rows, tn_common.h)
-template <bool DROP3, int CH, bool OUT8>
+// NV (round 5): 8-channel vectors per lane.  NV = 2 at 1024 channels with fp8 outputs: ONE wave then holds a whole row (lane l:
+// channels 8 l .. and 512 + 8 l ..), so the row maximum of the e4m3 row scale is a wave reduction — with one vector per lane a
+// row is two waves and every U rows cost an LDS exchange between two workgroup barriers (200 us per launch against 116 for the
+// bf16-only pass).
+template <bool DROP3, int CH, bool OUT8, int NV = 1>
 __global__ __launch_bounds__(256) void bn_bwd_apply_z3_kernel(const bf16_t* __restrict__ dZ, const bf16_t* __restrict__ Y, BnBwd bn, BnAct act3,
                                                               const float* __restrict__ gu, bf16_t* __restrict__ dS, int T, int chunk,
                                                               const int* __restrict__ len, Fp8Rows f8, Fp8Cols fc) {
-  constexpr int VC = CH / 8, RG = 256 / VC;       // channel vectors per row, row groups per workgroup
+  constexpr int VC = CH / 8 / NV, RG = 256 / VC;       // lanes per row, row groups per workgroup
+  constexpr int VS = VC * 8;                            // channel distance between a lane's vectors
+  constexpr bool XWAVE = OUT8 && VC > 64;               // a row spans two waves: row maxima through LDS
   __shared__ __attribute__((aligned(16))) float pg_k[5 * CH];      // k0, k1, k2, sc3, sh3
   __shared__ float wmax[4][4];
-  __shared__ float cmax[OUT8 ? 256 * 8 : 1];      // per-thread column maxima (fp8 weight gradient, Fp8Cols)
+  __shared__ float cmax[OUT8 ? 256 * 8 * NV : 1];      // per-thread column maxima (fp8 weight gradient, Fp8Cols)
   for (int c = threadIdx.x; c < CH; c += 256) {
     bn_bwd_coefs(bn, CH, c, pg_k[c], pg_k[CH + c], pg_k[2 * CH + c]);
     bn_scale_shift(act3, CH, c, pg_k[3 * CH + c], pg_k[4 * CH + c]);
   }
   __syncthreads();
   const uint32_t dkey3 = tn_act_key(act3), dthr3 = act3.drop_thr;
-  const int b = blockIdx.y, vc = threadIdx.x % VC, rg = threadIdx.x / VC, c0 = vc * 8;
-  float k0[8], k1[8], k2[8], s3[8], h3[8], ga[8], ub[8];
+  const int b = blockIdx.y, vc = threadIdx.x % VC, rg = threadIdx.x / VC, c0 = vc * 8;      // vector v of the lane: channels c0 + v VS ..
+  float k0[NV][8], k1[NV][8], k2[NV][8], s3[NV][8], h3[NV][8], ga[NV][8], ub[NV][8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    k0[u] = pg_k[c0 + u]; k1[u] = pg_k[CH + c0 + u]; k2[u] = pg_k[2 * CH + c0 + u]; s3[u] = pg_k[3 * CH + c0 + u]; h3[u] = pg_k[4 * CH + c0 + u];
-  }
-  load8(gu + (size_t)b * 2 * CH + c0, ga);
-  load8(gu + (size_t)b * 2 * CH + CH + c0, ub);
-  const bool cols = OUT8 && fc.q != nullptr;
-  float csc[8], cmx[8];
-  if (OUT8) {
+  for (int v = 0; v < NV; ++v) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { csc[u] = cols ? tn_e4m3_col_scale(fc.amax_prev[c0 + u]) : 1.f; cmx[u] = 0.f; }
-    if (cols && blockIdx.x == 0 && blockIdx.y == 0 && rg == 0) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) fc.cexp[c0 + u] = (uint8_t)(254u - ((__float_as_uint(csc[u]) >> 23) & 0xffu));      // E8M0 of 1 / scale
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + v * VS + u;
+      k0[v][u] = pg_k[c]; k1[v][u] = pg_k[CH + c]; k2[v][u] = pg_k[2 * CH + c]; s3[v][u] = pg_k[3 * CH + c]; h3[v][u] = pg_k[4 * CH + c];
     }
+    load8(gu + (size_t)b * 2 * CH + c0 + v * VS, ga[v]);
+    load8(gu + (size_t)b * 2 * CH + CH + c0 + v * VS, ub[v]);
   }
+  const bool cols = OUT8 && fc.q != nullptr;
+  // column scales of the fp8 weight gradient: in LDS (16 more registers per lane would spill the NV = 2 form)
+  __shared__ __attribute__((aligned(16))) float csc_l[OUT8 ? CH : 1];
+  float cmx[NV][8];
+  if (OUT8) {
+    for (int c = threadIdx.x; c < CH; c += 256) {
+      const float sc_ = cols ? tn_e4m3_col_scale(fc.amax_prev[c]) : 1.f;
+      csc_l[c] = sc_;
+      if (cols && blockIdx.x == 0 && blockIdx.y == 0) fc.cexp[c] = (uint8_t)(254u - ((__float_as_uint(sc_) >> 23) & 0xffu));      // E8M0 of 1 / scale
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cmx[v][u] = 0.f;
+  }
+  const bool keep16 = !(OUT8 && cols && fc.skip_bf16);      // (both fp8 copies are the only ones read: no bf16 dS)
   const int t0 = blockIdx.x * chunk, t_end = min(T, t0 + chunk);
   const int t1 = len ? min(t_end, len[b]) : t_end;       // padding frames of a variable-length batch: dS = 0 (written below)
   if (len) {
     const uint4 z4 = make_uint4(0, 0, 0, 0);
     for (int t = max(t0, t1) + rg; t < t_end; t += RG) {
       const size_t row = (size_t)b * T + t;
-      *reinterpret_cast<uint4*>(dS + row * CH + c0) = z4;
-      if (OUT8) {
-        *reinterpret_cast<uint2*>(f8.q + row * CH + c0) = make_uint2(0u, 0u);
-        if (c0 == 0) f8.rowexp[tn_rowexp_pos(row)] = (uint8_t)127;
-        if (cols) *reinterpret_cast<uint2*>(fc.q + row * CH + c0) = make_uint2(0u, 0u);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        if (keep16) *reinterpret_cast<uint4*>(dS + row * CH + c0 + v * VS) = z4;
+        if (OUT8) {
+          *reinterpret_cast<uint2*>(f8.q + row * CH + c0 + v * VS) = make_uint2(0u, 0u);
+          if (cols) *reinterpret_cast<uint2*>(fc.q + row * CH + c0 + v * VS) = make_uint2(0u, 0u);
+        }
       }
+      if (OUT8 && c0 == 0) f8.rowexp[tn_rowexp_pos(row)] = (uint8_t)127;
     }
   }
-  constexpr int U = 4;
-  // (tb is uniform over the workgroup: the row maximum of the fp8 output crosses two waves at 1024 channels)
+  constexpr int U = NV == 1 ? 4 : 2;
+  // (tb is uniform over the workgroup: with XWAVE the row maximum of the fp8 output crosses two waves)
   for (int tb = t0; tb < t1; tb += RG * U) {
-    uint4 rz[U], ry[U];
+    uint4 rz[U][NV], ry[U][NV];
 #pragma unroll
     for (int q = 0; q < U; ++q) {
       const int t = tb + rg + RG * q;
       if (t < t1) {
-        const size_t o = ((size_t)b * T + t) * CH + c0;
-        rz[q] = *reinterpret_cast<const uint4*>(dZ + o);
-        ry[q] = *reinterpret_cast<const uint4*>(Y + o);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const size_t o = ((size_t)b * T + t) * CH + c0 + v * VS;
+          rz[q][v] = *reinterpret_cast<const uint4*>(dZ + o);
+          ry[q][v] = *reinterpret_cast<const uint4*>(Y + o);
+        }
       }
     }
-    float zq[OUT8 ? U : 1][8], mxq[U];
+    float zq[OUT8 ? U : 1][NV][8], mxq[U];
 #pragma unroll
     for (int q = 0; q < U; ++q) {
       const int t = tb + rg + RG * q;
       const bool live = t < t1;
       const uint32_t row = (uint32_t)b * T + t;
-      float z[8];
-      if (live) {
-        float y[8], m[8];
-        unpack8(rz[q], z);
-        unpack8(ry[q], y);
+      float mx = 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) m[u] = (fmaf(y[u], s3[u], h3[u]) > 0.f) ? 1.f : 0.f;
-        if (DROP3) tn_drop8(m, (row * (uint32_t)CH + (uint32_t)c0) >> 3, dkey3, dthr3);
+      for (int v = 0; v < NV; ++v) {
+        float z[8];
+        if (live) {
+          float y[8], m[8];
+          unpack8(rz[q][v], z);
+          unpack8(ry[q][v], y);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const float v = fmaf(z[u], ga[u], ub[u]) * m[u];
-          z[u] = fmaf(k0[u], v, fmaf(k1[u], y[u], k2[u]));
+          for (int u = 0; u < 8; ++u) m[u] = (fmaf(y[u], s3[v][u], h3[v][u]) > 0.f) ? 1.f : 0.f;
+          if (DROP3) tn_drop8(m, (row * (uint32_t)CH + (uint32_t)(c0 + v * VS)) >> 3, dkey3, dthr3);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float w = fmaf(z[u], ga[v][u], ub[v][u]) * m[u];
+            z[u] = fmaf(k0[v][u], w, fmaf(k1[v][u], y[u], k2[v][u]));
+          }
+          if (keep16) store8(dS + (size_t)row * CH + c0 + v * VS, z);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) z[u] = 0.f;
         }
-        store8(dS + (size_t)row * CH + c0, z);
-      } else {
+        if (OUT8) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) z[u] = 0.f;
+          for (int u = 0; u < 8; ++u) { mx = fmaxf(mx, fabsf(z[u])); zq[q][v][u] = z[u]; }
+        }
       }
-      if (OUT8) {
-        float mx = 0.f;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { mx = fmaxf(mx, fabsf(z[u])); zq[q][u] = z[u]; }
-        mxq[q] = wave_max(mx);
-      }
+      if (OUT8) mxq[q] = wave_max(mx);
     }
     if (OUT8) {
-      // row maxima of the U rows: at 1024 channels a row is two waves — ONE exchange for all of them
-      if (VC == 128) {
+      if (XWAVE) {
+        // row maxima of the U rows across the two waves of a row: ONE exchange for all of them
         const int w = threadIdx.x >> 6;
 #pragma unroll
         for (int q = 0; q < U; ++q) wmax[w][q] = mxq[q];
@@ -884,13 +910,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_z3_kernel(const bf16_t* __re
         if (t < t1) {
           const size_t row = (size_t)b * T + t;
           const float sc = tn_e4m3_row_scale(mxq[q]);
-          *reinterpret_cast<uint2*>(f8.q + row * CH + c0) = tn_e4m3_pack8(zq[q], 1.f / sc);
-          if (c0 == 0) f8.rowexp[tn_rowexp_pos(row)] = tn_e8m0_of_pow2(sc);
-          if (cols) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) cmx[u] = fmaxf(cmx[u], fabsf(zq[q][u]));
-            *reinterpret_cast<uint2*>(fc.q + row * CH + c0) = tn_e4m3_pack8_cols(zq[q], csc);
+          for (int v = 0; v < NV; ++v) {
+            *reinterpret_cast<uint2*>(f8.q + row * CH + c0 + v * VS) = tn_e4m3_pack8(zq[q][v], 1.f / sc);
+            if (cols) {
+#pragma unroll
+              for (int u = 0; u < 8; ++u) cmx[v][u] = fmaxf(cmx[v][u], fabsf(zq[q][v][u]));
+              float cs8[8];
+              *reinterpret_cast<float4*>(cs8) = *reinterpret_cast<const float4*>(csc_l + c0 + v * VS);
+              *reinterpret_cast<float4*>(cs8 + 4) = *reinterpret_cast<const float4*>(csc_l + c0 + v * VS + 4);
+              *reinterpret_cast<uint2*>(fc.q + row * CH + c0 + v * VS) = tn_e4m3_pack8_cols(zq[q][v], cs8);
+            }
           }
+          if (c0 == 0) f8.rowexp[tn_rowexp_pos(row)] = tn_e8m0_of_pow2(sc);
         }
       }
     }
@@ -898,11 +930,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_z3_kernel(const bf16_t* __re
   if (OUT8) {
     if (cols) {      // workgroup-uniform
 #pragma unroll
-      for (int u = 0; u < 8; ++u) cmax[threadIdx.x * 8 + u] = cmx[u];
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cmax[(threadIdx.x * NV + v) * 8 + u] = cmx[v][u];
       __syncthreads();
+      // column c = vector v (c / VS) of lane (c % VS) / 8, held by the threads k VC + that lane, k < RG
       for (int c = threadIdx.x; c < CH; c += 256) {
+        const int v = c / VS, ln = (c % VS) / 8;
         float m = 0.f;
-        for (int k = 0; k < RG; ++k) m = fmaxf(m, cmax[(k * VC + c / 8) * 8 + (c & 7)]);
+        for (int k = 0; k < RG; ++k) m = fmaxf(m, cmax[((k * VC + ln) * NV + v) * 8 + (c & 7)]);
         if (m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(fc.amax_cur) + c, __float_as_uint(m));
       }
     }
@@ -914,7 +950,7 @@ inline int launch_bn_bwd_apply_z3_c(const bf16_t* dZ, const bf16_t* Y, const BnB
   const int chunk = 64;
   const dim3 grid((T + chunk - 1) / chunk, M / T);
   const bool d3 = act3.drop_thr != 0;
-#define TN_Z3(D, O) hipLaunchKernelGGL((bn_bwd_apply_z3_kernel<D, CH, O>), grid, dim3(256), 0, st, dZ, Y, bn, act3, gu, dS, T, chunk, bn.rm.len, f8, fc)
+#define TN_Z3(D, O) hipLaunchKernelGGL((bn_bwd_apply_z3_kernel<D, CH, O, ((O) && CH == 1024) ? 2 : 1>), grid, dim3(256), 0, st, dZ, Y, bn, act3, gu, dS, T, chunk, bn.rm.len, f8, fc)
   if (f8.q) { if (d3) TN_Z3(true, true); else TN_Z3(false, true); }
   else { if (d3) TN_Z3(true, false); else TN_Z3(false, false); }
 #undef TN_Z3
