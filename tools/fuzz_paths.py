@@ -32,8 +32,13 @@ def run(mask, cfg):
         lengths[int(torch.randint(0, cfg["B"], (1,), generator=g))] = cfg["T"]
     if cfg["train"]:
         m.train()
-        emb, preds, loss = m(x, speakers=y, lengths=lengths)
-        loss.backward()
+        # (fp8 plans: the pointwise weight gradients run on the f8f6f4 MFMA from the plan's SECOND backward on — delayed column
+        #  scales, include/titanet_amd.h TN_PREC_FP8 — so the same step is run twice and the second gradient is the one compared)
+        for rep in range(2 if cfg.get("prec") == "fp8" else 1):
+            m.zero_grad(set_to_none=False)
+            m._seed_base, m._step = 777, 0
+            emb, preds, loss = m(x, speakers=y, lengths=lengths)
+            loss.backward()
         grad = torch.cat([p.grad.flatten() for p in m.parameters()]).float().cpu()
         return emb.detach().float().cpu(), float(loss), grad
     m.eval()
