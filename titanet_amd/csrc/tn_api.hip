@@ -396,6 +396,12 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     // against 8.81 without — two persistent 256-workgroup grids do not share the chip, the late workgroups of whichever
     // kernel found the CUs taken start when the other kernel's finish and run their whole tile list alone.  TN_OVERLAP=1 (read
     // at plan creation) turns it on for A/B runs.
+    {
+      const char* ef = getenv("TN_ASP_FUSED");
+      const auto& cc = m->cfg;
+      p->asp_fused = !(ef && atoi(ef) == 0) && precision == TN_PREC_BF16 && !p->generic && !cc.simple_pool && cc.enc_out % 256 == 0 &&
+                     cc.attn_hidden == 128 && frames <= ASPV2_PR && p->tail_parts == 1;
+    }
     const char* eo = getenv("TN_OVERLAP");
     p->overlap = p->use_v2 && c.n_mega_blocks > 0 && eo && atoi(eo) != 0;
     if (p->overlap) {
@@ -1022,6 +1028,20 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       rc = gemm_store<AT, ProdPlain, EpiStoreTanh>(g1, pa1, ea1, 0, st);
     }
     if (rc) return rc;
+    bool pooled_done = false;
+    if (attn_v2 && p->asp_fused) {
+      // energies + softmax + statistics in one launch (no energy tensor)
+      AspV2Args fa;
+      memset(&fa, 0, sizeof(fa));
+      fa.HID = (const bf16_t*)(ws + p->HID); fa.W = (const bf16_t*)wsel<AT>(p, m->asp_wout, p->wwout);
+      fa.bias = params + m->asp_bout;
+      fa.E = (const bf16_t*)(ws + p->E); fa.actE = acte;
+      fa.pooled = (float*)(ws + p->pooled); fa.smax = (float*)(ws + p->smax); fa.sinv = (float*)(ws + p->sinv); fa.qv = (float*)(ws + p->qv);
+      fa.stats = statp(m->pool_bn); fa.B = B; fa.T = T; fa.D = D; fa.eps = 1e-6f;
+      rc = launch_asp_v2<0>(fa, st);
+      if (rc) return rc;             // (the plan promised the shape: -1000 here is a bug, not a fallback)
+      pooled_done = true;
+    } else
     if (attn_v2) {
       WideOutArgs wa;
       memset(&wa, 0, sizeof(wa));
@@ -1036,7 +1056,8 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       rc = gemm_store<AT, ProdPlain>(g2, pa2, ea2, 0, st);
     }
     if (rc) return rc;
-    if (p->tail_parts > 1)
+    if (pooled_done) {
+    } else if (p->tail_parts > 1)
       hipLaunchKernelGGL((asp_pool_fwd_kernel<AT, 16, 16>), dim3(B, (D + 127) / 128), dim3(256), 0, st, (const AT*)(ws + p->E), acte,
                          (const AT*)(ws + p->EN), T, D, 1e-6f, (float*)(ws + p->pooled), (float*)(ws + p->smax),
                          (float*)(ws + p->sinv), (float*)(ws + p->qv), statp(m->pool_bn));

@@ -363,6 +363,19 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
                        (const AT*)(ws + p->E), acte, T, D, (AT*)(ws + p->dEbn), bsum(m->epi_bn));
   } else
   {
+    if (attn_v2 && p->asp_fused) {
+      // energies recomputed from the tanh outputs (the forward stored none): d e -> dE, direct d x -> dEbn
+      AspV2Args fa;
+      memset(&fa, 0, sizeof(fa));
+      fa.HID = (const bf16_t*)(ws + p->HID); fa.W = (const bf16_t*)(ws + p->wwout.w);
+      fa.bias = params + m->asp_bout;
+      fa.E = (const bf16_t*)(ws + p->E); fa.actE = acte;
+      fa.pooled = (float*)(ws + p->pooled); fa.smax = (float*)(ws + p->smax); fa.sinv = (float*)(ws + p->sinv); fa.qv = (float*)(ws + p->qv);
+      fa.dpooled = (const float*)(ws + p->dpooled); fa.dEN = (bf16_t*)(ws + p->dE); fa.DXD = (bf16_t*)(ws + p->dEbn);
+      fa.g_bout = grads + m->asp_bout; fa.B = B; fa.T = T; fa.D = D; fa.eps = 1e-6f;
+      int rc = launch_asp_v2<1>(fa, st);
+      if (rc) return rc;
+    } else
     if (p->tail_parts > 1)
       hipLaunchKernelGGL((asp_bwd_de_kernel<AT, 16, 16>), dim3(B, (D + 127) / 128), dim3(256), 0, st, (const AT*)(ws + p->E), acte,
                          (const AT*)(ws + p->EN), T, D, 1e-6f, (const float*)(ws + p->pooled), (const float*)(ws + p->qv),

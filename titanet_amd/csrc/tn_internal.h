@@ -180,6 +180,10 @@ struct tn_plan {
   // skip data gradient beside the last two sub-blocks' fused data-gradient launches (backward) — one kernel's ramp-up fills
   // the other's drain.  Fork / join with plan-owned events; works under stream capture (the side stream joins the capture).
   bool overlap = false;
+  // attentive pooling without a stored energy tensor (asp_v2_kernel, tn_v2_wide_kernels.h): forward and backward recompute
+  // the K = 128 product.  Decided at plan creation (TN_ASP_FUSED=0 keeps the stored-energies kernels; shapes outside the
+  // kernel — frames > 320, several workgroups per utterance — always do): forward and backward must agree.
+  bool asp_fused = false;
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> ov_events;   // [block][4]: forward fork / join, backward fork / join
   // per-kernel event timing (tn_profile_*)

@@ -9,8 +9,10 @@
 // stream that scales with N is the output itself.  Per-channel reductions (BatchNorm statistics / BatchNorm
 // backward sums) stay in registers for a whole slab and cost one replicated atomic per (workgroup, channel).
 #pragma once
+#include <type_traits>
 #include "tn_gemm.h"
 #include "tn_v2_kernels.h"
+#include "tn_pgemm.h"
 
 struct WideOutArgs {
   const bf16_t* X;      // [M][K] A operand (stored final: no activation on load)
@@ -441,3 +443,354 @@ inline int launch_wide_in_v2(WideInArgs a, int max_wgs, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// asp_v2: attentive statistics pooling WITHOUT a stored energy tensor (round 5).  The energies e = W_out hid + b_out
+// (reference src/models.py:562-567; K = 128, [M][1536]) used to be written by wide_out_v2<128, 0> and read back by
+// asp_pool_fwd_kernel / asp_bwd_de_kernel: 3 passes over an A_D-sized tensor (236 MB at 256 x 300) that exist only to carry a
+// K = 128 product between launches.  Here both consumers recompute them: one workgroup per (utterance, group of 256-channel
+// slabs) stages the utterance's tanh outputs ([T <= 320][128] bf16, 82 KB) in LDS once, keeps the slab's 256 x 128 weights in
+// registers as MFMA A fragments, and works on the f32 accumulators IN THEIR MFMA LAYOUT (lane = frame, 16 registers = 16
+// channels): the epilog output E is loaded in that layout, so nothing is staged through LDS and the waves never meet after
+// the staging barrier.  The weight ROWS of a wave's 32-channel block are permuted (MFMA row 8g + 4h + j holds channel
+// 16 (r >> 3) + 8 h + (r & 7), r = 4g + j) so that a lane's 16 accumulator registers are two runs of 8 CONSECUTIVE channels:
+// 16-byte loads / stores, 32 contiguous bytes per frame and instruction (with the natural order a lane owns 4-channel pieces:
+// 8-byte accesses that cover half a 32-byte sector each — the backward kernel wrote its two tensors at 2.3 TB/s).
+// Reductions over time are lane-local until the end of a slab (one 32-lane butterfly per statistic).
+//   MODE 0 (forward): pass 1 = column maxima of the energies (MFMA only), pass 2 = exp / weighted sums -> mean, std, and what
+//           the backward needs (max, 1 / sum, q = sum alpha x^2) + the BatchNorm1d(2D) batch statistics of the pooled vector.
+//   MODE 1 (backward, element-wise part; asp_bwd_de_kernel's math): d e -> dEN, direct d x -> DXD, column sums -> d b_out.
+// Both directions compute the energies with the same MFMA sequence: the softmax weights of the backward are bit-identical to
+// the forward's (with the stored tensor they agreed through the same bf16 rounding).
+// ------------------------------------------------------------------------------------------
+struct AspV2Args {
+  const bf16_t* HID;    // [M][128] tanh outputs
+  const bf16_t* W;      // [D][128] W_out, row = channel
+  const float* bias;    // [D]
+  const bf16_t* E;      // [M][D] raw epilog output
+  BnAct actE;           // its BatchNorm (+ ReLU); rm.len = valid frames per utterance or null
+  float* pooled;        // [B][2D] mean | std            (MODE 1: input)
+  float* smax;          // [B][D] softmax maxima         (MODE 1: input)
+  float* sinv;          // [B][D] 1 / softmax sums       (MODE 1: input)
+  float* qv;            // [B][D] sum alpha x^2          (MODE 1: input)
+  float* stats;         // MODE 0: [TN_NREP][2][2D] batch statistics of `pooled`, or null
+  const float* dpooled; // MODE 1: [B][2D]
+  bf16_t* dEN;          // MODE 1: [M][D] gradient wrt the energies
+  bf16_t* DXD;          // MODE 1: [M][D] direct gradient wrt x = act(E)
+  float* g_bout;        // MODE 1: [D] += column sums of dEN
+  int B, T, D, spw;     // spw: 256-channel slabs per workgroup (divides D / 256)
+  float eps;
+  int force_exact;      // MODE 0 test hook (TN_ASP_EXACT=1): always take the exact-maxima pass
+};
+constexpr int ASPV2_PR = 320;         // frames staged per utterance (T <= ASPV2_PR)
+template <int MODE>
+__global__ __launch_bounds__(V2_NT, 2) void asp_v2_kernel(AspV2Args a) {
+  constexpr int K = 128, AP = K + 8, KS = K / 16, PR = ASPV2_PR, NK = MODE == 0 ? 3 : 6;
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem);                    // [PR][AP] tanh outputs of the utterance
+  float* par = reinterpret_cast<float*>(As + PR * AP);             // [spw][NK][256] per-channel constants
+  __shared__ int wide_range;                                       // MODE 0: some channel's energies may span more than e^64
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int nsg = (a.D / V2_C) / a.spw;
+  const int b = (int)blockIdx.x / nsg, slab0 = ((int)blockIdx.x % nsg) * a.spw;
+  const int L = a.actE.rm.len ? tn_sload_i32(a.actE.rm.len, b) : a.T;       // softmax over the valid frames only
+  const int row0 = b * a.T;
+  if (tid == 0) wide_range = a.force_exact;
+  {
+    constexpr int NSTG = PR * (K / 8) / V2_NT;       // 10
+    uint4 st[NSTG];
+#pragma unroll
+    for (int q = 0; q < NSTG; ++q) {
+      const int v = tid + q * V2_NT, r = v >> 4, cv = v & 15;
+      st[q] = r < L ? *reinterpret_cast<const uint4*>(a.HID + (size_t)(row0 + r) * K + cv * 8) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < NSTG; ++q) {
+      const int v = tid + q * V2_NT, r = v >> 4, cv = v & 15;
+      *reinterpret_cast<uint4*>(As + r * AP + cv * 8) = st[q];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < a.spw * V2_C; i += V2_NT) {
+    const int si = i >> 8, cl = i & 255, c = (slab0 + si) * V2_C + cl;
+    float* pk = par + (size_t)si * NK * V2_C + cl;
+    float sc, sh;
+    bn_scale_shift(a.actE, a.D, c, sc, sh);
+    pk[0] = sc; pk[V2_C] = sh;
+    if (MODE == 0) {
+      // |tanh| <= 1: the channel's energies lie in b_c +- R_c, R_c = sum_a |W[c][a]| — a softmax shift that needs no pass over
+      // the data (the result does not depend on the shift; the backward reads the one used from `smax`).  exp(e - shift) then
+      // spans [e^(-2 R_c), 1]: kept while 2 R_c <= 64 (f32 has e^-87), else the workgroup takes the exact maxima (pass 1 below)
+      float R = 0.f;
+#pragma unroll
+      for (int v = 0; v < K / 8; ++v) {
+        float w[8];
+        unpack8(*reinterpret_cast<const uint4*>(a.W + (size_t)c * K + v * 8), w);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) R += fabsf(w[u]);
+      }
+      if (R > 32.f) wide_range = 1;
+      pk[2 * V2_C] = R * LOG2E;                     // (shift of the bias-free energies: the accumulators start from zero)
+    } else {
+      const size_t o = (size_t)b * a.D + c;
+      const float mu = a.pooled[(size_t)b * 2 * a.D + c], sg = a.pooled[(size_t)b * 2 * a.D + a.D + c];
+      const float q = a.qv[o];
+      const float gmu = a.dpooled[(size_t)b * 2 * a.D + c], gsg = a.dpooled[(size_t)b * 2 * a.D + a.D + c];
+      const float dr = (q - mu * mu > a.eps) ? gsg / (2.f * sg) : 0.f;
+      const float dmu = gmu - 2.f * mu * dr;
+      const float iv = a.sinv[o];
+      pk[2 * V2_C] = (a.smax[o] - (a.bias ? a.bias[c] : 0.f)) * LOG2E;      // alpha = exp2(acc log2e - this) * iv  (bias-free accumulators)
+      pk[3 * V2_C] = iv * (dmu * mu + dr * q);      // d e = p (A1 x + A2 x^2 - A0),  d x = p (A1 + 2 A2 x),  p = alpha / iv
+      pk[4 * V2_C] = iv * dmu;
+      pk[5 * V2_C] = iv * dr;
+    }
+  }
+  __syncthreads();
+  const bool exact_max = MODE == 0 && wide_range != 0;
+  const int ntile = ((MODE == 0 ? L : a.T) + V2_R - 1) / V2_R;
+  const int M = a.B * a.T;
+  const pg_i32x4_t srdE = pg_make_srd(a.E, (unsigned)((size_t)M * a.D * sizeof(bf16_t)));
+  const __amdgpu_buffer_rsrc_t srdN = __builtin_amdgcn_make_buffer_rsrc(a.dEN, 0, MODE == 1 ? (int)((size_t)M * a.D * sizeof(bf16_t)) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdX = __builtin_amdgcn_make_buffer_rsrc(a.DXD, 0, MODE == 1 ? (int)((size_t)M * a.D * sizeof(bf16_t)) : 0, 0x00020000);
+  const int chl = wave * 32 + 8 * half;              // the lane's channels inside a slab: chl + 16 q + k  (register r = 8 q + k)
+  const bool relu = a.actE.relu != 0;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+  // E in the accumulator layout: frame tt + 32 h + l31 (clamped to the last valid frame: never used beyond it), 2 x 16 bytes.
+  // The loads are inline asm with a HAND-COUNTED wait at the end of the step that issues them: left to hipcc, (i) a
+  // conditional prefetch or store makes it wait for everything in flight (vmcnt(0) per tile: 246 us for the backward kernel),
+  // (ii) a copy cur = nxt at the end of the step waits for the prefetch inside the step, (iii) the unpacking of the next
+  // step's pieces floats up into this step and takes its wait along, (iv) at a loop header it merges the entry state (no
+  // stores behind the first loads) with the back edge's (8 stores) and drains the stores every iteration.  The queue at the
+  // end of a step: [the next step's 4 loads, issued at its top] [this step's NST stores] — vmcnt(NST) is exact; every
+  // memory instruction of the loop is unconditional (clamped tile / out-of-range offset instead of a branch).
+  constexpr int NST = MODE == 1 ? 8 : 0;
+  auto e_load = [&](int slab, int tt, u32x4_t (&ex)[2][2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int r = tt + 32 * h + l31;
+      r = r < L ? r : (L > 0 ? L - 1 : 0);
+      const unsigned voff = (unsigned)(((row0 + r) * a.D + chl) * (int)sizeof(bf16_t));
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((slab * V2_C + 16 * q) * (int)sizeof(bf16_t));
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ex[h][q]) : "v"(voff), "s"(srdE), "s"(soff) : "memory");
+      }
+    }
+  };
+  auto tile_mfma = [&](const bf16x8_t (&wf)[KS], int tt, f32x16_t& acc0, f32x16_t& acc1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }      // (the bias lives in the softmax shift)
+    const bf16_t* brow = As + (tt + l31) * AP + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(brow + ks * 16);
+      const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(brow + 32 * AP + ks * 16);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b1, acc1, 0, 0, 0);
+    }
+  };
+  // MFMA row m = l31 of the wave's block <- channel pi(m)
+  const int pim = [&] { const int g = l31 >> 3, hh = (l31 >> 2) & 1, j = l31 & 3, r = 4 * g + j; return 16 * (r >> 3) + 8 * hh + (r & 7); }();
+  for (int si = 0; si < a.spw; ++si) {
+    const int slab = slab0 + si;
+    const float* pk = par + (size_t)si * NK * V2_C;
+    bf16x8_t wf[KS];
+    {
+      const int co = slab * V2_C + wave * 32 + pim;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const bf16x8_t*>(a.W + (size_t)co * K + ks * 16 + half * 8);
+    }
+    u32x4_t ec[2][2], en[2][2] = {};
+    e_load(slab, 0, ec);
+    if (MODE == 0) {
+      if (exact_max) {
+        // ---- pass 1 (rare: see wide_range): column maxima of the energies over the valid frames
+        float mx[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx[r] = -INFINITY;
+        for (int t = 0; t < ntile; ++t) {
+          f32x16_t acc0, acc1;
+          tile_mfma(wf, t * V2_R, acc0, acc1);
+          const bool v0 = t * V2_R + l31 < L, v1 = t * V2_R + 32 + l31 < L;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx[r] = fmaxf(mx[r], fmaxf(v0 ? acc0[r] : -INFINITY, v1 ? acc1[r] : -INFINITY));
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
+        // the wave's own 32 channels of the shift table (no other wave reads them; LDS operations of a wave are in order)
+        if (l31 == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) par[(size_t)si * NK * V2_C + 2 * V2_C + chl + 16 * (r >> 3) + (r & 7)] = mx[r] * LOG2E;
+        }
+      }
+    }
+    // ---- the pass over E
+    float s0[16], s1[16], s2[16];      // MODE 0: sum p, sum p x, sum p x^2;  MODE 1: s0 = column sums of d e
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; s2[r] = 0.f; }
+    // one tile; `cur` holds its E pieces (loaded a tile ago), the next tile's go to `nxt`.  The two register sets swap roles
+    // in a loop unrolled by two: a copy cur = nxt at the end of the step made hipcc wait for the prefetch inside the step
+    auto step = [&](auto pf, int t, u32x4_t (&cur)[2][2], u32x4_t (&nxt)[2][2]) {
+      const int tt = t * V2_R;
+      if constexpr (decltype(pf)::value) e_load(slab, (t + 1 < ntile ? t + 1 : t) * V2_R, nxt);
+      f32x16_t acc[2];
+      tile_mfma(wf, tt, acc[0], acc[1]);
+      // (scheduling fences: left alone hipcc unpacks all 64 E values of the step among the MFMAs — 64 more live registers,
+      //  spills, and with a spill reload in the loop a vmcnt(0) that also drains the prefetch; the other wave of the SIMD fills
+      //  the MFMA shadow instead)
+      __builtin_amdgcn_sched_barrier(0);
+      // the per-channel constants are read from LDS where they are used: hoisted out of the tile loop (they are invariant)
+      // they would occupy 32 (forward) / 96 (backward) registers next to the weight fragments — an opaque offset per tile
+      int kch = chl;
+      asm volatile("" : "+v"(kch));
+      u32x4_t on[2][2], ox[2][2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (q) __builtin_amdgcn_sched_barrier(0);
+        float sc[8], sh[8], mv[8], a0[8], a1[8], a2[8];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          *reinterpret_cast<float4*>(sc + 4 * w) = *reinterpret_cast<const float4*>(pk + kch + 16 * q + 4 * w);
+          *reinterpret_cast<float4*>(sh + 4 * w) = *reinterpret_cast<const float4*>(pk + V2_C + kch + 16 * q + 4 * w);
+          *reinterpret_cast<float4*>(mv + 4 * w) = *reinterpret_cast<const float4*>(pk + 2 * V2_C + kch + 16 * q + 4 * w);
+          if (MODE == 1) {
+            *reinterpret_cast<float4*>(a0 + 4 * w) = *reinterpret_cast<const float4*>(pk + 3 * V2_C + kch + 16 * q + 4 * w);
+            *reinterpret_cast<float4*>(a1 + 4 * w) = *reinterpret_cast<const float4*>(pk + 4 * V2_C + kch + 16 * q + 4 * w);
+            *reinterpret_cast<float4*>(a2 + 4 * w) = *reinterpret_cast<const float4*>(pk + 5 * V2_C + kch + 16 * q + 4 * w);
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bool valid = tt + 32 * h + l31 < L;
+          const float kill = valid ? 0.f : -1000.f;        // exp2(-1000) = 0: padded frames carry no weight
+          float x[8];
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            x[2 * w] = __uint_as_float(cur[h][q][w] << 16);
+            x[2 * w + 1] = __uint_as_float(cur[h][q][w] & 0xffff0000u);
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            x[k] = fmaf(x[k], sc[k], sh[k]);
+            x[k] = relu ? fmaxf(x[k], 0.f) : x[k];
+          }
+          if (MODE == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const int r = 8 * q + k;
+              const float p = __builtin_amdgcn_exp2f(fmaf(acc[h][r], LOG2E, kill - mv[k]));
+              s0[r] += p;
+              const float px = p * x[k];
+              s1[r] += px;
+              s2[r] = fmaf(px, x[k], s2[r]);
+            }
+          } else {
+            float de[8], dx[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float p = __builtin_amdgcn_exp2f(fmaf(acc[h][8 * q + k], LOG2E, kill - mv[k]));
+              const float ax = a2[k] * x[k];
+              de[k] = p * (fmaf(a1[k] + ax, x[k], -a0[k]));
+              dx[k] = p * (a1[k] + 2.f * ax);
+              s0[8 * q + k] += de[k];
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { on[h][q][w] = f2bf_pk(de[2 * w], de[2 * w + 1]); ox[h][q][w] = f2bf_pk(dx[2 * w], dx[2 * w + 1]); }
+          }
+        }
+      }
+      if (MODE == 1) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          // frames [L, T): zeros (p = 0).  Frames >= T belong to the next utterance: an offset beyond the buffer drops the store
+          const int fr = tt + 32 * h + l31;
+          const int voff = fr < a.T ? ((row0 + fr) * a.D + chl) * (int)sizeof(bf16_t) : 0x7ffffff0;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            __builtin_amdgcn_raw_buffer_store_b128(on[h][q], srdN, voff, (slab * V2_C + 16 * q) * (int)sizeof(bf16_t), 0);
+            __builtin_amdgcn_raw_buffer_store_b128(ox[h][q], srdX, voff, (slab * V2_C + 16 * q) * (int)sizeof(bf16_t), 0);
+          }
+        }
+      }
+      // the prefetch has had the whole step to land; it is awaited HERE, at the end of the step that issued it, not at the
+      // top of the one that consumes it: between the two hipcc may COPY the registers (it did, on the way into the peeled last
+      // step: v_mov of pieces still in flight — utterances with garbage statistics, a few per launch)
+      if constexpr (decltype(pf)::value) {
+        if (NST == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(nxt[0][0]), "+v"(nxt[0][1]), "+v"(nxt[1][0]), "+v"(nxt[1][1]) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt[0][0]), "+v"(nxt[0][1]), "+v"(nxt[1][0]), "+v"(nxt[1][1]) : : "memory");
+      }
+    };
+    {
+      // (the first step's loads have no stores behind them: drained here, behind the weights / bias / pass-1 work)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(ec[0][0]), "+v"(ec[0][1]), "+v"(ec[1][0]), "+v"(ec[1][1]) : : "memory");
+      // ... and the COMPILER must see the weight fragments as arrived here: it puts its wait in front of the first use of a
+      // loaded register, which would be the MFMAs inside the loop — vmcnt(7 - ks), i.e. a drain of the prefetch per tile
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wf[ks]));
+      int t = 0;
+      for (; t + 1 < ntile; t += 2) { step(std::true_type{}, t, ec, en); step(std::true_type{}, t + 1, en, ec); }
+      if (t < ntile) step(std::false_type{}, t, ec, en);       // (no prefetch: a load nobody awaits would land in registers
+    }                                                          //  the compiler has handed to other values by then)
+    // ---- end of the slab: the 32 frame lanes of each half add up, lane r of a half then owns channel register r
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] += __shfl_xor(s0[r], o, 64);
+        if (MODE == 0) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
+      }
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, tm = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool me = l31 == r;
+      t0 = me ? s0[r] : t0;
+      if (MODE == 0) { t1 = me ? s1[r] : t1; t2 = me ? s2[r] : t2; }
+    }
+    if (l31 < 16) {
+      const int cg = slab * V2_C + chl + 16 * (l31 >> 3) + (l31 & 7);
+      if (MODE == 0) {
+        tm = pk[2 * V2_C + chl + 16 * (l31 >> 3) + (l31 & 7)];
+        const float inv = 1.f / t0;
+        const float mu = t1 * inv, q = t2 * inv;
+        const float sd = sqrtf(fmaxf(q - mu * mu, a.eps));
+        a.pooled[(size_t)b * 2 * a.D + cg] = mu;
+        a.pooled[(size_t)b * 2 * a.D + a.D + cg] = sd;
+        a.smax[(size_t)b * a.D + cg] = tm * (1.f / LOG2E) + (a.bias ? a.bias[cg] : 0.f);
+        a.sinv[(size_t)b * a.D + cg] = inv;
+        a.qv[(size_t)b * a.D + cg] = q;
+        if (a.stats) {
+          const int rep = b % TN_NREP;
+          atomic_add_f32(&a.stats[(size_t)(rep * 2 + 0) * 2 * a.D + cg], mu);
+          atomic_add_f32(&a.stats[(size_t)(rep * 2 + 1) * 2 * a.D + cg], mu * mu);
+          atomic_add_f32(&a.stats[(size_t)(rep * 2 + 0) * 2 * a.D + a.D + cg], sd);
+          atomic_add_f32(&a.stats[(size_t)(rep * 2 + 1) * 2 * a.D + a.D + cg], sd * sd);
+        }
+      } else {
+        atomic_add_f32(&a.g_bout[cg], t0);
+      }
+    }
+  }
+}
+
+// -1000: shape outside the kernel (the caller runs the stored-energies path)
+template <int MODE>
+inline int launch_asp_v2(AspV2Args a, hipStream_t st) {
+  const int nslab = a.D / V2_C;
+  if (a.D % V2_C || a.T > ASPV2_PR || a.actE.drop_thr || (size_t)a.B * a.T * a.D * sizeof(bf16_t) >= ((size_t)1 << 31)) return -1000;
+  // slabs per workgroup: the fewest workgroups that still give every CU two rounds (the staging of an utterance's tanh
+  // outputs is paid once per workgroup)
+  int spw = 1;
+  for (int s = nslab; s >= 1; --s)
+    if (nslab % s == 0 && (long)a.B * (nslab / s) >= 512) { spw = s; break; }
+  a.spw = spw;
+  { const char* e = getenv("TN_ASP_EXACT"); a.force_exact = e ? atoi(e) : 0; }
+  { const char* es = getenv("TN_ASP_SPW"); if (es && atoi(es) > 0 && nslab % atoi(es) == 0) a.spw = spw = atoi(es); }      // (debug)
+  const size_t smem = (size_t)ASPV2_PR * (128 + 8) * sizeof(bf16_t) + (size_t)spw * (MODE == 0 ? 3 : 6) * V2_C * sizeof(float);
+  if (smem > 160 * 1024) return -1000;
+  auto kern = asp_v2_kernel<MODE>;
+  TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(kern, dim3(a.B * (nslab / spw)), dim3(V2_NT), smem, st, a);
+  return (int)hipGetLastError();
+}
