@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static check of the one hazard hipcc cannot see: a register that an inline-asm load (`global_load_dword vN, ...` between
+"""Static check of the one hazard hipcc cannot see: a register that an inline-asm load (`global_load_dword vN, ...` / `buffer_load_dwordx4 v[a:b], ...` between
 ;;#ASMSTART / ;;#ASMEND) is still filling must not be read before the inline-asm `s_waitcnt vmcnt(..)` that retires it.  The
 compiler believes the value exists as soon as the asm statement has "executed", so any copy it schedules in between (PHI
 copies of a switch over "+v" operands did exactly that in dw_bwd_slab: non-finite gradients now and then) reads stale data.
@@ -52,7 +52,7 @@ def check_asm(text):
         if in_asm:
             if re.match(r"s_waitcnt\s+vmcnt", code):
                 pending = {}
-            m = re.match(r"global_load_dword(?:x\d)?\s+(v\d+|v\[\d+:\d+\])\s*,", code)
+            m = re.match(r"(?:global|buffer)_load_dword(?:x\d)?\s+(v\d+|v\[\d+:\d+\])\s*,", code)
             if m and "lds" not in code:
                 for r in regs_of(m.group(1)):
                     pending[r] = n
