@@ -481,6 +481,10 @@ struct AspV2Args {
   float eps;
   int force_exact;      // MODE 0 test hook (TN_ASP_EXACT=1): always take the exact-maxima pass
 };
+#ifndef TN_ASP_ST_AUX
+#define TN_ASP_ST_AUX 0      // cache policy bits of the backward kernel's stores.  Measured: 2 / 3 (nt) 203 -> 550 us — a store
+                             // instruction covers 32 bytes of 32 different lines; only the L2 merges them into whole lines
+#endif
 constexpr int ASPV2_PR = 320;         // frames staged per utterance (T <= ASPV2_PR)
 template <int MODE>
 __global__ __launch_bounds__(V2_NT, 2) void asp_v2_kernel(AspV2Args a) {
@@ -709,8 +713,8 @@ __global__ __launch_bounds__(V2_NT, 2) void asp_v2_kernel(AspV2Args a) {
           const int voff = fr < a.T ? ((row0 + fr) * a.D + chl) * (int)sizeof(bf16_t) : 0x7ffffff0;
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
-            __builtin_amdgcn_raw_buffer_store_b128(on[h][q], srdN, voff, (slab * V2_C + 16 * q) * (int)sizeof(bf16_t), 0);
-            __builtin_amdgcn_raw_buffer_store_b128(ox[h][q], srdX, voff, (slab * V2_C + 16 * q) * (int)sizeof(bf16_t), 0);
+            __builtin_amdgcn_raw_buffer_store_b128(on[h][q], srdN, voff, (slab * V2_C + 16 * q) * (int)sizeof(bf16_t), TN_ASP_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(ox[h][q], srdX, voff, (slab * V2_C + 16 * q) * (int)sizeof(bf16_t), TN_ASP_ST_AUX);
           }
         }
       }
