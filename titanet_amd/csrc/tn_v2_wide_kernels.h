@@ -66,7 +66,7 @@ __global__ __launch_bounds__(V2_NT, 2) void wide_out_v2_kernel(WideOutArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) biasn[4 * g + j] = a.bias ? a.bias[slab * V2_C + wave * 32 + 8 * g + 4 * half + j] : 0.f;
+      for (int j = 0; j < 4; ++j) biasn[4 * g + j] = (EPI != 2 && a.bias) ? a.bias[slab * V2_C + wave * 32 + 8 * g + 4 * half + j] : 0.f;      // (EPI 2 has no bias: 32 registers)
   };
   fetch_w(0);
   if (EPI == 2) {
@@ -78,8 +78,26 @@ __global__ __launch_bounds__(V2_NT, 2) void wide_out_v2_kernel(WideOutArgs a) {
     }
   }
 
+  // EPI 2: the two element-wise operands of a tile (the direct gradient in Y, the raw forward output) are PREFETCHED — issued at
+  // the end of the previous tile's epilogue, unconditional (rows clamped): loaded behind the staging barrier and used at once,
+  // every tile exposed a full HBM round trip to all eight waves at the same moment (162 us for 708 MB)
+  const __amdgpu_buffer_rsrc_t srdY = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, EPI == 2 ? __builtin_amdgcn_readfirstlane((int)((size_t)a.M * a.N * sizeof(bf16_t))) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdR = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.RAW), 0, EPI == 2 ? __builtin_amdgcn_readfirstlane((int)((size_t)a.M * a.N * sizeof(bf16_t))) : 0, 0x00020000);
+  uint4 rdc[4], ryc[4];
+  auto epi_fetch = [&](int p0_, int prow_, int slab_, int tt_, uint4 (&rd_)[4], uint4 (&ry_)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = min(tt_ + rq + 16 * q, prow_ - 1);
+      const int voff = (((p0_ + o) * a.N) + c0) * (int)sizeof(bf16_t);
+      const u32x4_t d = __builtin_amdgcn_raw_buffer_load_b128(srdY, voff, slab_ * V2_C * (int)sizeof(bf16_t), 0);
+      const u32x4_t y = __builtin_amdgcn_raw_buffer_load_b128(srdR, voff, slab_ * V2_C * (int)sizeof(bf16_t), 0);
+      rd_[q] = make_uint4(d[0], d[1], d[2], d[3]);
+      ry_[q] = make_uint4(y[0], y[1], y[2], y[3]);
+    }
+  };
   for (int p0 = r_begin; p0 < r_end; p0 += PR) {
     const int prow = min(PR, r_end - p0);
+    if (EPI == 2) epi_fetch(p0, prow, 0, 0, rdc, ryc);
     __syncthreads();                                // previous pass done with As
     {
       uint4 st[NSTG];
@@ -106,13 +124,9 @@ __global__ __launch_bounds__(V2_NT, 2) void wide_out_v2_kernel(WideOutArgs a) {
         const int nxt = slab + 1 < nslabs ? slab + 1 : 0;
         if (slab + 1 < nslabs || p0 + PR < r_end) fetch_w(nxt);
       }
-      float s1[8], s2[8], psc[8], psh[8];
+      float s1[8], s2[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-      if (EPI == 2) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { psc[i] = par[slab * V2_C + c0 + i]; psh[i] = par[a.N + slab * V2_C + c0 + i]; }
-      }
       for (int tt = 0; tt < prow; tt += V2_R) {
         f32x16_t acc0, acc1;
 #pragma unroll
@@ -137,35 +151,45 @@ __global__ __launch_bounds__(V2_NT, 2) void wide_out_v2_kernel(WideOutArgs a) {
         }
         __syncthreads();
         if (EPI == 2) {
-          uint4 rd[4], ry[4];
+          // BatchNorm scale / shift of the thread's 8 channels, read per tile (an opaque offset: as loop invariants they would
+          // hold 16 registers next to two tiles of prefetched operands and the weight double buffer — spills)
+          int pco = slab * V2_C + c0;
+          asm volatile("" : "+v"(pco));
+          float psc[8], psh[8];
+          *reinterpret_cast<float4*>(psc) = *reinterpret_cast<const float4*>(par + pco);
+          *reinterpret_cast<float4*>(psc + 4) = *reinterpret_cast<const float4*>(par + pco + 4);
+          *reinterpret_cast<float4*>(psh) = *reinterpret_cast<const float4*>(par + a.N + pco);
+          *reinterpret_cast<float4*>(psh + 4) = *reinterpret_cast<const float4*>(par + a.N + pco + 4);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int o = tt + rq + 16 * q;
-            if (o < prow) {
-              const size_t off = (size_t)(p0 + o) * a.N + slab * V2_C + c0;
-              rd[q] = *reinterpret_cast<const uint4*>(a.Y + off);
-              ry[q] = *reinterpret_cast<const uint4*>(a.RAW + off);
-            }
-          }
+            const bool ok = o < prow;
+            float g8[8], d[8], y[8];
+            unpack8(*reinterpret_cast<const uint4*>(Cs + (rq + 16 * q) * V2_AP + c0), g8);
+            unpack8(rdc[q], d);
+            unpack8(ryc[q], y);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int o = tt + rq + 16 * q;
-            if (o < prow) {
-              float g8[8], d[8], y[8];
-              unpack8(*reinterpret_cast<const uint4*>(Cs + (rq + 16 * q) * V2_AP + c0), g8);
-              unpack8(rd[q], d);
-              unpack8(ry[q], y);
-#pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                const float z = fmaf(y[i], psc[i], psh[i]);
-                const float v = (z > 0.f) ? (g8[i] + d[i]) : 0.f;
-                d[i] = v;
-                s1[i] += v;
-                s2[i] = fmaf(v, y[i], s2[i]);        // against the raw y; converted to xhat at the end of the slab
-              }
-              store8(a.Y + (size_t)(p0 + o) * a.N + slab * V2_C + c0, d);
+            for (int i = 0; i < 8; ++i) {
+              const float z = fmaf(y[i], psc[i], psh[i]);
+              const float v = (ok && z > 0.f) ? (g8[i] + d[i]) : 0.f;
+              d[i] = v;
+              s1[i] += v;
+              s2[i] = fmaf(v, y[i], s2[i]);        // against the raw y; converted to xhat at the end of the slab
             }
+            uint4 w;
+            w.x = f2bf_pk(d[0], d[1]); w.y = f2bf_pk(d[2], d[3]); w.z = f2bf_pk(d[4], d[5]); w.w = f2bf_pk(d[6], d[7]);
+            const u32x4_t wv = {w.x, w.y, w.z, w.w};
+            if (ok) __builtin_amdgcn_raw_buffer_store_b128(wv, srdY, (((p0 + o) * a.N) + c0) * (int)sizeof(bf16_t), slab * V2_C * (int)sizeof(bf16_t), 0);
           }
+          // the next tile's operands (next tile of this slab, first tile of the next slab, or — last tile of the pass — this tile
+          // again), issued BEHIND this tile's stores into the registers just consumed: they have the next tile's MFMA phase
+          // and two barriers to land.  (Issued at the top of the step into a second register set, the wait for them stood in
+          // front of a copy at the end of the step with this tile's stores in between — and `vmcnt` is in order only among
+          // loads: with the stores made unconditional through out-of-range offsets, a store instruction whose every lane is
+          // out of range retires at once, vmcnt(4) was satisfied with loads still in flight, and a few gradients per launch
+          // were garbage.)
+          const bool more_t = tt + V2_R < prow, more_s = slab + 1 < nslabs;
+          epi_fetch(p0, prow, more_t ? slab : (more_s ? slab + 1 : slab), more_t ? tt + V2_R : (more_s ? 0 : tt), rdc, ryc);
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -217,6 +241,7 @@ inline int launch_wide_out_v2(WideOutArgs a, int max_wgs, hipStream_t st) {
   a.rows_per_wg = (a.M + grid - 1) / grid;
   grid = (a.M + a.rows_per_wg - 1) / a.rows_per_wg;
   const size_t smem = (size_t)(PR * AP + V2_R * V2_AP) * sizeof(bf16_t) + (EPI == 2 ? (size_t)4 * a.N * sizeof(float) : 0);
+  if (EPI == 2 && (size_t)a.M * a.N * sizeof(bf16_t) >= ((size_t)1 << 31)) return -1000;      // 32-bit buffer offsets
   auto kern = wide_out_v2_kernel<K, EPI>;
   TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(V2_NT), smem, st, a);
@@ -272,8 +297,10 @@ __global__ __launch_bounds__(V2_NT, 2) void wide_in_v2_kernel(WideInArgs a) {
   // addresses hipcc hoisted the 20 + 8 per-lane 64-bit addresses of the unrolled steps out of the chunk loop and spilled them.
   // Rows at or beyond r_end read as zeros (num_records).
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+  // (the record count goes through readfirstlane: computed in vector registers it made the descriptor "divergent" and hipcc
+  //  wrapped every load of the stream in a waterfall loop)
   const __amdgpu_buffer_rsrc_t srdW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W), 0, NO * a.KW * (int)sizeof(bf16_t), 0x00020000);
-  const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.A), 0, (int)((size_t)r_end * a.KW * sizeof(bf16_t)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.A), 0, __builtin_amdgcn_readfirstlane((int)((size_t)r_end * a.KW * sizeof(bf16_t))), 0x00020000);
   const int voffW = ((tid >> 5) * a.KW + (tid & 31) * 8) * (int)sizeof(bf16_t);
   const int voffA = (rq * a.KW + c0) * (int)sizeof(bf16_t);
   auto w_load2 = [&](int kc, int q0, uint4 (&wr)[2]) {
@@ -327,7 +354,6 @@ __global__ __launch_bounds__(V2_NT, 2) void wide_in_v2_kernel(WideInArgs a) {
       for (int t = 0; t < GT; ++t) {
         if (t < ntile) {
           uint4 wp[2];
-          if (t < 4 && more_w) w_load2(kc + 1, 2 * t, wp);
           __syncthreads();                          // previous MFMA done with As (and, for t == 0, every wave holds its wf)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -344,9 +370,17 @@ __global__ __launch_bounds__(V2_NT, 2) void wide_in_v2_kernel(WideInArgs a) {
             }
             store8(As + (rq + 16 * q) * V2_AP + c0, v);
           }
-          // next tile of this chunk, or the first tile of the next chunk
-          if (t + 1 < ntile) a_fetch(kc, t + 1);
-          else if (kc + 1 < nchunks) a_fetch(kc + 1, 0);
+          // Order and form of the loads matter to where hipcc waits (vmcnt is in order, and a load under a condition makes it
+          // wait for everything): the next weight pieces go out AFTER the prefetched A tile has been consumed (issued in front
+          // of it, the A tile's vmcnt(0) also waited for them: an exposed L2 round trip per tile step) and BEFORE the next A
+          // tile (their store behind the MFMAs then waits with vmcnt(4), the A tile stays in flight); both are unconditional —
+          // past the end they re-read the current chunk / tile
+          if (t < 4) w_load2(more_w ? kc + 1 : kc, 2 * t, wp);
+          {
+            const bool nt_ = t + 1 < ntile;
+            const int kcn = nt_ ? kc : (kc + 1 < nchunks ? kc + 1 : kc), tn_ = nt_ ? t + 1 : (kc + 1 < nchunks ? 0 : t);
+            a_fetch(kcn, tn_);
+          }
           __syncthreads();
           const bf16_t* brow = As + (rh * 32 + (lane & 31)) * V2_AP + half * 8;
 #pragma unroll
@@ -354,7 +388,7 @@ __global__ __launch_bounds__(V2_NT, 2) void wide_in_v2_kernel(WideInArgs a) {
             const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(brow + ks * 16);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b, acc[t], 0, 0, 0);
           }
-          if (t < 4 && more_w) w_store2(2 * t, wp);
+          if (t < 4 && more_w) w_store2(2 * t, wp);       // (the last chunk's re-read pieces are dropped)
         }
       }
       // row groups of fewer than 4 tiles: the pieces no tile step moved
@@ -638,7 +672,7 @@ __global__ __launch_bounds__(V2_NT, 2) void asp_v2_kernel(AspV2Args a) {
     // in a loop unrolled by two: a copy cur = nxt at the end of the step made hipcc wait for the prefetch inside the step
     auto step = [&](auto pf, int t, u32x4_t (&cur)[2][2], u32x4_t (&nxt)[2][2]) {
       const int tt = t * V2_R;
-      if constexpr (decltype(pf)::value) e_load(slab, (t + 1 < ntile ? t + 1 : t) * V2_R, nxt);
+      if constexpr (decltype(pf)::value) e_load(slab, (t + 1) * V2_R, nxt);      // (a step with prefetch is never the last tile)
       f32x16_t acc[2];
       tile_mfma(wf, tt, acc[0], acc[1]);
       // (scheduling fences: left alone hipcc unpacks all 64 E values of the step among the MFMAs — 64 more live registers,
@@ -721,6 +755,10 @@ __global__ __launch_bounds__(V2_NT, 2) void asp_v2_kernel(AspV2Args a) {
       // the prefetch has had the whole step to land; it is awaited HERE, at the end of the step that issued it, not at the
       // top of the one that consumes it: between the two hipcc may COPY the registers (it did, on the way into the peeled last
       // step: v_mov of pieces still in flight — utterances with garbage statistics, a few per launch)
+      // vmcnt counts loads in order among loads and stores among stores — NOT across the two: a store instruction whose every
+      // lane is out of range (frames >= T: only in an utterance's LAST tile) retires at once, and vmcnt(8) would then be
+      // satisfied with loads still in flight (found in wide_out_v2's EPI 2, same trick).  Hence the loop structure below: the
+      // last tile is always a step without prefetch and without a counted wait.
       if constexpr (decltype(pf)::value) {
         if (NST == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(nxt[0][0]), "+v"(nxt[0][1]), "+v"(nxt[1][0]), "+v"(nxt[1][1]) : : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt[0][0]), "+v"(nxt[0][1]), "+v"(nxt[1][0]), "+v"(nxt[1][1]) : : "memory");
@@ -734,9 +772,12 @@ __global__ __launch_bounds__(V2_NT, 2) void asp_v2_kernel(AspV2Args a) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wf[ks]));
       int t = 0;
-      for (; t + 1 < ntile; t += 2) { step(std::true_type{}, t, ec, en); step(std::true_type{}, t + 1, en, ec); }
-      if (t < ntile) step(std::false_type{}, t, ec, en);       // (no prefetch: a load nobody awaits would land in registers
-    }                                                          //  the compiler has handed to other values by then)
+      for (; t + 2 < ntile; t += 2) { step(std::true_type{}, t, ec, en); step(std::true_type{}, t + 1, en, ec); }
+      // the last one or two tiles; the last without prefetch (a load nobody awaits would land in registers the compiler has
+      // handed to other values by then)
+      if (t + 1 < ntile) { step(std::true_type{}, t, ec, en); step(std::false_type{}, t + 1, en, ec); }
+      else if (t < ntile) step(std::false_type{}, t, ec, en);
+    }
     // ---- end of the slab: the 32 frame lanes of each half add up, lane r of a half then owns channel register r
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1)
