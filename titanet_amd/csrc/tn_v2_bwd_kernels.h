@@ -292,7 +292,8 @@ __global__ __launch_bounds__(V2_NT, 2) void wgrad_batched_v2_kernel(const WgradV
     // broadcast `part` from wave 0 to the other waves through LDS (cst is free now)
     if (tid == 0) reinterpret_cast<int*>(cst)[0] = part;
     __syncthreads();
-    part = reinterpret_cast<int*>(cst)[0];
+    part = __builtin_amdgcn_readfirstlane(reinterpret_cast<int*>(cst)[0]);      // (uniform for the compiler too: read from LDS the slab
+                                                                                //  descriptor was "divergent" and each of the 128 stores below sat in a waterfall loop)
     // buffer stores: ONE per-lane offset register + a scalar offset per accumulator register (128 precomputed 64-bit
     // addresses were hoisted out of the unit loop and lived in scratch: the kernel's "93 spilled VGPRs")
     float* slab = d.slabs + (size_t)part * V2_C * V2_C;
