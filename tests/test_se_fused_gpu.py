@@ -1,0 +1,77 @@
+"""SE squeeze + gate + residual combine of a mega block in ONE launch that reads the last sub-block's output once
+(se_combine_fwd_v3_kernel, csrc/tn_v2_kernels.h: the utterance's rows stay in registers across the two mat-vecs) against the
+two-kernel form of the same library (TN_SE_FUSED=0 at plan creation: se_squeeze_v2 + combine_fwd_v2).  Same arithmetic in the
+same order, so the eval forward (no atomics anywhere) must be BIT-identical, fixed-length and variable-length; a training step
+(dropout masks shared, BatchNorm statistics through float atomics) must agree to the run-to-run noise of either path.
+Reference behaviour: /root/reference/src/modules.py:173-189 (SqueezeExcitation), src/models.py:467-472 (MegaBlock.forward)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(fused, nb, B, T, masked, train):
+    from titanet_amd import LOSSES, TitaNet
+    old = os.environ.get("TN_SE_FUSED")
+    try:
+        os.environ["TN_SE_FUSED"] = "1" if fused else "0"
+        torch.manual_seed(5)
+        m = TitaNet.get_titanet(n_mega_blocks=nb, model_size="s", loss_function=LOSSES["ce"](192, 40, device="cuda"), dropout=0.1,
+                                device="cuda", precision="bf16")
+        g = torch.Generator().manual_seed(17)
+        x = (torch.randn(B, 80, T, generator=g) * 0.11 - 0.1).cuda()
+        y = torch.randint(0, 40, (B,), generator=g).cuda()
+        lengths = None
+        if masked:
+            lengths = torch.randint(1, T + 1, (B,), generator=g)
+            lengths[0] = T
+        if not train:
+            m.eval()
+            with torch.no_grad():
+                return m(x, lengths=lengths).float().cpu(), 0.0, None
+        m.train()
+        m._seed_base, m._step = 777, 0
+        emb, _, loss = m(x, speakers=y, lengths=lengths)
+        loss.backward()
+        grad = torch.cat([p.grad.flatten() for p in m.parameters()]).float().cpu()
+        return emb.detach().float().cpu(), float(loss.detach()), grad
+    finally:
+        if old is None:
+            os.environ.pop("TN_SE_FUSED", None)
+        else:
+            os.environ["TN_SE_FUSED"] = old
+
+
+SHAPES = [
+    (3, 256, 300, False),     # the benched shape: 19 rows per thread, the last partly past the utterance
+    (2, 64, 320, False),      # the longest utterance the kernel takes (every register row used)
+    (2, 40, 250, True),       # variable lengths: padding rows written as zeros, means over the valid frames
+    (1, 130, 17, True),       # utterances shorter than a row group
+    (2, 24, 129, False),
+]
+
+
+@pytest.mark.parametrize("nb,B,T,masked", SHAPES)
+def test_fused_se_combine_eval_bit_identical(nb, B, T, masked):
+    a, _, _ = _run(True, nb, B, T, masked, train=False)
+    b, _, _ = _run(False, nb, B, T, masked, train=False)
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b), float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("nb,B,T,masked", SHAPES[:4])
+def test_fused_se_combine_train_step(nb, B, T, masked):
+    e0, l0, g0 = _run(False, nb, B, T, masked, train=True)
+    e0b, _, g0b = _run(False, nb, B, T, masked, train=True)          # the yardstick: the same path twice
+    e1, l1, g1 = _run(True, nb, B, T, masked, train=True)
+    assert torch.isfinite(e1).all() and torch.isfinite(g1).all()
+    noise_e = float((e0b - e0).norm() / e0.norm())
+    noise_g = float((g0b - g0).norm() / g0.norm())
+    rel_e = float((e1 - e0).norm() / e0.norm())
+    rel_g = float((g1 - g0).norm() / g0.norm())
+    print(nb, B, T, masked, f"emb {rel_e:.2e} (rerun {noise_e:.2e})  grad {rel_g:.2e} (rerun {noise_g:.2e})  loss {l1:.6f} vs {l0:.6f}")
+    assert rel_e <= 3 * noise_e + 1e-4, (rel_e, noise_e)
+    assert rel_g <= 3 * noise_g + 1e-3, (rel_g, noise_g)
+    assert abs(l1 - l0) < 1e-3 * max(1.0, abs(l0))

@@ -402,6 +402,10 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
       p->asp_fused = !(ef && atoi(ef) == 0) && precision == TN_PREC_BF16 && !p->generic && !cc.simple_pool && cc.enc_out % 256 == 0 &&
                      cc.attn_hidden == 128 && frames <= ASPV2_PR && p->tail_parts == 1;
     }
+    {
+      const char* es = getenv("TN_SE_FUSED");
+      p->se_fused = !(es && atoi(es) == 0) && precision == TN_PREC_BF16 && p->use_v2 && frames <= 16 * SC3_MAXU && p->tail_parts == 1;
+    }
     const char* eo = getenv("TN_OVERLAP");
     p->overlap = p->use_v2 && c.n_mega_blocks > 0 && eo && atoi(eo) != 0;
     if (p->overlap) {
@@ -928,6 +932,27 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       };
       size_t smem = (size_t)(3 * H + ((Hr + 3) & ~3) + TG * H) * sizeof(float);
       int rc1 = -1000;
+      bool combined = false;
+      if (sizeof(AT) == 2 && H == V2_C && Hr == 16 && use_v2 && p->se_fused) {
+        // squeeze + gate + combine in one launch that reads Y3 once (the utterance's rows stay in registers)
+        { int rcj = join_skip(); if (rcj) return rcj; }
+        SeCombineV3Args fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.se.Y = (const bf16_t*)cur; fa.se.act = acur; fa.se.W1 = params + mb.se_w1; fa.se.W2 = params + mb.se_w2;
+        fa.se.m_out = (float*)(ws + bw.m); fa.se.h_out = (float*)(ws + bw.h); fa.se.g_out = (float*)(ws + bw.g); fa.se.T = T; fa.se.len = rm.len;
+        fa.S = (const bf16_t*)(ws + bw.S); fa.actS = make_act(p, mb.bnskip, M, training, 0, 0.f, seed, 0);
+        fa.OUT = (bf16_t*)(ws + bw.OUT);
+        if (training && pd > 0.f) {
+          fa.drop_thr = (uint32_t)lrintf(pd * 65536.f);
+          fa.drop_key = tn_layer_key(seed, (uint32_t)(i * (c.n_sub_blocks + 1) + c.n_sub_blocks));
+          fa.inv_keep = 1.f / (1.f - pd);
+        } else fa.inv_keep = 1.f;
+        fa.key_add = (const uint32_t*)(ws + p->step_state) + 2;
+        const int rcf = launch_se_combine_fwd_v3(fa, B, st);
+        if (rcf > 0) return rcf;
+        combined = rcf == 0;
+      }
+      if (!combined) {
       if (sizeof(AT) == 2 && H == V2_C && Hr == 16 && use_v2) {
         SeSqueezeV2Args sa;
         memset(&sa, 0, sizeof(sa));
@@ -973,6 +998,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
                            (const AT*)(ws + bw.S), acts, (const AT*)cur, acur, (const float*)(ws + bw.g), (AT*)(ws + bw.OUT), M,
                            T, H, rpb, thr, key, ik, (const uint32_t*)(ws + p->step_state) + 2,
                            listed ? (const int*)(ws + p->rowtiles) : (const int*)nullptr);
+      }
       }
     }
     xin = ws + bw.OUT;

@@ -184,6 +184,10 @@ struct tn_plan {
   // the K = 128 product.  Decided at plan creation (TN_ASP_FUSED=0 keeps the stored-energies kernels; shapes outside the
   // kernel — frames > 320, several workgroups per utterance — always do): forward and backward must agree.
   bool asp_fused = false;
+  // SE squeeze + residual combine of a mega block in one launch that keeps the utterance's Y3 in registers
+  // (se_combine_fwd_v3_kernel, tn_v2_kernels.h): hidden 256, bf16, frames <= 320, one workgroup per utterance.  TN_SE_FUSED=0
+  // (read at plan creation) keeps se_squeeze_v2 + combine_fwd_v2.
+  bool se_fused = false;
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> ov_events;   // [block][4]: forward fork / join, backward fork / join
   // per-kernel event timing (tn_profile_*)

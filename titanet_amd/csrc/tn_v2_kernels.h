@@ -556,6 +556,225 @@ inline int launch_se_squeeze_v2(const SeSqueezeV2Args& a, int B, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------------
+// se_combine_fwd_v3 (round 5): se_squeeze_v2 + combine_fwd_v2 in ONE launch that reads Y3 once.
+// The SE gate of an utterance needs the mean over ALL its frames of act3(Y3) before the first output row can be formed, so the
+// two-kernel form reads Y3 twice (17 x 39 MB per step).  An utterance of <= 320 frames x 256 channels is 160 KB of bf16: the
+// 512 threads of its workgroup KEEP it in registers (<= 20 rows x 16 bytes per thread, the row / channel-vector assignment of
+// se_squeeze_v2) across the two mat-vecs and apply the gate to the rows they hold; only the skip operand S is streamed in the
+// second phase (first rows requested before the mat-vec tail, the rest one group of 4 rows ahead).  Same arithmetic in the same
+// order as the two kernels it replaces: outputs, means, hidden layer and gates are bit-identical (tests/test_se_fused_gpu.py).
+// One workgroup per utterance (B >= the CU count at the benched shape); T > 320: the two-kernel form.
+// ------------------------------------------------------------------------------------------
+#define SC3_MAXU 20
+// the keep decisions of tn_drop8 as 8 bits (bit i = element i kept)
+__device__ __forceinline__ uint32_t tn_drop8_bits(uint32_t idx8, uint32_t key, uint32_t thr) {
+  const uint32_t x = tn_drop_shared(idx8, key);
+  const uint32_t h0 = tn_drop_final(x, TN_DROP_C0), h1 = tn_drop_final(x, TN_DROP_C1);
+  const uint32_t h2 = tn_drop_final(x, TN_DROP_C2), h3 = tn_drop_final(x, TN_DROP_C3);
+  uint32_t m = 0;
+  m |= ((h0 & 0xffffu) >= thr) ? 1u : 0u;  m |= ((h0 >> 16) >= thr) ? 2u : 0u;
+  m |= ((h1 & 0xffffu) >= thr) ? 4u : 0u;  m |= ((h1 >> 16) >= thr) ? 8u : 0u;
+  m |= ((h2 & 0xffffu) >= thr) ? 16u : 0u; m |= ((h2 >> 16) >= thr) ? 32u : 0u;
+  m |= ((h3 & 0xffffu) >= thr) ? 64u : 0u; m |= ((h3 >> 16) >= thr) ? 128u : 0u;
+  return m;
+}
+struct SeCombineV3Args {
+  SeSqueezeV2Args se;        // Y = Y3, act = act3, W1, W2, m_out / h_out / g_out, T, len
+  const bf16_t* S; BnAct actS;
+  bf16_t* OUT;
+  uint32_t drop_thr, drop_key;
+  float inv_keep;
+  const uint32_t* key_add;   // see BnAct::key_add
+};
+template <int FL3, bool DROP>
+__global__ __launch_bounds__(512) void se_combine_fwd_v3_kernel(SeCombineV3Args aa) {
+  constexpr int HR = 16, G = 4, NG = SC3_MAXU / G;
+  const SeSqueezeV2Args& a = aa.se;
+  __shared__ float cst[4 * V2_C];
+  __shared__ float part[16][V2_C];
+  __shared__ float mean[V2_C];
+  __shared__ float gs[V2_C];
+  __shared__ float hbuf[HR];
+  const int tid = threadIdx.x, vc = tid & 31, tg = tid >> 5, c0 = vc * 8, b = blockIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int T = a.T;
+  const int L = a.len ? a.len[b] : T;
+  const size_t base = (size_t)b * T;
+  // BatchNorm constants first: their loads must not queue behind the utterance's rows (vmcnt retires in order)
+  float cs0 = 1.f, ch0 = 0.f, cs1 = 1.f, ch1 = 0.f;
+  if (tid < V2_C) {
+    if (FL3 & 1) bn_scale_shift(a.act, V2_C, tid, cs1, ch1);
+    bn_scale_shift(aa.actS, V2_C, tid, cs0, ch0);
+  }
+  // the whole utterance: unconditional buffer loads through a descriptor of the utterance's VALID rows (frames past them read
+  // as zeros and are masked out of the sums); one voffset per thread, the row step in the scalar offset
+  typedef __attribute__((ext_vector_type(4))) unsigned int sc3_u32x4_t;
+  const __amdgpu_buffer_rsrc_t srdY = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.Y + base * V2_C), 0, L * V2_C * (int)sizeof(bf16_t), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdS = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(aa.S + base * V2_C), 0, L * V2_C * (int)sizeof(bf16_t), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc(aa.OUT + base * V2_C, 0, T * V2_C * (int)sizeof(bf16_t), 0x00020000);
+  const int voff = (tg * V2_C + c0) * (int)sizeof(bf16_t);
+  constexpr int USTEP = 16 * V2_C * (int)sizeof(bf16_t);
+  // NO load may be out of range: a buffer load whose lanes are all past the descriptor returns its zeros at once, ahead of older
+  // loads still in flight, and every counted wait behind it (the compiler's and the ones below) is then one short — rows past
+  // the valid frames re-read the last valid row and are masked by `t < L`
+  const int lastrow = max(L, 1) - 1;
+  auto row_off = [&](int u) -> int { return (min(tg + 16 * u, lastrow) * V2_C + c0) * (int)sizeof(bf16_t); };
+  uint4 ry[SC3_MAXU];
+#pragma unroll
+  for (int u = 0; u < SC3_MAXU; ++u) ry[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srdY, row_off(u), 0, 0));
+  // skip rows: three groups of 4 rows in flight (the first behind the utterance's rows, the second before the mat-vec tail)
+  uint4 rs[3][G];
+  auto load_s = [&](int g, uint4 (&dst)[G]) {
+#pragma unroll
+    for (int q = 0; q < G; ++q) dst[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srdS, row_off(g * G + q), 0, 0));
+  };
+  load_s(0, rs[0]);
+  if (tid < V2_C) { cst[tid] = cs0; cst[V2_C + tid] = ch0; cst[2 * V2_C + tid] = cs1; cst[3 * V2_C + tid] = ch1; }
+  __syncthreads();
+  float sc3[8], sh3[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { sc3[i] = cst[2 * V2_C + c0 + i]; sh3[i] = cst[3 * V2_C + c0 + i]; }
+  const uint32_t dkey3 = tn_act_key(a.act), dthr3 = a.act.drop_thr;
+  uint32_t km[SC3_MAXU / 4];
+#pragma unroll
+  for (int i = 0; i < SC3_MAXU / 4; ++i) km[i] = 0u;
+  {
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int u = 0; u < SC3_MAXU; ++u) {
+      const int t = tg + 16 * u;
+      float v[8];
+      unpack8(ry[u], v);
+      act8_t<FL3 & 3>(v, sc3, sh3, dkey3, dthr3, (uint32_t)b * T + t, c0);
+      if (FL3 & 4) {
+        // the keep bits of the row are kept for phase 2 (8 bits per row; left to itself hipcc stashes the 64-bit compare
+        // results of all 160 elements in VGPR lanes for reuse, and the reused masks came back wrong in ~1 % of the elements)
+        const uint32_t m = tn_drop8_bits((((uint32_t)b * T + t) * (uint32_t)V2_C + (uint32_t)c0) >> 3, dkey3, dthr3);
+        km[u / 4] |= m << (8 * (u % 4));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (m & (1u << i)) ? v[i] : 0.f;
+      }
+      const bool ok = t < L;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += ok ? v[i] : 0.f;
+      __builtin_amdgcn_sched_barrier(0);      // (one row's arithmetic at a time, not all twenty interleaved: registers)
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part[tg][c0 + i] = acc[i];
+  }
+  // weights of the tail (L2 hits: every workgroup reads the same 32 KB), in flight during the partial-sum exchange
+  float w1a[4], w1b[4];      // W1 rows wave and wave + 8, columns lane + 64 k
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { w1a[k] = a.W1[(size_t)wave * V2_C + lane + 64 * k]; w1b[k] = a.W1[(size_t)(wave + 8) * V2_C + lane + 64 * k]; }
+  float4 w2[4];              // W2 row tid (tid < 256)
+  if (tid < V2_C) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w2[k] = *reinterpret_cast<const float4*>(a.W2 + (size_t)tid * HR + 4 * k);
+  }
+  load_s(1, rs[1]);
+  __syncthreads();
+  if (tid < V2_C) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += part[k][tid];
+    s *= 1.f / (float)max(L, 1);
+    mean[tid] = s;
+    a.m_out[(size_t)b * V2_C + tid] = s;
+  }
+  __syncthreads();
+  {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s0 = fmaf(w1a[k], mean[lane + 64 * k], s0); s1 = fmaf(w1b[k], mean[lane + 64 * k], s1); }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if (lane == 0) {
+      s0 = fmaxf(s0, 0.f); s1 = fmaxf(s1, 0.f);
+      hbuf[wave] = s0; hbuf[wave + 8] = s1;
+      a.h_out[(size_t)b * HR + wave] = s0;
+      a.h_out[(size_t)b * HR + wave + 8] = s1;
+    }
+  }
+  __syncthreads();
+  if (tid < V2_C) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s = fmaf(w2[k].x, hbuf[4 * k], s); s = fmaf(w2[k].y, hbuf[4 * k + 1], s);
+      s = fmaf(w2[k].z, hbuf[4 * k + 2], s); s = fmaf(w2[k].w, hbuf[4 * k + 3], s);
+    }
+    const float gv = 1.f / (1.f + __expf(-s));
+    gs[tid] = gv;
+    a.g_out[(size_t)b * V2_C + tid] = gv;
+  }
+  __syncthreads();
+  // ---- phase 2: OUT = dropout(relu(BN(S) + g * act3(Y3))) on the rows this thread holds
+  // (the rows stay PACKED across the tail: without this hipcc keeps phase 1's activated f32 values of all 20 rows for reuse —
+  //  twice the registers, spills)
+#pragma unroll
+  for (int u = 0; u < SC3_MAXU; ++u) asm volatile("" : "+v"(ry[u].x), "+v"(ry[u].y), "+v"(ry[u].z), "+v"(ry[u].w));
+#pragma unroll
+  for (int i = 0; i < SC3_MAXU / 4; ++i) asm volatile("" : "+v"(km[i]));
+  float scS[8], shS[8], g[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    scS[i] = cst[c0 + i]; shS[i] = cst[V2_C + c0 + i]; g[i] = gs[c0 + i];
+    if (DROP) { scS[i] *= aa.inv_keep; shS[i] *= aa.inv_keep; g[i] *= aa.inv_keep; }   // relu(k x) = k relu(x), k > 0
+  }
+  const uint32_t okey = aa.key_add ? aa.drop_key + *aa.key_add : aa.drop_key;
+#pragma unroll
+  for (int gq = 0; gq < NG; ++gq) {
+    if (gq + 2 < NG) load_s(gq + 2, rs[(gq + 2) % 3]);
+    // hipcc counts its waits as if loads and stores retired in ONE order: with the previous groups' stores in flight its
+    // vmcnt(newer loads + newer stores) is satisfied as soon as the STORES are acknowledged, this group's rows still on their
+    // way (measured: wrong outputs from the third group on).  Loads do retire in order among themselves, so the wait that
+    // holds is vmcnt(newer loads only) — conservative when stores are pending.
+    if (gq + 2 < NG) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (gq + 1 < NG) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);      // (hipcc otherwise hoists every group's loads to the top: 80 more live registers, spills)
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      const int u = gq * G + q, t = tg + 16 * u;
+      const uint32_t row = (uint32_t)b * T + t;
+      float s[8], y[8], o[8];
+      unpack8(rs[gq % 3][q], s);
+      unpack8(ry[u], y);
+      act8_t<FL3 & 3>(y, sc3, sh3, dkey3, dthr3, row, c0);
+      if (FL3 & 4) {
+        const uint32_t m = km[u / 4] >> (8 * (u % 4));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] = (m & (1u << i)) ? y[i] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = fmaxf(fmaf(s[i], scS[i], fmaf(g[i], y[i], shS[i])), 0.f);
+      if (DROP) tn_drop8(o, (row * (uint32_t)V2_C + (uint32_t)c0) >> 3, okey, aa.drop_thr);
+      const bool ok = t < L;                 // padding rows are written as zeros; rows >= T fall outside the descriptor
+      sc3_u32x4_t w;
+      w[0] = ok ? f2bf_pk(o[0], o[1]) : 0u; w[1] = ok ? f2bf_pk(o[2], o[3]) : 0u;
+      w[2] = ok ? f2bf_pk(o[4], o[5]) : 0u; w[3] = ok ? f2bf_pk(o[6], o[7]) : 0u;
+      // (the row step goes into the VECTOR offset, scalar offset 0: with an SGPR scalar offset hipcc's hazard recogniser assumes
+      //  a 16-byte store has read its data registers at issue and lets a VALU write of the first one follow within 5
+      //  instructions — on gfx950 the last lanes of the store then carried the NEW value: the first bf16 pair of ~0.03 % of
+      //  the rows came out as the next load's address.  Found as zeros in elements 0, 1 of rows 48 + tg, 112 + tg, ..)
+      __builtin_amdgcn_raw_buffer_store_b128(w, srdO, voff + u * USTEP, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);      // one row's arithmetic at a time: two interleaved rows do not fit the register file
+    }
+  }
+}
+// -1000: shape / flags outside the kernel (the caller runs se_squeeze_v2 + combine_fwd_v2)
+inline int launch_se_combine_fwd_v3(const SeCombineV3Args& a, int B, hipStream_t st) {
+  if (a.se.T > 16 * SC3_MAXU) return -1000;
+  const int fl3 = (a.se.act.mode != 0 ? 1 : 0) | (a.se.act.relu ? 2 : 0) | (a.se.act.drop_thr ? 4 : 0);
+  if (fl3 == 7 && a.drop_thr) hipLaunchKernelGGL((se_combine_fwd_v3_kernel<7, true>), dim3(B), dim3(512), 0, st, a);
+  else if (fl3 == 3 && !a.drop_thr) hipLaunchKernelGGL((se_combine_fwd_v3_kernel<3, false>), dim3(B), dim3(512), 0, st, a);
+  else return -1000;
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // sub_fwd_v5: PRODUCER / CONSUMER wave specialisation of the forward sub-block.
 // With one 512-thread workgroup per CU every wave used to sit in the same barrier-separated phase
 // (activation -> stencil -> MFMA -> epilogue -> store), so VALU, LDS and MFMA time ADDED up.  Here waves 0-3

@@ -179,7 +179,10 @@ __global__ __launch_bounds__(V2_NT, 2) void wide_out_v2_kernel(WideOutArgs a) {
             uint4 w;
             w.x = f2bf_pk(d[0], d[1]); w.y = f2bf_pk(d[2], d[3]); w.z = f2bf_pk(d[4], d[5]); w.w = f2bf_pk(d[6], d[7]);
             const u32x4_t wv = {w.x, w.y, w.z, w.w};
-            if (ok) __builtin_amdgcn_raw_buffer_store_b128(wv, srdY, (((p0 + o) * a.N) + c0) * (int)sizeof(bf16_t), slab * V2_C * (int)sizeof(bf16_t), 0);
+            // (scalar offset 0, the slab in the vector offset: a 16-byte store with an SGPR scalar offset gets no hazard slots from
+            //  hipcc before a VALU write of its data registers, and on gfx950 the store then reads the new contents — see
+            //  se_combine_fwd_v3_kernel, tools/check_asm_hazards.py check_store_data)
+            if (ok) __builtin_amdgcn_raw_buffer_store_b128(wv, srdY, (((p0 + o) * a.N) + c0 + slab * V2_C) * (int)sizeof(bf16_t), 0, 0);
           }
           // the next tile's operands (next tile of this slab, first tile of the next slab, or — last tile of the pass — this tile
           // again), issued BEHIND this tile's stores into the registers just consumed: they have the next tile's MFMA phase
@@ -747,8 +750,10 @@ __global__ __launch_bounds__(V2_NT, 2) void asp_v2_kernel(AspV2Args a) {
           const int voff = fr < a.T ? ((row0 + fr) * a.D + chl) * (int)sizeof(bf16_t) : 0x7ffffff0;
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
-            __builtin_amdgcn_raw_buffer_store_b128(on[h][q], srdN, voff, (slab * V2_C + 16 * q) * (int)sizeof(bf16_t), TN_ASP_ST_AUX);
-            __builtin_amdgcn_raw_buffer_store_b128(ox[h][q], srdX, voff, (slab * V2_C + 16 * q) * (int)sizeof(bf16_t), TN_ASP_ST_AUX);
+            // (scalar offset 0: see the store-data hazard note in wide_out_v2_kernel; the out-of-range sentinel stays out of range)
+            const int vo = voff + (slab * V2_C + 16 * q) * (int)sizeof(bf16_t);
+            __builtin_amdgcn_raw_buffer_store_b128(on[h][q], srdN, vo, 0, TN_ASP_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(ox[h][q], srdX, vo, 0, TN_ASP_ST_AUX);
           }
         }
       }

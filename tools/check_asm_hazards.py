@@ -94,9 +94,47 @@ def check_asm(text):
     return findings
 
 
+STORE_WINDOW = 12      # instructions after the store in which a write of its data registers is flagged
+
+
+def check_store_data(text):
+    """Second hazard (round 5, found in se_combine_fwd_v3_kernel on gfx950): a buffer store of more than 8 bytes whose SCALAR offset
+    is an SGPR, followed within a few instructions by a VALU write (or a load) into one of its data registers — hipcc's hazard
+    recogniser only covers the immediate-offset form, and the last lanes of the store went out with the NEW register contents.
+    Flags any write of a >64-bit store's data registers within STORE_WINDOW instructions when the store's soffset is a register."""
+    findings = []
+    func = None
+    recent = []           # (line, data registers, text) of the flagged-form stores still inside the window
+    for n, line in enumerate(text.split("\n"), 1):
+        s = line.strip()
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            func, recent = m.group(1), []
+            continue
+        if not s or s.startswith(";") or s.startswith("."):
+            continue
+        code = s.split(";")[0].strip()
+        if not code or code.endswith(":"):
+            continue
+        ops = code.split(None, 1)
+        if len(ops) > 1 and recent:
+            # destination = first operand of everything but stores / compares into SGPRs / s_* instructions
+            if not re.match(r"(buffer_store|global_store|flat_store|scratch_store|ds_write|s_|v_cmp|v_readlane|v_readfirstlane)", ops[0]):
+                dst = regs_of(ops[1].split(",")[0])
+                for ln, regs, txt in recent:
+                    hit = dst & regs
+                    if hit:
+                        findings.append((func, n, f"{code}   [data of `{txt}` at line {ln}]", sorted(hit)))
+        recent = [(ln, regs, txt) for ln, regs, txt in recent if n - ln < STORE_WINDOW]
+        m = re.match(r"buffer_store_dwordx[34]\s+(v\[\d+:\d+\])\s*,\s*(\S+)\s*,\s*(s\[\d+:\d+\])\s*,\s*(\S+)", code)
+        if m and re.match(r"s\d+$", m.group(4)):
+            recent.append((n, regs_of(m.group(1)), code))
+    return findings
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1].endswith(".s"):      # an ISA listing made elsewhere (tuning harnesses)
-        f = check_asm(open(sys.argv[1]).read())
+        f = check_asm(open(sys.argv[1]).read()) + check_store_data(open(sys.argv[1]).read())
         print(f"{sys.argv[1]}: {len(f)} reads of in-flight asm-load registers")
         for func, n, code, regs in f[:40]:
             print(f"   {func[:60]} line {n}: {code}   (v{regs})")
@@ -109,11 +147,11 @@ def main():
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             raise SystemExit(r.stderr[-2000:])
-        return src, check_asm(r.stdout)
+        return src, check_asm(r.stdout) + check_store_data(r.stdout)
     bad = 0
     with ThreadPoolExecutor(max_workers=4) as ex:
         for src, f in ex.map(one, srcs):
-            print(f"{src}: {len(f)} reads of in-flight asm-load registers")
+            print(f"{src}: {len(f)} reads of in-flight asm-load registers / early writes of store data")
             for func, n, code, regs in f[:20]:
                 print(f"   {func[:60]} line {n}: {code}   (v{regs})")
             bad += len(f)
