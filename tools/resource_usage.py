@@ -15,7 +15,7 @@ CSRC = os.path.join(ROOT, "titanet_amd", "csrc")
 sys.path.insert(0, ROOT)
 from titanet_amd.csrc.build import FLAGS, SOURCES  # noqa: E402
 
-HOT = re.compile(r"_v2|_v4|_v5|_v6|wide|dgrad|wgrad_batched|pgemm|slab")
+HOT = re.compile(r"_v2|_v3|_v4|_v5|_v6|wide|dgrad|wgrad_batched|pgemm|slab")
 # documented exceptions (spilled VGPRs allowed): everything else on the hot path must not spill
 ALLOW = {}
 
