@@ -398,7 +398,12 @@ inline int launch_dw_fwd_slab(DwFwdSlabArgs a, int KD, hipStream_t st) {
   a.ntiles = a.rowtiles ? a.n_rowtiles * 4 : (a.M + 63) / 64;
   if (a.ntiles <= 0) return 0;
   const int nslab = a.C / 256;
-  int per = 256 / nslab;
+  // K = 7 (TitaNet-M): 80 KB of LDS and <= 114 VGPRs — TWO workgroups fit a CU, and one's tile-top wait (its DMA and the previous
+  // tile's stores, vmcnt(0)) hides behind the other's arithmetic: 49.9 -> 41.3 us per layer at 76800 x 512 with 512 workgroups
+  // (tools/dw_slab_harness, profiles/r05_dw_slab_wgs.txt).  K = 11 needs 88 KB and 140 - 152 VGPRs: one per CU (512: 116 vs 113 us)
+  static const int forced_wgs = [] { const char* e = getenv("TN_DWF_WGS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();      // (tuning switch)
+  const int max_wgs = forced_wgs ? forced_wgs : (KD == 7 ? 512 : 256);
+  int per = max_wgs / nslab;
   if (per < 1) per = 1;
   if (per > a.ntiles) per = a.ntiles;
   const int grid = per * nslab;

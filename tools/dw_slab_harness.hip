@@ -18,6 +18,7 @@ template <class F> float timeit(F f, int n = 20) {
 }
 int main(int argc, char** argv) {
   const int M = 256 * 300, T = 300, CMAX = 1024, NSET = 3;
+  const int BWGS = argc > 1 ? atoi(argv[1]) : 256;      // persistent workgroups of the backward kernel (forward: TN_DWF_WGS)
   std::vector<bf16_t*> D(NSET), X(NSET), O(NSET), ADD(NSET);
   std::vector<unsigned short> hx((size_t)M * CMAX);
   for (size_t i = 0; i < hx.size(); ++i) hx[i] = (unsigned short)((0x3c00 + (i * 7919u) % 0x300) ^ ((i & 1) << 15));
@@ -52,7 +53,7 @@ int main(int argc, char** argv) {
       a.actX = act; a.wdw = wdw; a.g_wdw = gw; a.g_bdw = gb; a.bsumsX = bs; a.M = M; a.T = T; a.C = C;
       int rc = 0;
       float us = timeit([&](int i) { a.dD = D[i % NSET]; a.X = X[i % NSET]; a.OUT = O[i % NSET];
-                                     rc |= K == 7 ? launch_dw_bwd_slab<7>(a, 256, 0) : launch_dw_bwd_slab<11>(a, 256, 0); });
+                                     rc |= K == 7 ? launch_dw_bwd_slab<7>(a, BWGS, 0) : launch_dw_bwd_slab<11>(a, BWGS, 0); });
       printf("C %4d K %2d dw_bwd_slab<BN relu drop>   : %7.2f us  (3t = %.0f MB -> %.2f TB/s) rc %d\n", C, K, us, 3 * t / 1e6, 3 * t / us / 1e6, rc);
     }
   }
