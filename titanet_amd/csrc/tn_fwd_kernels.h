@@ -253,7 +253,10 @@ __global__ __launch_bounds__(512, 2) void dw_fwd_slab_kernel(DwFwdSlabArgs a) {
   constexpr int PADR = (KD - 1) / 2, ROWS = 64 + KD - 1, WPS = 4 / CH, RS = 8 * WPS;
   constexpr int TILE_B = ROWS * 512;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* cst = reinterpret_cast<float*>(smem + 2 * TILE_B);      // sc, sh, bias, wd[KD] : [3 + KD][256]
+  // sc, sh, bias, wd[KD] : [3 + KD][256] — staged through the SECOND tile buffer, which the first DMA does not touch and which is
+  // only refilled behind the loop's first barrier (every thread has its constants in registers by then): 2 x 37 KB at K = 11
+  float* cst = reinterpret_cast<float*>(smem + TILE_B);
+  static_assert((3 + KD) * 256 * 4 <= TILE_B, "constants fit a tile buffer");
   const unsigned ring_lds = (unsigned)(uintptr_t)(tn_lds_char*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cl = (wave % WPS) * 64 * CH + lane * CH;             // first channel of the lane inside the slab
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void dw_fwd_slab_kernel(DwFwdSlabArgs a) {
 }
 template <int KD, int FL>
 inline int launch_dw_fwd_slab_t(DwFwdSlabArgs a, int grid, hipStream_t st) {
-  const size_t smem = (size_t)2 * (64 + KD - 1) * 512 + (size_t)(3 + KD) * 256 * sizeof(float);
+  const size_t smem = (size_t)2 * (64 + KD - 1) * 512;
   // 4 channels per lane (2 measured 140 vs 103 us with dropout: one hash per 8 channels)
   auto kern = a.act.rm.len ? dw_fwd_slab_kernel<KD, FL, 4, true> : dw_fwd_slab_kernel<KD, FL, 4, false>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -4;
@@ -400,7 +403,8 @@ inline int launch_dw_fwd_slab(DwFwdSlabArgs a, int KD, hipStream_t st) {
   const int nslab = a.C / 256;
   // K = 7 (TitaNet-M): 80 KB of LDS and <= 114 VGPRs — TWO workgroups fit a CU, and one's tile-top wait (its DMA and the previous
   // tile's stores, vmcnt(0)) hides behind the other's arithmetic: 49.9 -> 41.3 us per layer at 76800 x 512 with 512 workgroups
-  // (tools/dw_slab_harness, profiles/r05_dw_slab_wgs.txt).  K = 11 needs 88 KB and 140 - 152 VGPRs: one per CU (512: 116 vs 113 us)
+  // (tools/dw_slab_harness, profiles/r05_dw_slab_wgs.txt).  K = 11 needs 140 - 152 VGPRs: one per CU (512 workgroups: 116 vs 113 us;
+  // capped at 128 registers it spills 20 and runs 140 - 173 us)
   static const int forced_wgs = [] { const char* e = getenv("TN_DWF_WGS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();      // (tuning switch)
   const int max_wgs = forced_wgs ? forced_wgs : (KD == 7 ? 512 : 256);
   int per = max_wgs / nslab;
