@@ -963,10 +963,13 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       }
       if (rc1 == -1000) {
         float* acc = p->tail_parts > 1 ? (float*)(ws + p->se_acc) : nullptr;
+        // activation flags of the last sub-block's output as a template parameter where they are the usual ones
+        const int flse = (acur.mode != 0 ? 1 : 0) | (acur.relu ? 2 : 0) | (acur.drop_thr ? 4 : 0);
+        auto kse = flse == 7 ? se_squeeze_fc_kernel<AT, 7> : flse == 3 ? se_squeeze_fc_kernel<AT, 3> : se_squeeze_fc_kernel<AT, -1>;
         if (acc)     // partial column sums from tail_parts workgroups per utterance, then the two mat-vecs per utterance
-          hipLaunchKernelGGL(se_squeeze_fc_kernel<AT>, dim3(B, p->tail_parts), dim3(512), smem, st, (const AT*)cur, acur, T, H, Hr,
+          hipLaunchKernelGGL(kse, dim3(B, p->tail_parts), dim3(512), smem, st, (const AT*)cur, acur, T, H, Hr,
                              params + mb.se_w1, params + mb.se_w2, (float*)(ws + bw.m), (float*)(ws + bw.h), (float*)(ws + bw.g), acc, 1, p->tail_parts);
-        hipLaunchKernelGGL(se_squeeze_fc_kernel<AT>, dim3(B), dim3(512), smem, st, (const AT*)cur, acur, T, H, Hr,
+        hipLaunchKernelGGL(kse, dim3(B), dim3(512), smem, st, (const AT*)cur, acur, T, H, Hr,
                            params + mb.se_w1, params + mb.se_w2, (float*)(ws + bw.m), (float*)(ws + bw.h), (float*)(ws + bw.g), acc, acc ? 2 : 0, p->tail_parts);
       }
       { int rcj = join_skip(); if (rcj) return rcj; }      // the combine reads S and the skip BatchNorm's statistics

@@ -456,7 +456,9 @@ inline int launch_dw_fwd(const AT* X, const BnAct& act, const float* wdw, const 
 // mode 2 (one workgroup per utterance) adds them in order and turns the sums into mean / h / g.
 //   mode 0: everything in one workgroup;  1: partial sums of frames [p T/P, (p+1) T/P) -> acc[b][p];  2: acc[b][0..parts) -> m, h, g
 // ------------------------------------------------------------------------------------------
-template <typename AT>
+// FL >= 0: the activation flags as a compile-time constant (1 BatchNorm, 2 ReLU, 4 dropout) — the row loop of the generic form
+// (FL = -1: run-time flags, a padding test with an integer division per row) is VALU-bound at hidden 512 / 1024
+template <typename AT, int FL = -1>
 __global__ __launch_bounds__(512) void se_squeeze_fc_kernel(const AT* __restrict__ Y, BnAct act, int T, int C, int Hr,
                                                             const float* __restrict__ W1, const float* __restrict__ W2,
                                                             float* __restrict__ m_out, float* __restrict__ h_out,
@@ -500,7 +502,20 @@ __global__ __launch_bounds__(512) void se_squeeze_fc_kernel(const AT* __restrict
       for (int u = 0; u < U; ++u) {
         const int t = t0 + u * TG;
         const uint32_t row = (uint32_t)b * T + min(t, t_hi - 1);
-        act8(v[u], kr, hr, act, row, C, vc * 8);
+        if constexpr (FL >= 0) {
+          // (every row visited is a valid frame: t < t_hi <= len[b])
+          if (FL & 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[u][i] = v[u][i] * kr[i] + hr[i];
+          }
+          if (FL & 2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[u][i] = fmaxf(v[u][i], 0.f);
+          }
+          if (FL & 4) tn_drop8(v[u], (row * (uint32_t)C + (uint32_t)(vc * 8)) >> 3, act.drop_key, act.drop_thr);      // (key resolved above)
+        } else {
+          act8(v[u], kr, hr, act, row, C, vc * 8);
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) s[i] += (t < t_hi) ? v[u][i] : 0.f;
       }
