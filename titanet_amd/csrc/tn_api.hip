@@ -778,7 +778,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   TN_CHECK_HIP(tn_zero_async(ws + p->zero_begin, p->zero_bytes, st));
   if (p->n_cast > 0) {
     hipLaunchKernelGGL(cast_params_kernel<AT>, dim3(64, p->n_cast), dim3(256), 0, st, (const CastDesc*)(ws + p->cast_table));
-    if (sizeof(AT) == 2 && (size_t)c.hidden * c.enc_out >= (size_t)512 * 512)      // (some matrix of the model is large: tiles through LDS)
+    if (sizeof(AT) == 2 && (size_t)c.hidden * c.enc_out >= (size_t)TN_CAST_TILED_MIN)      // (matrices of that size: tiles through LDS)
       hipLaunchKernelGGL(cast_params_tiled_kernel<AT>, dim3(96, p->n_cast), dim3(256), 0, st, (const CastDesc*)(ws + p->cast_table));
     if (p->n_swz) hipLaunchKernelGGL(swizzle256_kernel<0>, dim3(16, p->n_swz), dim3(256), 0, st, (const SwzDesc*)(ws + p->swz_table));
   }

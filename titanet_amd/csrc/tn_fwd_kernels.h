@@ -16,11 +16,14 @@ struct CastDesc {
   int R, C;
 };
 
+// matrices of at least this many elements go through the LDS-tiled kernel below (round 5: 128 x 128 instead of 512 x 512 — the 68
+// 256 x 256 pointwise weights of TitaNet-S spent 32 us per step in the element-wise kernel's strided 2-byte transposed stores)
+#define TN_CAST_TILED_MIN (128 * 128)
 template <typename AT>
 __global__ void cast_params_kernel(const CastDesc* descs) {
   const CastDesc d = descs[blockIdx.y];
   const int n = d.R * d.C;
-  if (sizeof(AT) == 2 && n >= (512 * 512) && !(d.C & 3) && !(d.R & 3)) return;      // large matrices: cast_params_tiled_kernel
+  if (sizeof(AT) == 2 && n >= TN_CAST_TILED_MIN && !(d.C & 3) && !(d.R & 3)) return;      // cast_params_tiled_kernel takes these
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float v = d.src[i];
     if (d.dst) reinterpret_cast<AT*>(d.dst)[i] = Elem<AT>::from_f(v);
@@ -31,12 +34,11 @@ __global__ void cast_params_kernel(const CastDesc* descs) {
   }
 }
 
-// The same for LARGE matrices (R * C >= 512 * 512: the pointwise weights of TitaNet-M / -L, the epilog conv), 64 x 64 tiles through
+// The same for matrices of >= TN_CAST_TILED_MIN elements (every pointwise weight, the epilog conv), 64 x 64 tiles through
 // LDS: the transposed copy of cast_params_kernel is a 2-byte store per lane at a stride of a whole row — 64 cache lines per wave
 // instruction, 218 us per step for the 24.7 M weights of TitaNet-L.  Here both copies are written as 8-byte row pieces.
 // grid (tiles per launch, descriptors); descriptors with small matrices are left to cast_params_kernel (skipped here / there by
 // the same size test).
-#define TN_CAST_TILED_MIN (512 * 512)
 template <typename AT>
 __global__ __launch_bounds__(256) void cast_params_tiled_kernel(const CastDesc* descs) {
   const CastDesc d = descs[blockIdx.y];
