@@ -1101,7 +1101,14 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
     if ((2 * D) % 1024 == 0 && p->slab_bytes >= (size_t)4 * D * sizeof(float)) {
       float* scsh = (float*)(ws + p->slabs);       // scratch: the weight-gradient slabs are idle in the forward pass
       hipLaunchKernelGGL(bn_scale_shift_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, st, actp, 2 * D, scsh);
-      hipLaunchKernelGGL(tail_linear_fwd2_kernel, dim3((B + 3) / 4, (c.emb + 63) / 64), dim3(256), (size_t)4 * 2 * D * sizeof(float), st,
+      // 4 utterances x 16 outputs per workgroup (round 5): 768 workgroups of 48 KB LDS, three per CU, two passes per wave.  The
+      // kernel is a latency chain per workgroup, not L2 traffic: 4 x 64 (192 workgroups, 8 passes per wave) took 37 us, 8 x 32
+      // (half the weight re-reads, 96 KB of LDS: one workgroup per CU) 33 us.  LDS > 128 KB (enc_out 3072 would need 96 KB: fits)
+      constexpr int TL_NB = 4, TL_ET = 16;
+      auto ktl = tail_linear_fwd2_kernel<TL_NB, TL_ET>;
+      const size_t tl_smem = (size_t)TL_NB * 2 * D * sizeof(float);
+      TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ktl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl_smem));
+      hipLaunchKernelGGL(ktl, dim3((B + TL_NB - 1) / TL_NB, (c.emb + TL_ET - 1) / TL_ET), dim3(256), tl_smem, st,
                          (const float*)(ws + p->pooled), (const float*)scsh, B, 2 * D, c.emb, params + m->lin_w, params + m->lin_b,
                          (float*)(ws + p->lin), statp(m->lin_bn));
     } else {

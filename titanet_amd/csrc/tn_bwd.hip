@@ -331,10 +331,10 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     hipLaunchKernelGGL(rows_bn_bwd_sums_kernel, dim3((c.emb + 255) / 256, (B + 15) / 16), dim3(256), 0, st, demb, lin, actL, B, c.emb, bsum(m->lin_bn));
     hipLaunchKernelGGL(rows_bn_bwd_apply_kernel, dim3((B * c.emb + 255) / 256), dim3(256), 0, st, demb, lin,
                        make_bnbwd(p, m->lin_bn, B, training), B, c.emb, dlin);
-    hipLaunchKernelGGL(tail_bwd_dw_kernel, dim3((K2 + 255) / 256, (c.emb + 7) / 8), dim3(256), (size_t)B * 8 * sizeof(float), st, (const float*)dlin, pooled, actP, B, K2,
+    hipLaunchKernelGGL(tail_bwd_dw_kernel, dim3((K2 + 63) / 64, (c.emb + 7) / 8), dim3(256), (size_t)(B * 8 + 4 * 8 * 64) * sizeof(float), st, (const float*)dlin, pooled, actP, B, K2,
                        c.emb, grads + m->lin_w);
     // d pbn -> (in place) d pooled
-    hipLaunchKernelGGL(tail_bwd_dp_kernel, dim3((K2 + 255) / 256, B), dim3(256), 0, st, (const float*)dlin, params + m->lin_w, B, K2,
+    hipLaunchKernelGGL(tail_bwd_dp_kernel, dim3((K2 + 255) / 256, (B + 3) / 4), dim3(256), 0, st, (const float*)dlin, params + m->lin_w, B, K2,
                        c.emb, dpool);
     if (!c.simple_pool) {
       hipLaunchKernelGGL(rows_bn_bwd_sums_kernel, dim3((K2 + 255) / 256, (B + 15) / 16), dim3(256), 0, st, (const float*)dpool, pooled, actP, B, K2,

@@ -1060,50 +1060,81 @@ __global__ __launch_bounds__(256) void rows_bn_bwd_apply_kernel(const float* __r
   }
 }
 
-// d W_lin[e][k] = sum_b dlin[b][e] * pbn[b][k],  pbn = BN(pooled).  grid = (ceil(K/256), ceil(E/8)): every
-// thread owns one k and 8 consecutive e (pbn is read once per 8 outputs; dlin comes from LDS as a broadcast).
+// d W_lin[e][k] = sum_b dlin[b][e] * pbn[b][k],  pbn = BN(pooled).  grid = (ceil(K/64), ceil(E/8)): a workgroup owns 64 k and 8
+// consecutive e; its 4 waves take a QUARTER of the utterances each and their partial sums are added in wave order (round 5: with one
+// thread walking all B utterances the launch was 1152 waves of a 256-step load-to-use chain, 28 us; deterministic, the order of the
+// additions is (q0 + q1) + (q2 + q3) instead of one running sum).  dlin comes from LDS as a broadcast.
 __global__ __launch_bounds__(256) void tail_bwd_dw_kernel(const float* __restrict__ dlin, const float* __restrict__ pooled,
                                                           BnAct actP, int B, int K, int E, float* __restrict__ g_W) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* dl = reinterpret_cast<float*>(smem);   // [B][8]
+  float* part = dl + (size_t)B * 8;             // [4][8][64]
   const int e0 = blockIdx.y * 8;
   for (int i = threadIdx.x; i < B * 8; i += 256) {
     const int b = i >> 3, j = i & 7;
     dl[i] = (e0 + j < E) ? dlin[(size_t)b * E + e0 + j] : 0.f;
   }
   __syncthreads();
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= K) return;
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  const int kc = min(k, K - 1);
   float sc, sh;
-  bn_scale_shift(actP, K, k, sc, sh);
+  bn_scale_shift(actP, K, kc, sc, sh);
   float s[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float pv = pooled[(size_t)b * K + k] * sc + sh;
+  const int per = (B + 3) / 4, b_lo = q * per, b_hi = min(B, b_lo + per);
+  for (int b = b_lo; b < b_hi; ++b) {
+    const float pv = pooled[(size_t)b * K + kc] * sc + sh;
     const float4 d0 = *reinterpret_cast<const float4*>(dl + b * 8), d1 = *reinterpret_cast<const float4*>(dl + b * 8 + 4);
     s[0] = fmaf(d0.x, pv, s[0]); s[1] = fmaf(d0.y, pv, s[1]); s[2] = fmaf(d0.z, pv, s[2]); s[3] = fmaf(d0.w, pv, s[3]);
     s[4] = fmaf(d1.x, pv, s[4]); s[5] = fmaf(d1.y, pv, s[5]); s[6] = fmaf(d1.z, pv, s[6]); s[7] = fmaf(d1.w, pv, s[7]);
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
-    if (e0 + j < E) g_W[(size_t)(e0 + j) * K + k] = s[j];
+  for (int j = 0; j < 8; ++j) part[(q * 8 + j) * 64 + lane] = s[j];
+  __syncthreads();
+  // 512 sums (8 e x 64 k) by 256 threads: two each
+  for (int i = threadIdx.x; i < 8 * 64; i += 256) {
+    const int j = i >> 6, l = i & 63, kk = blockIdx.x * 64 + l;
+    const float v = (part[(0 * 8 + j) * 64 + l] + part[(1 * 8 + j) * 64 + l]) + (part[(2 * 8 + j) * 64 + l] + part[(3 * 8 + j) * 64 + l]);
+    if (kk < K && e0 + j < E) g_W[(size_t)(e0 + j) * K + kk] = v;
+  }
 }
 
-// d pbn[b][k] = sum_e dlin[b][e] * W[e][k]
+// d pbn[b][k] = sum_e dlin[b][e] * W[e][k].  grid = (ceil(K/256), ceil(B/4)): a thread owns one k and FOUR utterances (round 5: with
+// one utterance per workgroup row W was read B times through L2 — 604 MB for a 2.4 MB matrix, 29 us); the sum over e of every
+// (b, k) keeps its four interleaved chains, so the result is bit-identical
 __global__ __launch_bounds__(256) void tail_bwd_dp_kernel(const float* __restrict__ dlin, const float* __restrict__ W, int B,
                                                           int K, int E, float* __restrict__ dpbn) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  const int b = blockIdx.y;
+  const int b0 = blockIdx.y * 4;
   if (k >= K) return;
-  float s4[4] = {0.f, 0.f, 0.f, 0.f};        // independent chains: 4 weight rows in flight
+  float s4[4][4];
+  const float* dl[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    dl[r] = dlin + (size_t)min(b0 + r, B - 1) * E;      // (rows past B: a clamped re-read, not stored)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s4[r][q] = 0.f;
+  }
   int e = 0;
   for (; e + 4 <= E; e += 4) {
+    float w[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s4[q] = fmaf(dlin[(size_t)b * E + e + q], W[(size_t)(e + q) * K + k], s4[q]);
+    for (int q = 0; q < 4; ++q) w[q] = W[(size_t)(e + q) * K + k];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s4[r][q] = fmaf(dl[r][e + q], w[q], s4[r][q]);
   }
-  for (; e < E; ++e) s4[0] = fmaf(dlin[(size_t)b * E + e], W[(size_t)e * K + k], s4[0]);
-  dpbn[(size_t)b * K + k] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  for (; e < E; ++e) {
+    const float w = W[(size_t)e * K + k];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s4[r][0] = fmaf(dl[r][e], w, s4[r][0]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (b0 + r < B) dpbn[(size_t)(b0 + r) * K + k] = (s4[r][0] + s4[r][1]) + (s4[r][2] + s4[r][3]);
 }
 
 // ------------------------------------------------------------------------------------------

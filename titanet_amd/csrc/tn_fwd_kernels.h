@@ -790,19 +790,20 @@ __global__ void bn_scale_shift_kernel(BnAct act, int K, float* __restrict__ scsh
     scsh[k] = sc; scsh[K + k] = sh;
   }
 }
+template <int NB, int ET>
 __global__ __launch_bounds__(256) void tail_linear_fwd2_kernel(const float* __restrict__ pooled, const float* __restrict__ scsh, int B,
                                                                int K, int E, const float* __restrict__ W, const float* __restrict__ bias,
                                                                float* __restrict__ lin, float* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* p = reinterpret_cast<float*>(smem);   // [4][K] normalised pooled rows
-  const int tid = threadIdx.x, b0 = blockIdx.x * 4, e0 = blockIdx.y * 64;
+  float* p = reinterpret_cast<float*>(smem);   // [NB][K] normalised pooled rows
+  const int tid = threadIdx.x, b0 = blockIdx.x * NB, e0 = blockIdx.y * ET;
   for (int k = tid * 4; k < K; k += 1024) {
     const float4 sc = *reinterpret_cast<const float4*>(scsh + k), sh = *reinterpret_cast<const float4*>(scsh + K + k);
-    float4 v[4];
+    float4 v[NB];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) v[s] = (b0 + s < B) ? *reinterpret_cast<const float4*>(pooled + (size_t)(b0 + s) * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < NB; ++s) v[s] = (b0 + s < B) ? *reinterpret_cast<const float4*>(pooled + (size_t)(b0 + s) * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < NB; ++s) {
       const bool ok = b0 + s < B;
       *reinterpret_cast<float4*>(p + s * K + k) = ok ? make_float4(fmaf(v[s].x, sc.x, sh.x), fmaf(v[s].y, sc.y, sh.y), fmaf(v[s].z, sc.z, sh.z), fmaf(v[s].w, sc.w, sh.w))
                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -810,12 +811,14 @@ __global__ __launch_bounds__(256) void tail_linear_fwd2_kernel(const float* __re
   }
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
-  const int e_end = min(E, e0 + 64);
+  const int e_end = min(E, e0 + ET);
   for (int e = e0 + 2 * wave; e < e_end; e += 8) {
     const bool two = e + 1 < e_end;
     const float* w0 = W + (size_t)e * K;
     const float* w1 = W + (size_t)(two ? e + 1 : e) * K;
-    float s[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float s[2][NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) { s[0][q] = 0.f; s[1][q] = 0.f; }
     for (int kb = lane * 4; kb < K; kb += 1024) {
       float4 wv[2][4];
 #pragma unroll
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(256) void tail_linear_fwd2_kernel(const float* __re
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NB; ++q) {
           const float4 pv = *reinterpret_cast<const float4*>(p + q * K + kb + 256 * u);
           s[0][q] += wv[0][u].x * pv.x + wv[0][u].y * pv.y + wv[0][u].z * pv.z + wv[0][u].w * pv.w;
           s[1][q] += wv[1][u].x * pv.x + wv[1][u].y * pv.y + wv[1][u].z * pv.z + wv[1][u].w * pv.w;
@@ -835,12 +838,12 @@ __global__ __launch_bounds__(256) void tail_linear_fwd2_kernel(const float* __re
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) s[h][q] = wave_sum(s[h][q]);
+      for (int q = 0; q < NB; ++q) s[h][q] = wave_sum(s[h][q]);
     if (lane == 0) {
       for (int h = 0; h < (two ? 2 : 1); ++h) {
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NB; ++q) {
           if (b0 + q < B) {
             const float v = s[h][q] + bias[e + h];
             lin[(size_t)(b0 + q) * E + e + h] = v;
