@@ -155,3 +155,33 @@ def test_no_reads_of_in_flight_inline_asm_load_registers():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_asm_hazards.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "tn_bwd.hip: 0 reads" in r.stdout
+
+
+def test_store_data_hazard_checker_flags_the_pattern_it_was_written_for():
+    """tools/check_asm_hazards.py check_store_data on listings of the two forms met in round 5 (se_combine_fwd_v3_kernel, DESIGN.md
+    6): a 16-byte buffer store with an SGPR scalar offset followed by a VALU write of its first data register is flagged; the
+    same store with scalar offset 0 (where hipcc inserts the hazard slots itself) and a write of an unrelated register are not."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_asm_hazards", os.path.join(root, "tools", "check_asm_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = """_Z4kernv:
+	v_cvt_pk_bf16_f32 v47, v62, v63
+	buffer_store_dwordx4 v[44:47], v8, s[48:51], s36 offen
+	v_or_b32_e32 v44, 0xc0, v154
+	s_endpgm
+"""
+    good = """_Z4kernv:
+	buffer_store_dwordx4 v[44:47], v60, s[48:51], 0 offen
+	s_nop 1
+	v_or_b32_e32 v44, 0xc0, v154
+	buffer_store_dwordx4 v[20:23], v8, s[48:51], s36 offen
+	v_or_b32_e32 v24, 0xc0, v154
+	v_cmp_gt_u32_e64 s[2:3], s74, v20
+	s_endpgm
+"""
+    f = mod.check_store_data(bad)
+    assert len(f) == 1 and f[0][3] == [44], f
+    assert mod.check_store_data(good) == []
