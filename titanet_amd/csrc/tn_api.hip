@@ -775,10 +775,14 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   // side stream (tn_plan::overlap): the skip conv of a mega block runs beside its sub-block chain
   const bool ov = p->overlap && use_v2 && p->side != nullptr;
 
+  p->fwd_q16_skipped = false;
   TN_CHECK_HIP(tn_zero_async(ws + p->zero_begin, p->zero_bytes, st));
   if (p->n_cast > 0) {
     hipLaunchKernelGGL(cast_params_kernel<AT>, dim3(64, p->n_cast), dim3(256), 0, st, (const CastDesc*)(ws + p->cast_table));
-    if (sizeof(AT) == 2 && (size_t)c.hidden * c.enc_out >= (size_t)TN_CAST_TILED_MIN)      // (matrices of that size: tiles through LDS)
+    // every bf16 plan: cast_params_kernel leaves each matrix of >= TN_CAST_TILED_MIN elements (R, C multiples of 4) to the tiled
+    // kernel, which returns at once for the others — the two per-descriptor tests must see the same set of launches, whatever the
+    // model's widths (a hidden x enc_out test here once skipped the prolog / pooling matrices of narrow configurations)
+    if (sizeof(AT) == 2)
       hipLaunchKernelGGL(cast_params_tiled_kernel<AT>, dim3(96, p->n_cast), dim3(256), 0, st, (const CastDesc*)(ws + p->cast_table));
     if (p->n_swz) hipLaunchKernelGGL(swizzle256_kernel<0>, dim3(16, p->n_swz), dim3(256), 0, st, (const SwzDesc*)(ws + p->swz_table));
   }
@@ -887,7 +891,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
             fa.Q = (bf16_t*)(ws + bw.Q[j]); fa.Q8 = q8; fa.M = M; fa.T = T; fa.C = H;
             // fp8 weight gradient with column maxima on record: the backward will contract the e4m3 copy — the bf16 one (2 of
             // the 3 bytes this pass writes per element) is not stored (a fallback to the generic producer below stores both)
-            if (p->fp8_wgrad && p->fp8_hist_valid && training && q8 && !bw.Q8.empty()) fa.Q = nullptr;
+            if (p->fp8_wgrad && p->fp8_hist_valid && training && q8 && !bw.Q8.empty()) { fa.Q = nullptr; p->fwd_q16_skipped = true; }
             if (p->masked && p->skip_pad_tiles && p->n_rowtiles > 0) { fa.rowtiles = (const int*)(ws + p->rowtiles); fa.n_rowtiles = p->n_rowtiles; }
             rc = launch_dw_fwd_slab(fa, c.kernel, st);
             if (rc > 0) return rc;

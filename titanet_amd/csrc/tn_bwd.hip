@@ -157,6 +157,9 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   // first backward has no column maxima yet — it runs the bf16 contraction and only RECORDS them
   const bool f8_wgrad = tn_batched && p->fp8_wgrad && p->tn_f8_table != 0 && training;
   const bool f8_wgrad_now = f8_wgrad && p->fp8_hist_valid;
+  // the forward decided from the same flag whether to store the bf16 depthwise outputs: a change in between (a rebind, anything
+  // that drops the history) would send the bf16 contraction over tensors this forward never wrote
+  if (f8_wgrad && !f8_wgrad_now && p->fwd_q16_skipped) return TN_E_STATE;
   auto fcols_of = [&](const BlockWs& bw_, int j) -> Fp8Cols {
     if (!f8_wgrad || bw_.dS8c.empty()) return Fp8Cols{nullptr, nullptr, nullptr, nullptr, 0};
     // (skip_bf16: with the maxima on record the data gradient reads the row-scaled copy and the weight gradient the column-scaled
@@ -331,6 +334,13 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
     hipLaunchKernelGGL(rows_bn_bwd_sums_kernel, dim3((c.emb + 255) / 256, (B + 15) / 16), dim3(256), 0, st, demb, lin, actL, B, c.emb, bsum(m->lin_bn));
     hipLaunchKernelGGL(rows_bn_bwd_apply_kernel, dim3((B * c.emb + 255) / 256), dim3(256), 0, st, demb, lin,
                        make_bnbwd(p, m->lin_bn, B, training), B, c.emb, dlin);
+    {
+      // (B * 8 + 2048 floats of dynamic LDS: past the 64 KB default from B = 1793 on)
+      const size_t dw_smem = (size_t)(B * 8 + 4 * 8 * 64) * sizeof(float);
+      if (dw_smem > (size_t)160 * 1024) return TN_E_UNSUPPORTED;
+      if (dw_smem > (size_t)48 * 1024)
+        TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tail_bwd_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dw_smem));
+    }
     hipLaunchKernelGGL(tail_bwd_dw_kernel, dim3((K2 + 63) / 64, (c.emb + 7) / 8), dim3(256), (size_t)(B * 8 + 4 * 8 * 64) * sizeof(float), st, (const float*)dlin, pooled, actP, B, K2,
                        c.emb, grads + m->lin_w);
     // d pbn -> (in place) d pooled

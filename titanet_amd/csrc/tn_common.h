@@ -330,7 +330,9 @@ struct Fp8Rows { uint8_t* q; uint8_t* rowexp; };      // [M][C] e4m3 bytes, [cei
 struct Fp8Cols { uint8_t* q; const float* amax_prev; float* amax_cur; uint8_t* cexp; int skip_bf16; };      // skip_bf16: both fp8 copies are the only ones read — the bf16 dS is not stored
 // power-of-two scale for a column whose previous maximum was amax: 2^floor(log2(56 / amax)), exponent within +-60; 1 without history
 __device__ __forceinline__ float tn_e4m3_col_scale(float amax) {
-  if (!(amax > 0.f)) return 1.f;
+  // (a non-finite maximum — an overflowed step leaves +inf in the record, NaNs never enter it — is no history either: 56 / inf = 0
+  //  would clamp to 2^-60 and turn every byte of the column into zero on the next backward without any signal)
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
   const float r = 56.f / amax;
   int e = (int)((__float_as_uint(r) >> 23) & 0xffu) - 127;
   e = e < -60 ? -60 : (e > 60 ? 60 : e);

@@ -118,6 +118,7 @@ struct tn_plan {
                                         // (pgemm_tn_f8_batched_kernel); delayed per-column scales: the FIRST backward of a plan has no
                                         // history and runs the bf16 contraction (fp8_hist_valid)
   bool fp8_hist_valid = false;
+  bool fwd_q16_skipped = false;          // the last forward left the bf16 depthwise outputs of the sub-blocks unwritten (fp8 weight gradient with history)
   size_t tn_f8_table = 0, tn_skip_table = 0;   // PGemmTnF8Desc of the sub-block layers / PGemmTnDesc of the skip convs alone (backward order)
   int n_fp8 = 0;
   bool split_dw = false;                // wide models: depthwise producer as its own streaming kernel (forward)

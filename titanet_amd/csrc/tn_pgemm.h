@@ -760,7 +760,11 @@ inline int launch_rwgemm_k512(const GemmShape& g, const PGemmNtArgs& pa, const P
     // LDS-DMA ring of 32-row stages (rwgemm_k512_v2_kernel); the DMA moves whole 1 KB rows: lda == 512 only
     const int ntiles = pa.rowtiles ? pa.n_rowtiles * 8 : (g.M + RW2_R - 1) / RW2_R;
     if (ntiles <= 0) return 0;
-    if (ntiles * tiles_n < 2 * max_wgs || pa.lda != RW_K) return -1000;
+    if (ntiles * tiles_n < 2 * max_wgs) return -1000;
+    if (pa.lda != RW_K) variant = 1;      // a strided A: the register-prefetch kernel below takes any lda
+  }
+  if (variant == 2) {
+    const int ntiles = pa.rowtiles ? pa.n_rowtiles * 8 : (g.M + RW2_R - 1) / RW2_R;
     const size_t smem = (size_t)RW2_NS * RW2_R * RW2_PITCH + (size_t)8 * RW2_R * RW2_OP;
     auto kern = (ea.bias || ea.stats) ? rwgemm_k512_v2_kernel<true> : rwgemm_k512_v2_kernel<false>;
     TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
