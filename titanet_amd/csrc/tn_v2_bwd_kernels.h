@@ -1567,6 +1567,8 @@ inline int launch_dgrad_v2(DgradV2Args a, int max_wgs, hipStream_t st) {
 // ==========================================================================================
 #define V6_R 32
 #define V6_OUT 30
+// position of channel c in a SPLIT row of 256 per-channel constants: the low four channels of every 8-channel vector, then the high four
+__device__ __forceinline__ int v6_split(int c) { return ((c & 4) ? V2_C / 2 : 0) + (c >> 3) * 4 + (c & 3); }
 struct DgradDwArgs {
   const bf16_t* dZ; const bf16_t* Y; BnBwd bn;       // gradient wrt the BatchNorm output of this sub-block, its raw output
   const uint4* Wswz;                                   // W^T in MFMA-fragment order (swizzle256_kernel)
@@ -1612,20 +1614,26 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int vc = tid & 31, rq = tid >> 5, c0 = vc * 8;   // transform layout: 8 channels x rows rq, rq + 16
   const int c4 = lane * 4;                               // stencil layout: 4 channels per lane, one wave per strip of 4 rows
+  const int cs0 = vc * 4, cs1 = V2_C / 2 + vc * 4;       // this thread's two float4 of a SPLIT constant row (v6_split)
   const float mscale = (FL & 4) ? a.actX.inv_keep : 1.f;
   const uint32_t dkey = tn_act_key(a.actX), dthr = a.actX.drop_thr;
   if (tid < V2_C) {
     float k0, k1, k2, s = 1.f, h = 0.f, mean = 0.f, rstd = 1.f;
     bn_bwd_coefs(a.bn, V2_C, tid, k0, k1, k2);
     if (FL & 1) { bn_scale_shift(a.actX, V2_C, tid, s, h); bn_mean_rstd(a.actX, V2_C, tid, mean, rstd); }
-    cst[tid] = k0; cst[V2_C + tid] = k1; cst[2 * V2_C + tid] = k2;
+    // the rows the transform reads per tile as two float4 per thread (k0, k1, k2, sc3, sh3, and gus below) are stored SPLIT:
+    // channels 8 v .. 8 v + 3 of all 32 vectors first, then channels 8 v + 4 .. 8 v + 7 — each ds_read_b128 then has a 16-byte
+    // lane stride (the natural order, a 32-byte stride, is a 2-way bank conflict on every one of them: round 5's counters had
+    // the Z3 variant at 4x the plain variant's SQ_LDS_BANK_CONFLICT)
+    const int ps = v6_split(tid);
+    cst[ps] = k0; cst[V2_C + ps] = k1; cst[2 * V2_C + ps] = k2;
     cst[3 * V2_C + tid] = s; cst[4 * V2_C + tid] = h; cst[5 * V2_C + tid] = mean * rstd; cst[6 * V2_C + tid] = rstd;
 #pragma unroll
     for (int k = 0; k < KD; ++k) cst[(7 + k) * V2_C + tid] = a.wdw[(size_t)tid * KD + k];
     if (Z3) {
       float s3 = 1.f, h3 = 0.f;
       bn_scale_shift(a.act3, V2_C, tid, s3, h3);
-      cst[10 * V2_C + tid] = s3; cst[11 * V2_C + tid] = h3;
+      cst[10 * V2_C + ps] = s3; cst[11 * V2_C + ps] = h3;
     }
   }
   const uint32_t dkey3 = Z3 ? tn_act_key(a.act3) : 0u, dthr3 = Z3 ? a.act3.drop_thr : 0u;
@@ -1639,7 +1647,11 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
     bb = bb < nbat ? bb : nbat - 1;
     pg = *reinterpret_cast<const uint2*>(a.gu + (size_t)bb * 2 * V2_C + (tid & 255) * 2);
   };
-  auto publish_g = [&]() { *reinterpret_cast<uint2*>(gus + (tid >> 8) * 2 * V2_C + (tid & 255) * 2) = pg; };
+  // (thread j < 256 of a half holds floats 2 j, 2 j + 1 of the utterance's [ga | ub] record: one row, two adjacent channels)
+  auto publish_g = [&]() {
+    const int i2 = (tid & 255) * 2;
+    *reinterpret_cast<uint2*>(gus + (tid >> 8) * 2 * V2_C + (i2 & V2_C) + v6_split(i2 & (V2_C - 1))) = pg;
+  };
   bf16x8_t wf[16];
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) wf[ks] = __builtin_bit_cast(bf16x8_t, a.Wswz[((size_t)wave * 16 + ks) * 64 + lane]);
@@ -1689,32 +1701,32 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
         float m[8];
         {
           float c3[8], h3v[8];
-          *reinterpret_cast<float4*>(c3) = *reinterpret_cast<const float4*>(cst + 10 * V2_C + c0);
-          *reinterpret_cast<float4*>(c3 + 4) = *reinterpret_cast<const float4*>(cst + 10 * V2_C + c0 + 4);
-          *reinterpret_cast<float4*>(h3v) = *reinterpret_cast<const float4*>(cst + 11 * V2_C + c0);
-          *reinterpret_cast<float4*>(h3v + 4) = *reinterpret_cast<const float4*>(cst + 11 * V2_C + c0 + 4);
+          *reinterpret_cast<float4*>(c3) = *reinterpret_cast<const float4*>(cst + 10 * V2_C + cs0);
+          *reinterpret_cast<float4*>(c3 + 4) = *reinterpret_cast<const float4*>(cst + 10 * V2_C + cs1);
+          *reinterpret_cast<float4*>(h3v) = *reinterpret_cast<const float4*>(cst + 11 * V2_C + cs0);
+          *reinterpret_cast<float4*>(h3v + 4) = *reinterpret_cast<const float4*>(cst + 11 * V2_C + cs1);
 #pragma unroll
           for (int i = 0; i < 8; ++i) m[i] = (fmaf(y[i], c3[i], h3v[i]) > 0.f) ? 1.f : 0.f;
         }
         if (FL & 4) tn_drop8(m, ((uint32_t)gr * (uint32_t)V2_C + (uint32_t)c0) >> 3, dkey3, dthr3);
-        const float* gsel = gus + (gr >= e0 ? 2 * V2_C : 0) + c0;
+        const float* gsel = gus + (gr >= e0 ? 2 * V2_C : 0);
         float gav[8], ubv[8];
-        *reinterpret_cast<float4*>(gav) = *reinterpret_cast<const float4*>(gsel);
-        *reinterpret_cast<float4*>(gav + 4) = *reinterpret_cast<const float4*>(gsel + 4);
-        *reinterpret_cast<float4*>(ubv) = *reinterpret_cast<const float4*>(gsel + V2_C);
-        *reinterpret_cast<float4*>(ubv + 4) = *reinterpret_cast<const float4*>(gsel + V2_C + 4);
+        *reinterpret_cast<float4*>(gav) = *reinterpret_cast<const float4*>(gsel + cs0);
+        *reinterpret_cast<float4*>(gav + 4) = *reinterpret_cast<const float4*>(gsel + cs1);
+        *reinterpret_cast<float4*>(ubv) = *reinterpret_cast<const float4*>(gsel + V2_C + cs0);
+        *reinterpret_cast<float4*>(ubv + 4) = *reinterpret_cast<const float4*>(gsel + V2_C + cs1);
 #pragma unroll
         for (int i = 0; i < 8; ++i) z[i] = fmaf(z[i], gav[i], ubv[i]) * m[i];
       }
       {
         // k0, k1, k2 from LDS (the registers go to the stencil window): unconditional 16-byte reads, then a select
         float k0v[8], k1v[8], k2v[8];
-        *reinterpret_cast<float4*>(k0v) = *reinterpret_cast<const float4*>(cst + c0);
-        *reinterpret_cast<float4*>(k0v + 4) = *reinterpret_cast<const float4*>(cst + c0 + 4);
-        *reinterpret_cast<float4*>(k1v) = *reinterpret_cast<const float4*>(cst + V2_C + c0);
-        *reinterpret_cast<float4*>(k1v + 4) = *reinterpret_cast<const float4*>(cst + V2_C + c0 + 4);
-        *reinterpret_cast<float4*>(k2v) = *reinterpret_cast<const float4*>(cst + 2 * V2_C + c0);
-        *reinterpret_cast<float4*>(k2v + 4) = *reinterpret_cast<const float4*>(cst + 2 * V2_C + c0 + 4);
+        *reinterpret_cast<float4*>(k0v) = *reinterpret_cast<const float4*>(cst + cs0);
+        *reinterpret_cast<float4*>(k0v + 4) = *reinterpret_cast<const float4*>(cst + cs1);
+        *reinterpret_cast<float4*>(k1v) = *reinterpret_cast<const float4*>(cst + V2_C + cs0);
+        *reinterpret_cast<float4*>(k1v + 4) = *reinterpret_cast<const float4*>(cst + V2_C + cs1);
+        *reinterpret_cast<float4*>(k2v) = *reinterpret_cast<const float4*>(cst + 2 * V2_C + cs0);
+        *reinterpret_cast<float4*>(k2v + 4) = *reinterpret_cast<const float4*>(cst + 2 * V2_C + cs1);
         const bool ok = gr >= 0 && gr < a.M;
         const bool valid = !MK || tn_tile_valid(tm, gr);
 #pragma unroll
