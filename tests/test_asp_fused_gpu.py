@@ -12,7 +12,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _step(env, size, nb, B, T, masked, train=True):
+def _step(env, size, nb, B, T, masked, train=True, fetch=None):
     from titanet_amd import LOSSES, TitaNet
     old = {k: os.environ.get(k) for k in ("TN_ASP_FUSED", "TN_ASP_EXACT")}
     try:
@@ -38,6 +38,10 @@ def _step(env, size, nb, B, T, masked, train=True):
         emb, _, loss = m(x, speakers=y, lengths=lengths)
         loss.backward()
         grad = torch.cat([p.grad.flatten() for p in m.parameters()]).float().cpu()
+        if fetch:
+            D = 1536
+            extra = {k: m.debug_fetch(k, (B, D, T)).float().cpu() for k in fetch}
+            return emb.detach().float().cpu(), float(loss.detach()), grad, extra
         return emb.detach().float().cpu(), float(loss.detach()), grad
     finally:
         for k, v in old.items():
@@ -74,3 +78,29 @@ def test_fused_pooling_eval_is_deterministic_and_close():
     c, _, _ = _step({"TN_ASP_FUSED": "0"}, "s", 1, 256, 300, False, train=False)
     assert torch.equal(a, b)                        # no atomics on the eval path of the pooling: bit-identical reruns
     assert float((a - c).norm() / c.norm()) < 1e-3
+
+
+@pytest.mark.parametrize("B,T", [(256, 300), (24, 300), (192, 129)])
+def test_decoder_gradient_tensors_elementwise(B, T):
+    """The two encoder-output-sized gradient tensors of the decoder side, ELEMENT BY ELEMENT, fused pooling against the
+    stored-energies path.  Round 5 found a store-data hazard that corrupted a few 4-byte pieces per launch of exactly these two
+    tensors (asp_v2<1>, wide_out_v2<128, 2>) for a round: invisible to cosines and norms over 118 M elements.  The two paths
+    differ by the bf16 rounding of the stored energies, a few percent of an element's own size at worst; a corrupted piece is
+    off by the size of the tensor's large elements."""
+    names = ("d_energies", "d_epilog_bn")
+    _, _, _, ref = _step({"TN_ASP_FUSED": "0"}, "s", 1, B, T, False, fetch=names)
+    _, _, _, got = _step({}, "s", 1, B, T, False, fetch=names)
+    for k in names:
+        a, b = ref[k], got[k]
+        assert torch.isfinite(b).all()
+        scale = float(a.abs().max())
+        rms = float(a.pow(2).mean().sqrt())
+        err = (a - b).abs()
+        # an element may differ by a share of its own magnitude (rounded energies -> slightly different softmax weights) plus
+        # a floor of the tensor's typical element; never by a large element's worth
+        bound = 0.25 * a.abs() + 8.0 * rms + 1e-3 * scale      # (measured worst: 5 rms at a mid-sized element)
+        worst = float((err / bound).max())
+        nbad = int((err > bound).sum())
+        print(k, B, T, f"max |ref| {scale:.3e} rms {rms:.3e} max |diff| {float(err.max()):.3e} worst/bound {worst:.3f} beyond {nbad}")
+        assert nbad == 0, (k, nbad, worst)
+        assert float(err.max()) < 0.2 * scale, (k, float(err.max()), scale)

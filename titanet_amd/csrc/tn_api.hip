@@ -1426,6 +1426,11 @@ extern "C" int tn_debug_fetch(tn_plan* p, const char* what, float* dst, int64_t 
   if (w == "pooled") return copyf(p->pooled, (int64_t)p->B * 2 * c.enc_out);
   if (w == "prolog_out") return fetch(p->Y0, make_act(p, m->prolog_bn, p->M, p->last_training, 1, 0.f, 0, 0), c.hidden);
   if (w == "epilog_out") return fetch(p->E, make_act(p, m->epi_bn, p->M, p->last_training, 1, 0.f, 0, 0), c.enc_out);
+  // after tn_backward: the two encoder-output-sized gradient tensors of the decoder side (the attention energies' gradient as
+  // the pooling backward wrote it; the gradient wrt the epilog BatchNorm output with the attention data gradient added) — what
+  // an element-wise comparison of two pooling paths needs (a corrupted 4-byte piece does not move a cosine)
+  if (w == "d_energies") return fetch(p->dE, identity_act(), c.enc_out);
+  if (w == "d_epilog_bn") return fetch(p->dEbn, identity_act(), c.enc_out);
   if (w.rfind("block_out:", 0) == 0) {
     int i = atoi(w.c_str() + 10);
     if (i < 0 || i >= c.n_mega_blocks) return TN_E_BADARG;
