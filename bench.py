@@ -468,11 +468,16 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
+    trainer.reducer.measure = world > 1           # (two event records per step on the rank's streams: nothing at N = 1)
+    trainer.host_enqueue_s, trainer.host_enqueue_steps = 0.0, 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         emb, preds, lv = trainer.step(x, y)
     torch.cuda.synchronize()
     dt_rank = time.perf_counter() - t0            # this rank's own clock (spread across ranks reported below)
+    host_enqueue_ms = trainer.host_enqueue_s / max(trainer.host_enqueue_steps, 1) * 1e3
+    exposed = sorted(trainer.reducer.exposed_ms()) if world > 1 else []
+    trainer.reducer.measure = False
     barrier()
     dt = time.perf_counter() - t0
     ms, cnt = C.c_double(), C.c_int64()
@@ -551,6 +556,11 @@ def main():
                        "grad_groups_note": ("N > 1 runs the weight-gradient launch per gradient bucket (overlapped all-reduce): the same rank "
                                             "program costs ~0.1 ms/step more than the single-bucket N = 1 program (DESIGN.md 5)") if world > 1 else None,
                        "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
+                       # rank 0's host time to ENQUEUE a step (asynchronous launches; must stay below ms_per_step or the GPU starves:
+                       # N ranks share the host's cores) and, at N > 1, the part of the gradient all-reduce that backward did not
+                       # hide: end of the last bucket's collective - end of backward, HIP events on the rank's two streams
+                       "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
+                       "exposed_allreduce_ms": ({"median": round(exposed[len(exposed) // 2], 3), "max": round(exposed[-1], 3)} if exposed else None),
                        "device": device_note(dev)},
             "roofline": {
                 "bound": "hbm", "scope": "whole step: SURVEY.md 8(d) algorithmic bytes / step time (per GPU)",

@@ -192,4 +192,7 @@ def test_bench_spawn_path_two_ranks_same_device():
     assert d["n_gpus"] == 2 and cfg["rccl_ranks"] == 2 and cfg["global_batch"] == 128 and cfg["parallelism"] == "dp2"
     assert cfg["grad_groups"] == 2 and cfg["grad_groups_note"] and cfg["params_finite"]
     assert 0 < cfg["rank_ms_per_step"]["min"] <= cfg["rank_ms_per_step"]["max"]
+    # the two multi-rank health numbers: host enqueue time per step, and what of the all-reduce backward did not hide
+    assert cfg["host_enqueue_ms_per_step"] > 0
+    assert cfg["exposed_allreduce_ms"] is not None and 0 <= cfg["exposed_allreduce_ms"]["median"] <= cfg["exposed_allreduce_ms"]["max"]
     assert abs(d["value"] - 128 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3 and d["scaling"] == "weak"

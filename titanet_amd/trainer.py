@@ -20,6 +20,7 @@ lives in device memory (``tn_plan_step_tick`` / ``tn_adam_step_plan``, include/t
 launch-bound (batch 8: the reference's own parameters.yml batch), which is where this pays.
 """
 import ctypes as C
+import time
 
 import torch
 import torch.distributed as dist
@@ -47,6 +48,26 @@ class FlatAllReducer:
         self.n_buckets, self.group = n_buckets, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self._stream = None
+        # measure = True: every reduction records (end of backward on the compute stream, end of the last collective on the
+        # communication stream) — the part of the all-reduce backward did NOT hide is the time between the two (exposed_ms)
+        self.measure = False
+        self._marks = []
+
+    def _mark(self, cur, done_stream):
+        if not self.measure:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        return e0
+
+    def exposed_ms(self):
+        """Per measured step: max(0, last collective's end - backward's end) in ms (synchronises the recorded events)."""
+        out = []
+        for e0, e1 in self._marks:
+            e1.synchronize()
+            out.append(max(0.0, e0.elapsed_time(e1)))
+        self._marks = []
+        return out
 
     def all_reduce_overlapped_(self, flat, plan, lib):
         """The overlapped form: backward has been ENQUEUED on the current stream and records one event per gradient bucket
@@ -62,8 +83,11 @@ class FlatAllReducer:
             for i, (lo, hi) in enumerate(plan.buckets):
                 check(lib.tn_plan_wait_grad_bucket(plan.handle, i, C.c_void_p(self._stream.cuda_stream)), "tn_plan_wait_grad_bucket")
                 dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(enable_timing=self.measure)
             done.record(self._stream)
+        e0 = self._mark(cur, self._stream)      # backward's last kernel is the last thing enqueued on the compute stream
+        if e0 is not None:
+            self._marks.append((e0, done))
         cur.wait_event(done)
         return flat
 
@@ -82,8 +106,10 @@ class FlatAllReducer:
                 # blocks (high offsets) first
                 for lo, hi in reversed(bucket_ranges(flat.numel(), self.n_buckets)):
                     dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
-                done = torch.cuda.Event()
+                done = torch.cuda.Event(enable_timing=self.measure)
                 done.record(self._stream)
+            if self.measure:
+                self._marks.append((self._mark(cur, self._stream), done))
             cur.wait_event(done)
         else:
             for lo, hi in reversed(bucket_ranges(flat.numel(), self.n_buckets)):
@@ -103,6 +129,7 @@ class Trainer:
         # every step (tn_mark_host), sleeping between polls — never spinning, see _lib.HostMarks.
         self.max_steps_in_flight = max(0, int(max_steps_in_flight))
         self._marks, self._mark_i = None, 0
+        self.host_enqueue_s, self.host_enqueue_steps = 0.0, 0
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.reducer = FlatAllReducer(n_buckets, group)
         self.step_count = 0
@@ -162,7 +189,12 @@ class Trainer:
 
     def step(self, spectrograms, speakers, lengths=None):
         self._throttle()
+        t0 = time.perf_counter()
         out = self._step(spectrograms, speakers, lengths)
+        # host time to ENQUEUE the step (launches are asynchronous): what must stay below the step time on every rank for the
+        # GPU not to starve — 8 ranks share the host's cores (bench.py reports it per step)
+        self.host_enqueue_s += time.perf_counter() - t0
+        self.host_enqueue_steps += 1
         self._mark_step(out[0].device)
         return out
 
