@@ -26,6 +26,9 @@
 #define V2_NT 512
 #define WG2_RK 32
 #define WG2_PITCH 288      // 576-byte rows: the 4 rows of a transpose read land on distinct banks
+#ifndef V5_MD
+#define V5_MD 0      // tuning only: fragment reads in flight of a hand-scheduled MFMA phase in sub_fwd_v5's consumers (0: hipcc's schedule)
+#endif
 #ifndef V2_DBG_SKIP
 #define V2_DBG_SKIP 0   // tuning only: 1 skip MFMA, 2 skip stencil, 4 skip global stores, 8 skip act
 #endif
@@ -992,6 +995,15 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) { acc[cbk][0][r] = biasr[cbk][r]; acc[cbk][1][r] = biasr[cbk][r]; }
         const bf16_t* brow = As + (lane & 31) * V2_AP + half * 8;
+#if V5_MD
+        if constexpr (R == 32) {
+          // hand-scheduled: V5_MD fragment reads in flight (tuning switch; this wave is the only MFMA wave of its SIMD)
+          f32x16_t a2[2] = {acc[0][0], acc[1][0]};
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          tn_mfma_sched_lds<16, 1, 2, V5_MD, 32, 0>(&wf[0][0], brow, &a2[0]);
+          acc[0][0] = a2[0]; acc[1][0] = a2[1];
+        } else
+#endif
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
           const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(brow + ks * 16);
