@@ -701,7 +701,9 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_v2_kernel(GemmShape g, PGe
       typedef __attribute__((ext_vector_type(4))) unsigned int rw2_u32x4_t;
       const rw2_u32x4_t u = *reinterpret_cast<const rw2_u32x4_t*>(ob + o * RW2_OP + opc * 16);
       const unsigned voff = ((unsigned)gr * (unsigned)ea.ldy + (unsigned)(col0 + wave * 32 + opc * 8)) * 2u;
-      asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(u), "v"(voff), "s"(srdY) : "memory");
+      // (s_nop: an inline-asm store gets no hazard slots from hipcc before a write of its data registers — found in the v3
+      //  kernel below, where the next row's ds_read landed in them; here the two rows happen to get distinct registers)
+      asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(u), "v"(voff), "s"(srdY) : "memory");
       if (EPI && ea.stats && gr < g.M) {
         const uint32_t uw[4] = {u[0], u[1], u[2], u[3]};
 #pragma unroll
@@ -744,6 +746,158 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_v2_kernel(GemmShape g, PGe
     }
   }
 }
+// ==========================================================================================
+// rwgemm_k512_v3_kernel (round 6): the ring of rwgemm_k512_v2 with 64 OUTPUT COLUMNS PER WAVE.  v2's eight waves own 32 columns
+// each: every 16-byte B fragment read from LDS feeds ONE MFMA (1 KB of LDS per MFMA, 256 KB per 32-row tile: LDS reads and the
+// matrix pipe are co-bound and did not overlap, 2.3 us per tile against 0.85).  Here a workgroup is FOUR waves, one per SIMD,
+// each holding the 64 x 512 weight block of its columns — 256 registers per lane, which only fits at one wave per SIMD (512
+// registers: hipcc keeps what does not fit the 256 architectural ones in AGPRs) — so a fragment feeds TWO MFMAs and a tile costs
+// 128 KB of LDS reads.  The fragment reads are hand-scheduled (tn_mfma_sched_lds, 8 in flight: nothing else runs on the SIMD to
+// cover an exposed LDS round trip).  DMA: 8 rows per wave and stage; output: a private 32 x 64-column block per wave.
+// MEASURED (profiles/r06_rwgemm_v3.txt): 51.6 / 57.6 us against v2's 49.9 / 52.4 (plain / bias + statistics) at 76800 x 512 x 512 —
+// halving the fragment reads buys nothing, the lone wave's serial epilogue costs 2 - 5 us: the kernel runs at ~3.1 TB/s of its own
+// bytes whatever N is (r05 N sweep), i.e. it is the stream, not LDS or the matrix pipe.  Not the default (TN_RW_VARIANT=3 selects it).
+// ==========================================================================================
+#define RW3_OP 144           // pitch (bytes) of a wave's private 32 x 64-channel output block
+template <bool EPI>
+__global__ __launch_bounds__(256, 1) void rwgemm_k512_v3_kernel(GemmShape g, PGemmNtArgs pa, PGemmEpiArgs ea, int tiles_n, int ntiles) {
+  constexpr int STAGE_B = RW2_R * RW2_PITCH;      // 33280
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);                           // [8][2][256] at the end (inside the ring)
+  const unsigned lds0 = (unsigned)(uintptr_t)(tn_lds_char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* ob = smem + RW2_NS * STAGE_B + wave * (RW2_R * RW3_OP);         // this wave's output block
+  const int G = gridDim.x, v = pg_virtual_id(blockIdx.x, G);
+  const int ct = v % tiles_n, first = v / tiles_n, stride = G / tiles_n;      // G is a multiple of tiles_n (launcher)
+  const int col0 = ct * 256;
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
+  const int* __restrict__ rowtiles = pa.rowtiles;
+  bf16x8_t wf[2 * 32];      // [column block][k-step]
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const bf16_t* wr = W + (size_t)(col0 + wave * 64 + cb * 32 + (lane & 31)) * RW_K + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) wf[cb * 32 + ks] = *reinterpret_cast<const bf16x8_t*>(wr + ks * 16);
+  }
+  float bv[EPI ? 32 : 1];
+  if constexpr (EPI) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[cb * 16 + 4 * gq + r] = ea.bias ? ea.bias[col0 + wave * 64 + cb * 32 + 8 * gq + 4 * half + r] : 0.f;
+  }
+  const pg_i32x4_t srdA = pg_make_srd(pa.A, (unsigned)((size_t)g.M * pa.lda * sizeof(bf16_t)));
+  const pg_i32x4_t srdY = pg_make_srd(ea.Y, (unsigned)((size_t)g.M * ea.ldy * sizeof(bf16_t)));
+  auto tile_row0 = [&](int t) -> int {
+    if (t >= ntiles) return g.M;
+    return rowtiles ? tn_sload_i32(rowtiles, t >> 3) * 256 + (t & 7) * RW2_R : t * RW2_R;
+  };
+  // this wave's rows of a stage: wave + 4 q
+  auto dma_tile = [&](int t, int stage) {
+    const int r0 = tile_row0(t);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int row = wave + 4 * q;
+      const unsigned voff = (unsigned)(r0 + row) * (unsigned)(pa.lda * 2) + (unsigned)lane * 16u;
+      pg_dma16_buf(voff, srdA, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + row * RW2_PITCH)));
+    }
+  };
+  // output pieces of this lane: (row orow + 8 q, 16-byte piece opc of the wave's 128-byte row segment)
+  const int orow = lane >> 3, opc = lane & 7;
+  float ssum[EPI ? 8 : 1], ssq[EPI ? 8 : 1];
+  if constexpr (EPI) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ssum[i] = 0.f; ssq[i] = 0.f; }
+  }
+  // (see rwgemm_k512_v2: the compiler-visible loads retire here, and the compiler knows it)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int ks = 0; ks < 64; ++ks) asm volatile("" : "+v"(wf[ks]));
+  if constexpr (EPI) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(bv[i]));
+  }
+  int tile = first, it = 0, stage = 0;
+#pragma unroll 1
+  for (int d = 0; d < RW2_NS - 1; ++d) dma_tile(tile + d * stride, d);
+#pragma unroll 1
+  for (; tile < ntiles; tile += stride, ++it) {
+    // this wave's rows of the stage have landed: per iteration the queue holds 8 DMA instructions then 4 output stores
+    if (it == 0) pg_wait<16>();
+    else if (it == 1) pg_wait<20>();
+    else if (it == 2) pg_wait<24>();
+    else pg_wait<28>();
+    pg_barrier();      // everybody's rows have landed; every wave is past its MFMAs of the previous tile
+    {
+      const int ns = stage == 0 ? RW2_NS - 1 : stage - 1;      // the stage of the previous tile is free now
+      dma_tile(tile + (RW2_NS - 1) * stride, ns);
+    }
+    const char* st_ = smem + stage * STAGE_B;
+    f32x16_t acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = EPI ? bv[r] : 0.f; acc[1][r] = EPI ? bv[16 + r] : 0.f; }
+    const char* brow = st_ + (lane & 31) * RW2_PITCH + half * 16;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    tn_mfma_sched_lds<32, 1, 2, 8, 32, 0>(&wf[0], brow, &acc[0]);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        uint2 w;
+        w.x = f2bf_pk(acc[cb][4 * gq], acc[cb][4 * gq + 1]);
+        w.y = f2bf_pk(acc[cb][4 * gq + 2], acc[cb][4 * gq + 3]);
+        *reinterpret_cast<uint2*>(ob + (lane & 31) * RW3_OP + (cb * 32 + 8 * gq + 4 * half) * 2) = w;
+      }
+    // (the block is private to the wave: the compiler's lgkmcnt wait orders the reads below behind the writes above)
+    const int r0 = tile_row0(tile);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = orow + 8 * q, gr = r0 + o;
+      typedef __attribute__((ext_vector_type(4))) unsigned int rw3_u32x4_t;
+      const rw3_u32x4_t u = *reinterpret_cast<const rw3_u32x4_t*>(ob + o * RW3_OP + opc * 16);
+      const unsigned voff = ((unsigned)gr * (unsigned)ea.ldy + (unsigned)(col0 + wave * 64 + opc * 8)) * 2u;
+      // (s_nop: an inline-asm store gets no hazard slots from hipcc, and the next row's ds_read lands in the same data registers —
+      //  without it the plain variant wrote 5 % wrong elements)
+      asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(u), "v"(voff), "s"(srdY) : "memory");
+      if (EPI && ea.stats && gr < g.M) {
+        const uint32_t uw[4] = {u[0], u[1], u[2], u[3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float y0 = __uint_as_float(uw[i] << 16), y1 = __uint_as_float(uw[i] & 0xffff0000u);
+          ssum[2 * i] += y0; ssq[2 * i] = fmaf(y0, y0, ssq[2 * i]);
+          ssum[2 * i + 1] += y1; ssq[2 * i + 1] = fmaf(y1, y1, ssq[2 * i + 1]);
+        }
+      }
+    }
+    stage = stage + 1 == RW2_NS ? 0 : stage + 1;
+  }
+  pg_wait<0>();
+  if (EPI && ea.stats) {
+    __syncthreads();
+    {
+      // columns of this lane: wave * 64 + opc * 8 + i; the 8 lanes groups (orow) hold partial sums of the same columns
+      const int sv = wave * 8 + opc, sr = orow;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { red[(sr * 2 + 0) * 256 + sv * 8 + i] = ssum[i]; red[(sr * 2 + 1) * 256 + sv * 8 + i] = ssq[i]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const int c = tid;      // 256 threads: one column each, sums then sums of squares
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += red[(k * 2 + which) * 256 + c];
+      if (first == 0 && ea.pad_rows != 0.f && ea.bias) {
+        const float b = bf2f((bf16_t)(f2bf_pk(ea.bias[col0 + c], 0.f) & 0xffffu));
+        s = which ? fmaf(-ea.pad_rows * b, b, s) : fmaf(-ea.pad_rows, b, s);
+      }
+      atomic_add_f32(ea.stats + (size_t)((blockIdx.x % TN_NREP) * 2 + which) * g.N + col0 + c, s);
+    }
+  }
+}
 // -1000: not this kernel's shape
 // variant: 2 = the LDS-DMA ring kernel (falls through to 1 when its shape conditions fail), 1 = register prefetch
 inline int launch_rwgemm_k512(const GemmShape& g, const PGemmNtArgs& pa, const PGemmEpiArgs& ea, hipStream_t st, int max_wgs, int variant = 2) {
@@ -755,6 +909,19 @@ inline int launch_rwgemm_k512(const GemmShape& g, const PGemmNtArgs& pa, const P
   {
     static const int forced = [] { const char* e = getenv("TN_RW_VARIANT"); return e ? atoi(e) : 0; }();      // (debug switch)
     if (forced) variant = forced;
+  }
+  if (variant == 3) {
+    // 64 columns per wave, one wave per SIMD (rwgemm_k512_v3_kernel); same shape conditions as variant 2
+    const int ntiles = pa.rowtiles ? pa.n_rowtiles * 8 : (g.M + RW2_R - 1) / RW2_R;
+    if (ntiles <= 0) return 0;
+    if (ntiles * tiles_n < 2 * max_wgs || pa.lda != RW_K) variant = 2;
+    else {
+      const size_t smem = (size_t)RW2_NS * RW2_R * RW2_PITCH + (size_t)4 * RW2_R * RW3_OP;
+      auto kern = (ea.bias || ea.stats) ? rwgemm_k512_v3_kernel<true> : rwgemm_k512_v3_kernel<false>;
+      TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, g, pa, ea, tiles_n, ntiles);
+      return (int)hipGetLastError();
+    }
   }
   if (variant == 2) {
     // LDS-DMA ring of 32-row stages (rwgemm_k512_v2_kernel); the DMA moves whole 1 KB rows: lda == 512 only
