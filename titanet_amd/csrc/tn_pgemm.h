@@ -569,6 +569,9 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_kernel(GemmShape g, PGemmN
 // Past its last tile a workgroup keeps requesting out-of-range rows (descriptor bounds check: zeros, no memory traffic): every
 // wait has the same count and no branch splits the stream.
 // ==========================================================================================
+#ifndef RW_DBG
+#define RW_DBG 0      // tuning only: 1 = rwgemm_k512_v2 runs 2 of its 32 k-steps (the stream without the arithmetic), 2 = no output stores
+#endif
 #define RW2_R 32
 #define RW2_PITCH 1040       // bytes: 1 KB row + 16
 #define RW2_NS 4
@@ -675,7 +678,7 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_v2_kernel(GemmShape g, PGe
 #pragma unroll
     for (int d = 0; d < PF; ++d) bq[d] = *reinterpret_cast<const bf16x8_t*>(brow + d * 32);
 #pragma unroll
-    for (int ks = 0; ks < 32; ++ks) {
+    for (int ks = 0; ks < ((RW_DBG & 1) ? 2 : 32); ++ks) {
       const bf16x8_t b0 = bq[ks % PF];
       if (ks + PF < 32) bq[ks % PF] = *reinterpret_cast<const bf16x8_t*>(brow + (ks + PF) * 32);
       if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b0, acc1, 0, 0, 0);
@@ -703,7 +706,8 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_v2_kernel(GemmShape g, PGe
       const unsigned voff = ((unsigned)gr * (unsigned)ea.ldy + (unsigned)(col0 + wave * 32 + opc * 8)) * 2u;
       // (s_nop: an inline-asm store gets no hazard slots from hipcc before a write of its data registers — found in the v3
       //  kernel below, where the next row's ds_read landed in them; here the two rows happen to get distinct registers)
-      asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(u), "v"(voff), "s"(srdY) : "memory");
+      if (!(RW_DBG & 2)) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(u), "v"(voff), "s"(srdY) : "memory");
+      else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(u), "v"(0x7ffffff0u), "s"(srdY) : "memory");
       if (EPI && ea.stats && gr < g.M) {
         const uint32_t uw[4] = {u[0], u[1], u[2], u[3]};
 #pragma unroll
@@ -898,6 +902,150 @@ __global__ __launch_bounds__(256, 1) void rwgemm_k512_v3_kernel(GemmShape g, PGe
     }
   }
 }
+// ==========================================================================================
+// rwgemm_k512_v4_kernel (round 6): v2's ring kernel as TWO INDEPENDENT 256-thread workgroups per CU on 128-column tiles.
+// v2's cycle stamps: per wave and tile 1963 cycles in the MFMA loop (the pipe is full there: 2 waves x 32 MFMAs x 32 cycles) and
+// 844 + 962 cycles waiting for the ring / in the output phase, during which the pipe idles — both waves of a SIMD are in the same
+// phase of the same tile, the per-tile workgroup barrier keeps them there.  Two workgroups per CU share nothing but the CU: their
+// phases drift apart and one's output phase runs under the other's MFMA loop.  Each wave still owns 32 columns (128 weight
+// registers); ring of RW4_NS stages per workgroup (2 x 2 x 33 KB per CU); every A row is read by N / 128 workgroups, adjacent in
+// launch order (one XCD: L2 hits).
+// ==========================================================================================
+#define RW4_NS 2
+template <bool EPI>
+__global__ __launch_bounds__(256, 2) void rwgemm_k512_v4_kernel(GemmShape g, PGemmNtArgs pa, PGemmEpiArgs ea, int tiles_n, int ntiles) {
+  constexpr int STAGE_B = RW2_R * RW2_PITCH;      // 33280
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);                           // [16][2][128] at the end (inside the ring)
+  const unsigned lds0 = (unsigned)(uintptr_t)(tn_lds_char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* ob = smem + RW4_NS * STAGE_B + wave * (RW2_R * RW2_OP);         // this wave's output block
+  const int G = gridDim.x, v = pg_virtual_id(blockIdx.x, G);
+  const int ct = v % tiles_n, first = v / tiles_n, stride = G / tiles_n;      // G is a multiple of tiles_n (launcher)
+  const int col0 = ct * 128;
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
+  const int* __restrict__ rowtiles = pa.rowtiles;
+  bf16x8_t wf[32];
+  {
+    const bf16_t* wr = W + (size_t)(col0 + wave * 32 + (lane & 31)) * RW_K + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) wf[ks] = *reinterpret_cast<const bf16x8_t*>(wr + ks * 16);
+  }
+  float bv[EPI ? 16 : 1];
+  if constexpr (EPI) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[4 * gq + r] = ea.bias ? ea.bias[col0 + wave * 32 + 8 * gq + 4 * half + r] : 0.f;
+  }
+  const pg_i32x4_t srdA = pg_make_srd(pa.A, (unsigned)((size_t)g.M * pa.lda * sizeof(bf16_t)));
+  const pg_i32x4_t srdY = pg_make_srd(ea.Y, (unsigned)((size_t)g.M * ea.ldy * sizeof(bf16_t)));
+  auto tile_row0 = [&](int t) -> int {
+    if (t >= ntiles) return g.M;
+    return rowtiles ? tn_sload_i32(rowtiles, t >> 3) * 256 + (t & 7) * RW2_R : t * RW2_R;
+  };
+  // this wave's rows of a stage: wave + 4 q
+  auto dma_tile = [&](int t, int stage) {
+    const int r0 = tile_row0(t);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int row = wave + 4 * q;
+      const unsigned voff = (unsigned)(r0 + row) * (unsigned)(pa.lda * 2) + (unsigned)lane * 16u;
+      pg_dma16_buf(voff, srdA, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + row * RW2_PITCH)));
+    }
+  };
+  const int orow = lane >> 2, opc = lane & 3;
+  float ssum[EPI ? 8 : 1], ssq[EPI ? 8 : 1];
+  if constexpr (EPI) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ssum[i] = 0.f; ssq[i] = 0.f; }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) asm volatile("" : "+v"(wf[ks]));
+  if constexpr (EPI) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(bv[i]));
+  }
+  int tile = first, it = 0, stage = 0;
+#pragma unroll 1
+  for (int d = 0; d < RW4_NS - 1; ++d) dma_tile(tile + d * stride, d);
+#pragma unroll 1
+  for (; tile < ntiles; tile += stride, ++it) {
+    // per iteration the queue holds 8 DMA instructions (issued at the top, for the next tile) then 2 output stores: what may
+    // stay outstanding behind this tile's rows is the previous iteration's 2 stores
+    if (it == 0) pg_wait<0>();
+    else pg_wait<2>();
+    pg_barrier();      // everybody's rows have landed; every wave is past its MFMAs of the previous tile
+    dma_tile(tile + (RW4_NS - 1) * stride, stage ^ 1);
+    const char* st_ = smem + stage * STAGE_B;
+    f32x16_t acc, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
+    const char* brow = st_ + (lane & 31) * RW2_PITCH + half * 16;
+    constexpr int PF = 8;
+    bf16x8_t bq[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) bq[d] = *reinterpret_cast<const bf16x8_t*>(brow + d * 32);
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+      const bf16x8_t b0 = bq[ks % PF];
+      if (ks + PF < 32) bq[ks % PF] = *reinterpret_cast<const bf16x8_t*>(brow + (ks + PF) * 32);
+      if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b0, acc1, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b0, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      uint2 w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[4 * gq + r] += acc1[4 * gq + r] + (EPI ? bv[4 * gq + r] : 0.f);
+      w.x = f2bf_pk(acc[4 * gq], acc[4 * gq + 1]);
+      w.y = f2bf_pk(acc[4 * gq + 2], acc[4 * gq + 3]);
+      *reinterpret_cast<uint2*>(ob + (lane & 31) * RW2_OP + (8 * gq + 4 * half) * 2) = w;
+    }
+    const int r0 = tile_row0(tile);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int o = orow + 16 * q, gr = r0 + o;
+      typedef __attribute__((ext_vector_type(4))) unsigned int rw4_u32x4_t;
+      const rw4_u32x4_t u = *reinterpret_cast<const rw4_u32x4_t*>(ob + o * RW2_OP + opc * 16);
+      const unsigned voff = ((unsigned)gr * (unsigned)ea.ldy + (unsigned)(col0 + wave * 32 + opc * 8)) * 2u;
+      asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(u), "v"(voff), "s"(srdY) : "memory");
+      if (EPI && ea.stats && gr < g.M) {
+        const uint32_t uw[4] = {u[0], u[1], u[2], u[3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float y0 = __uint_as_float(uw[i] << 16), y1 = __uint_as_float(uw[i] & 0xffff0000u);
+          ssum[2 * i] += y0; ssq[2 * i] = fmaf(y0, y0, ssq[2 * i]);
+          ssum[2 * i + 1] += y1; ssq[2 * i + 1] = fmaf(y1, y1, ssq[2 * i + 1]);
+        }
+      }
+    }
+    stage ^= 1;
+  }
+  pg_wait<0>();
+  if (EPI && ea.stats) {
+    __syncthreads();
+    {
+      const int sv = wave * 4 + opc, sr = orow;      // columns wave * 32 + opc * 8 + i of the 128; 16 row groups
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { red[(sr * 2 + 0) * 128 + sv * 8 + i] = ssum[i]; red[(sr * 2 + 1) * 128 + sv * 8 + i] = ssq[i]; }
+    }
+    __syncthreads();
+    {
+      const int which = tid >> 7, c = tid & 127;      // 256 threads: sums | sums of squares of the 128 columns
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += red[(k * 2 + which) * 128 + c];
+      if (first == 0 && ea.pad_rows != 0.f && ea.bias) {
+        const float b = bf2f((bf16_t)(f2bf_pk(ea.bias[col0 + c], 0.f) & 0xffffu));
+        s = which ? fmaf(-ea.pad_rows * b, b, s) : fmaf(-ea.pad_rows, b, s);
+      }
+      atomic_add_f32(ea.stats + (size_t)((blockIdx.x % TN_NREP) * 2 + which) * g.N + col0 + c, s);
+    }
+  }
+}
 // -1000: not this kernel's shape
 // variant: 2 = the LDS-DMA ring kernel (falls through to 1 when its shape conditions fail), 1 = register prefetch
 inline int launch_rwgemm_k512(const GemmShape& g, const PGemmNtArgs& pa, const PGemmEpiArgs& ea, hipStream_t st, int max_wgs, int variant = 2) {
@@ -909,6 +1057,21 @@ inline int launch_rwgemm_k512(const GemmShape& g, const PGemmNtArgs& pa, const P
   {
     static const int forced = [] { const char* e = getenv("TN_RW_VARIANT"); return e ? atoi(e) : 0; }();      // (debug switch)
     if (forced) variant = forced;
+  }
+  if (variant == 4) {
+    // two independent 256-thread workgroups per CU on 128-column tiles (rwgemm_k512_v4_kernel)
+    const int ntiles = pa.rowtiles ? pa.n_rowtiles * 8 : (g.M + RW2_R - 1) / RW2_R;
+    const int tn4 = g.N / 128;
+    int grid4 = ((2 * max_wgs) / (8 * tn4)) * 8 * tn4;
+    if (ntiles <= 0) return 0;
+    if (grid4 <= 0 || ntiles * tn4 < 2 * grid4 || pa.lda != RW_K) variant = 2;
+    else {
+      const size_t smem = (size_t)RW4_NS * RW2_R * RW2_PITCH + (size_t)4 * RW2_R * RW2_OP;
+      auto kern = (ea.bias || ea.stats) ? rwgemm_k512_v4_kernel<true> : rwgemm_k512_v4_kernel<false>;
+      TN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL(kern, dim3(grid4), dim3(256), smem, st, g, pa, ea, tn4, ntiles);
+      return (int)hipGetLastError();
+    }
   }
   if (variant == 3) {
     // 64 columns per wave, one wave per SIMD (rwgemm_k512_v3_kernel); same shape conditions as variant 2

@@ -111,15 +111,15 @@ int main(int argc, char** argv) {
     // the two resident-weight kernels side by side (variant 1: register prefetch, 2: LDS-DMA ring), forward (bias + statistics)
     // and data-gradient (plain) forms; outputs compared bitwise
     for (int epi = 0; epi < 2; ++epi) {
-      std::vector<unsigned short> y1((size_t)M * N), y2((size_t)M * N), y3((size_t)M * N);
-      for (int var = 1; var <= 3; ++var) {
+      std::vector<unsigned short> y1((size_t)M * N), y2((size_t)M * N), y3((size_t)M * N), y4((size_t)M * N);
+      for (int var = 1; var <= 4; ++var) {
         PGemmNtArgs pa{A[0], K};
         PGemmEpiArgs ea{Y[0], N, epi ? bias : nullptr, epi ? stats_tmp : nullptr, nullptr};
         CK(hipMemset(Y[0], 0, (size_t)M * N * 2));
         int rc = launch_rwgemm_k512(g, pa, ea, 0, 256, var);
         if (rc) { printf("rwgemm variant %d: rc %d\n", var, rc); continue; }
         CK(hipDeviceSynchronize());
-        CK(hipMemcpy((var == 1 ? y1 : var == 2 ? y2 : y3).data(), Y[0], y1.size() * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy((var == 1 ? y1 : var == 2 ? y2 : var == 3 ? y3 : y4).data(), Y[0], y1.size() * 2, hipMemcpyDeviceToHost));
         float us = timeit([&](int i) { pa.A = A[i % NSET]; ea.Y = Y[i % NSET]; launch_rwgemm_k512(g, pa, ea, 0, 256, var); });
         printf("rwgemm_k512 variant %d %-28s: %8.2f us  %.3f PFLOP/s  %.2f TB/s of its own bytes\n", var, epi ? "(bias + statistics)" : "(plain)", us, flop / us / 1e9,
                ((double)M * K * 2 + (double)M * N * 2) / us / 1e6);
@@ -154,6 +154,13 @@ int main(int argc, char** argv) {
           maxd3 = fmax(maxd3, fabs((double)fa - fb));
         }
         printf("  variant 3 (64 columns per wave) vs variant 2: %zu of %zu output elements differ, max abs diff %.4g\n", bad3, y1.size(), maxd3);
+        size_t bad4 = 0; double maxd4 = 0;
+        for (size_t i = 0; i < y1.size(); ++i) {
+          bad4 += y4[i] != y2[i];
+          uint32_t a = (uint32_t)y4[i] << 16, b = (uint32_t)y2[i] << 16; float fa, fb; memcpy(&fa, &a, 4); memcpy(&fb, &b, 4);
+          maxd4 = fmax(maxd4, fabs((double)fa - fb));
+        }
+        printf("  variant 4 (two 256-thread workgroups per CU, 128-column tiles) vs variant 2: %zu of %zu output elements differ, max abs diff %.4g\n", bad4, y1.size(), maxd4);
       }
     }
   }
