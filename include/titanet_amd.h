@@ -271,7 +271,9 @@ int tn_profile_read(tn_plan* p, double* total_ms, int64_t* launches);
 /* Copies a named internal tensor of the last forward as float32 in the REFERENCE layout.
  * what: "logits" [B][n_classes]; "embeddings_raw" [B][emb]; "pooled" [B][2*enc_out];
  *       "block_out:<i>" [B][hidden][T]; "prolog_out" [B][hidden][T]; "epilog_out" [B][enc_out][T];
- *       "se_gate:<i>" [B][hidden].  dst: device float buffer of the right size. */
+ *       "se_gate:<i>" [B][hidden]; after tn_backward also "d_energies" and "d_epilog_bn" [B][enc_out][T] (the attention
+ *       energies' gradient / the gradient wrt the epilog BatchNorm output: element-wise comparisons of pooling paths).
+ *       dst: device float buffer of the right size. */
 int tn_debug_fetch(tn_plan* p, const char* what, float* dst, int64_t dst_floats, void* stream);
 const char* tn_version(void);
 
