@@ -62,6 +62,13 @@ __device__ __forceinline__ void pg_dma16_buf(unsigned voff, pg_i32x4_t srd, unsi
                : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_addr) : "memory");
 }
 
+// the same with the non-temporal policy (tuning switch RW_POL bit 0 of rwgemm_k512_v2)
+__device__ __forceinline__ void pg_dma16_buf_nt(unsigned voff, pg_i32x4_t srd, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_addr) : "memory");
+}
+
 // what an absent bias / column scale reads in the deep-ring variants (N <= 3072; one copy per translation unit)
 static __device__ const float pg_const_zeros[3072] = {};
 // ... and what absent row exponents read: E8M0 127 = scale 1 in every byte
@@ -569,6 +576,9 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_kernel(GemmShape g, PGemmN
 // Past its last tile a workgroup keeps requesting out-of-range rows (descriptor bounds check: zeros, no memory traffic): every
 // wait has the same count and no branch splits the stream.
 // ==========================================================================================
+#ifndef RW_POL
+#define RW_POL 0      // tuning only: 1 = nt on rwgemm_k512_v2's LDS-DMA loads, 2 = nt on its output stores
+#endif
 #ifndef RW_DBG
 #define RW_DBG 0      // tuning only: 1 = rwgemm_k512_v2 runs 2 of its 32 k-steps (the stream without the arithmetic), 2 = no output stores
 #endif
@@ -623,7 +633,8 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_v2_kernel(GemmShape g, PGe
     for (int q = 0; q < 4; ++q) {
       const int row = wave + 8 * q;
       const unsigned voff = (unsigned)(r0 + row) * (unsigned)(pa.lda * 2) + (unsigned)lane * 16u;
-      pg_dma16_buf(voff, srdA, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + row * RW2_PITCH)));
+      if (RW_POL & 1) pg_dma16_buf_nt(voff, srdA, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + row * RW2_PITCH)));
+      else pg_dma16_buf(voff, srdA, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage * STAGE_B + row * RW2_PITCH)));
     }
   };
   // output pieces of this lane: (row orow + 16 q, 16-byte piece opc of the wave's 64-byte row segment)
@@ -706,7 +717,8 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_v2_kernel(GemmShape g, PGe
       const unsigned voff = ((unsigned)gr * (unsigned)ea.ldy + (unsigned)(col0 + wave * 32 + opc * 8)) * 2u;
       // (s_nop: an inline-asm store gets no hazard slots from hipcc before a write of its data registers — found in the v3
       //  kernel below, where the next row's ds_read landed in them; here the two rows happen to get distinct registers)
-      if (!(RW_DBG & 2)) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(u), "v"(voff), "s"(srdY) : "memory");
+      if (RW_POL & 2) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen nt\n\ts_nop 1" ::"v"(u), "v"(voff), "s"(srdY) : "memory");
+      else if (!(RW_DBG & 2)) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(u), "v"(voff), "s"(srdY) : "memory");
       else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(u), "v"(0x7ffffff0u), "s"(srdY) : "memory");
       if (EPI && ea.stats && gr < g.M) {
         const uint32_t uw[4] = {u[0], u[1], u[2], u[3]};
