@@ -1499,7 +1499,7 @@ __global__ __launch_bounds__(V2_NT, (R == 32 ? 4 : 2)) void dgrad_v2_kernel(Dgra
       {
         dg_u32x4_t zs;
         zs[0] = f2bf_pk(z[0], z[1]); zs[1] = f2bf_pk(z[2], z[3]); zs[2] = f2bf_pk(z[4], z[5]); zs[3] = f2bf_pk(z[6], z[7]);
-        __builtin_amdgcn_raw_buffer_store_b128(zs, srdS, ((out0 + r) * V2_C + c0) * (int)sizeof(bf16_t), 0, 0);      // (rows >= M: out of range)
+        __builtin_amdgcn_raw_buffer_store_b128(zs, srdS, ((out0 + r) * V2_C + c0) * (int)sizeof(bf16_t), 0, (TN_NT_WGRAD_OPERANDS & 16) ? 2 : 0);      // (rows >= M: out of range)
       }
       store8(Pt + r * V2_AP + c0, z);
     }
@@ -1662,6 +1662,12 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
     const bool ok = gr >= 0 && gr < a.M;
     const size_t o = (size_t)gr * V2_C + c0;
     pz[q] = ok ? *reinterpret_cast<const uint4*>(a.dZ + o) : make_uint4(0, 0, 0, 0);
+    if (TN_NT_WGRAD_OPERANDS & 4) {
+      // (the raw output Y is read here for the LAST time in the step: streamed past the Infinity Cache)
+      typedef __attribute__((ext_vector_type(4))) unsigned int v6_u4;
+      const v6_u4 t = ok ? __builtin_nontemporal_load(reinterpret_cast<const v6_u4*>(a.Y + o)) : v6_u4{0u, 0u, 0u, 0u};
+      py[q] = make_uint4(t[0], t[1], t[2], t[3]);
+    } else
     py[q] = ok ? *reinterpret_cast<const uint4*>(a.Y + o) : make_uint4(0, 0, 0, 0);
     px[q] = ok ? *reinterpret_cast<const uint4*>(a.X + o) : make_uint4(0, 0, 0, 0);
   };
@@ -1736,7 +1742,14 @@ __global__ __launch_bounds__(V2_NT, 2) void dgrad_dw_v6_kernel(DgradDwArgs a) {
         }
       }
       store8(Pt + r * V2_AP + c0, z);
-      if (a.dS_out && r >= 1 && r <= V6_OUT && gr >= 0 && gr < a.M) store8(a.dS_out + (size_t)gr * V2_C + c0, z);
+      if (a.dS_out && r >= 1 && r <= V6_OUT && gr >= 0 && gr < a.M) {
+        if (TN_NT_WGRAD_OPERANDS & 2) {
+          typedef __attribute__((ext_vector_type(4))) unsigned int v6_s4;
+          v6_s4 w4;
+          w4[0] = f2bf_pk(z[0], z[1]); w4[1] = f2bf_pk(z[2], z[3]); w4[2] = f2bf_pk(z[4], z[5]); w4[3] = f2bf_pk(z[6], z[7]);
+          __builtin_nontemporal_store(w4, reinterpret_cast<v6_s4*>(a.dS_out + (size_t)gr * V2_C + c0));
+        } else store8(a.dS_out + (size_t)gr * V2_C + c0, z);
+      }
       *reinterpret_cast<uint4*>(Xb + r * V2_C + c0) = px[q];
       if (tile + (int)gridDim.x < a.ntiles) prefetch_q(tile + gridDim.x, q);
     }

@@ -26,6 +26,18 @@
 #define V2_NT 512
 #define WG2_RK 32
 #define WG2_PITCH 288      // 576-byte rows: the 4 rows of a transpose read land on distinct banks
+#ifndef TN_NT_WGRAD_OPERANDS
+// Infinity-Cache management by store policy (round 6).  The 256 MB memory-side cache holds about six hidden-width tensors of the
+// benched batch, and the kernels of a mega block mostly read what the previous launch wrote.  Tensors that are written now and
+// read only much later are stored NON-TEMPORAL so that they do not push the next kernels' operands out:
+//   bit 0 (1)  the kept depthwise outputs Q of sub_fwd_v5 (read by the weight-gradient launch at the end of backward)
+//   bit 1 (2)  the stored dS of dgrad_dw_v6 (same reader)
+//   bit 3 (8)  the skip conv's output S of sub_fwd_v4 (read four launches and ~240 MB of writes later by the combine)
+//   bit 4 (16) the stored dS of the skip conv's layer in dgrad_v2
+//   bit 2 (4)  [off] non-temporal LOADS of Y in dgrad_dw_v6 (its last use): measured +0.03 ms
+// Same-box round-robin of the step (profiles/r06_ab_nt_stores.txt): 8.344 ms with 0, 8.180 with 11, 8.142 with 27 (-2.4 %).
+#define TN_NT_WGRAD_OPERANDS 27
+#endif
 #ifndef V5_MD
 #define V5_MD 0      // tuning only: fragment reads in flight of a hand-scheduled MFMA phase in sub_fwd_v5's consumers (0: hipcc's schedule)
 #endif
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v4_kernel(SubFwdV2Args a) {
       const int o = rq + 16 * q, gr = out0 + o;
       const bool keep = o < OUTR && gr < a.M;
       const uint4 raw = *reinterpret_cast<const uint4*>(Cs + (keep ? o : 0) * V2_AP + c0);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4_u32x4_t, raw), srdY, keep ? (gr * V2_C + c0) * (int)sizeof(bf16_t) : 0x7ffffff0, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4_u32x4_t, raw), srdY, keep ? (gr * V2_C + c0) * (int)sizeof(bf16_t) : 0x7ffffff0, 0, (!DW && (TN_NT_WGRAD_OPERANDS & 8)) ? 2 : 0);
       if (keep) {
         float y[8];
         unpack8(raw, y);
@@ -854,7 +866,7 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
     auto store_q = [&](int row, bool keep, const float (&v)[8]) {
       v5_u32x4_t w;
       w[0] = f2bf_pk(v[0], v[1]); w[1] = f2bf_pk(v[2], v[3]); w[2] = f2bf_pk(v[4], v[5]); w[3] = f2bf_pk(v[6], v[7]);
-      __builtin_amdgcn_raw_buffer_store_b128(w, srdQ, keep ? (row * V2_C + c0) * (int)sizeof(bf16_t) : V5_OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(w, srdQ, keep ? (row * V2_C + c0) * (int)sizeof(bf16_t) : V5_OOB, 0, (TN_NT_WGRAD_OPERANDS & 1) ? 2 : 0);
     };
     uint4 pf[R / 8];
     auto prefetch_q = [&](int tile, int q) {
