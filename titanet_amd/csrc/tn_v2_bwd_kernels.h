@@ -1536,7 +1536,7 @@ __global__ __launch_bounds__(V2_NT, (R == 32 ? 4 : 2)) void dgrad_v2_kernel(Dgra
     for (int q = 0; q < NQ; ++q) {
       const int o = rq + 16 * q, gr = out0 + o;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dg_u32x4_t, *reinterpret_cast<const uint4*>(Dt + o * V2_AP + c0)), srdO,
-                                             (gr * V2_C + c0) * (int)sizeof(bf16_t), 0, 0);      // (rows >= M: out of range)
+                                             (gr * V2_C + c0) * (int)sizeof(bf16_t), 0, (TN_NT_WGRAD_OPERANDS & 32) ? 2 : 0);      // (rows >= M: out of range)
     }
   }
 }

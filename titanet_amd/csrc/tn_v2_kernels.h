@@ -34,9 +34,11 @@
 //   bit 1 (2)  the stored dS of dgrad_dw_v6 (same reader)
 //   bit 3 (8)  the skip conv's output S of sub_fwd_v4 (read four launches and ~240 MB of writes later by the combine)
 //   bit 4 (16) the stored dS of the skip conv's layer in dgrad_v2
+//   bit 5 (32) the skip data gradient dgrad_v2 writes (added three launches and ~400 MB later by the first sub-block's pass)
 //   bit 2 (4)  [off] non-temporal LOADS of Y in dgrad_dw_v6 (its last use): measured +0.03 ms
-// Same-box round-robin of the step (profiles/r06_ab_nt_stores.txt): 8.344 ms with 0, 8.180 with 11, 8.142 with 27 (-2.4 %).
-#define TN_NT_WGRAD_OPERANDS 27
+// Same-box round-robin of the step (profiles/r06_ab_nt_stores.txt): 8.344 ms with 0, 8.180 with 11, 8.142 with 27; 8.401 / 8.187 /
+// 8.143 with 0 / 27 / 59 (-3.1 %).
+#define TN_NT_WGRAD_OPERANDS 59
 #endif
 #ifndef V5_MD
 #define V5_MD 0      // tuning only: fragment reads in flight of a hand-scheduled MFMA phase in sub_fwd_v5's consumers (0: hipcc's schedule)
