@@ -408,6 +408,16 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     }
     const char* eo = getenv("TN_OVERLAP");
     p->overlap = p->use_v2 && c.n_mega_blocks > 0 && eo && atoi(eo) != 0;
+    {
+      // (the late launch wants S stored with the default policy: it follows the compile-time store policy unless TN_SKIP_LATE says otherwise)
+      const char* el = getenv("TN_SKIP_LATE");
+      p->skip_late = el ? atoi(el) != 0 : (p->use_v2 && !(TN_NT_WGRAD_OPERANDS & 8));
+    }
+    {
+      // wide models: the skip conv's output and the skip data gradient (pipelined GEMMs) stored non-temporal; TN_NT_SKIP=0 turns it off
+      const char* en = getenv("TN_NT_SKIP");
+      p->nt_skip = !(en && atoi(en) == 0);
+    }
     if (p->overlap) {
       if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) { p->side = nullptr; p->overlap = false; }
       for (int i = 0; p->overlap && i < 4 * c.n_mega_blocks; ++i) {
@@ -730,7 +740,7 @@ int gemm_store(const GemmShape& g, const typename Prod::Args& pa, const EpiStore
 // plain stored bf16 operand, big problem: the pipelined LDS-DMA GEMM (tn_pgemm.h); -1000 = not applicable
 template <typename AT>
 int gemm_plain_pipe(const tn_plan* p, const GemmShape& g, const void* X, int ldx, const BnAct& act, const EpiStoreArgs& ea, hipStream_t st,
-                    bool zero_pad = true) {
+                    bool zero_pad = true, bool nt_out = false) {
   // variable-length batches: every plain operand of this path is STORED with zero padding rows (dw_fwd_slab, combine_fwd),
   // so the masks of the activation / epilogue have nothing left to do except for the statistics: y == bias on those rows
   if (sizeof(AT) != 2 || p->generic || (p->masked && (g.M != p->M || !zero_pad))) return -1000;
@@ -740,7 +750,7 @@ int gemm_plain_pipe(const tn_plan* p, const GemmShape& g, const void* X, int ldx
   const bool listed = p->masked && p->n_rowtiles > 0;
   PGemmNtArgs pa{(const bf16_t*)X, ldx, listed ? (const int*)(p->ws + p->rowtiles) : nullptr, listed ? p->n_rowtiles : 0};
   // (statistics: the padding rows INSIDE the computed tiles give y == bias; the skipped tiles add nothing)
-  PGemmEpiArgs pe{(bf16_t*)ea.Y, ea.ldy, ea.bias, ea.stats, ea.colscale, p->masked ? (float)(p->active_rows - p->n_valid) : 0.f};
+  PGemmEpiArgs pe{(bf16_t*)ea.Y, ea.ldy, ea.bias, ea.stats, ea.colscale, p->masked ? (float)(p->active_rows - p->n_valid) : 0.f, nt_out ? 1 : 0};
   return launch_pgemm_nt(g, pa, pe, st);
 }
 
@@ -824,14 +834,20 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
   for (int i = 0; i < c.n_mega_blocks; ++i) {
     const MegaBlockRef& mb = m->blocks[i];
     BlockWs& bw = p->blk[i];
-    // skip connection: 1x1 conv (reference src/models.py:452-455)
+    // skip connection: 1x1 conv (reference src/models.py:452-455).  tn_plan::skip_late: launched BEHIND the sub-block chain, right in
+    // front of the combine that reads its output (the block input is still in the Infinity Cache then, and S is when the combine
+    // reads it); the side-stream overlap keeps the early launch
     bool skip_on_side = false;
-    {
+    const void* const blk_in = xin;
+    const BnAct blk_act = actx;
+    auto run_skip = [&]() -> int {
+      const void* xin = blk_in;
+      const BnAct actx = blk_act;
       int rc = -1000;
       if (keep_a0 && i == 0) {
         GemmShape g{M, H, H, wsel<AT>(p, mb.wskip, bw.wskip)};
         EpiStoreArgs ea{ws + bw.S, H, params + mb.bskip, statp(mb.bnskip), rm};
-        rc = gemm_plain_pipe<AT>(p, g, ws + p->a0, H, identity_rows(p), ea, st);
+        rc = gemm_plain_pipe<AT>(p, g, ws + p->a0, H, identity_rows(p), ea, st, true, p->nt_skip);
       }
       if (use_v2) {
         SubFwdV2Args va{(const bf16_t*)xin, actx, nullptr, nullptr, (const bf16_t*)(ws + bw.wskip.w), params + mb.bskip,
@@ -853,11 +869,13 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
         GemmShape g{M, H, H, wsel<AT>(p, mb.wskip, bw.wskip)};
         ProdPlain::Args pa{xin, H, actx};
         EpiStoreArgs ea{ws + bw.S, H, params + mb.bskip, statp(mb.bnskip), rm};
-        rc = (H >= 512) ? gemm_plain_pipe<AT>(p, g, xin, H, actx, ea, st) : -1000;
+        rc = (H >= 512) ? gemm_plain_pipe<AT>(p, g, xin, H, actx, ea, st, true, p->nt_skip) : -1000;
         if (rc == -1000) rc = gemm_store<AT, ProdPlain>(g, pa, ea, 0, st);
       }
-      if (rc) return rc;
-    }
+      return rc;
+    };
+    const bool skip_late = p->skip_late && !ov;
+    if (!skip_late) { const int rcs = run_skip(); if (rcs) return rcs; }
     const void* cur = xin;
     BnAct acur = actx;
     for (int j = 0; j < c.n_sub_blocks; ++j) {
@@ -927,6 +945,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
       cur = ws + bw.Y[j];
       acur = make_act(p, sb.bn, M, training, 1, pd, seed, i * (c.n_sub_blocks + 1) + j);
     }
+    if (skip_late) { const int rcs = run_skip(); if (rcs) return rcs; }
     // SE gate + residual combine (reference src/modules.py:173-189, src/models.py:467-472)
     {
       const int CV = H / 8, TG = 512 / CV;

@@ -109,7 +109,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   auto pipe_layer = [&](size_t dz, size_t y, const BnRef& bn, int Cout, const WcRef& wc, int Cin, size_t dx_out, const void* q, bool q_plain,
                         const BnAct& qact, int64_t wgrad_off, bool ds_ready = false, bool defer_tn = false,
                         Fp8Rows f8rows = Fp8Rows{nullptr, nullptr}, size_t w8t = 0, size_t w8ts = 0,
-                        Fp8Cols fcols = Fp8Cols{nullptr, nullptr, nullptr, nullptr, 0}) -> int {
+                        Fp8Cols fcols = Fp8Cols{nullptr, nullptr, nullptr, nullptr, 0}, bool nt_out = false) -> int {
     DBG("pipe dZ in", dz, (size_t)M * Cout); DBG("pipe Y", y, (size_t)M * Cout);
     DBGF("pipe bsums", ws + p->bsums[bn.id], TN_NREP * 2 * Cout); DBGF("pipe fstats", ws + p->stats[bn.id], TN_NREP * 2 * Cout);
     int rc = 0;
@@ -127,12 +127,12 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       // the weight scales in the epilogue
       GemmShape g8{M, Cin, Cout, ws + w8t};
       PGemmNtArgs pa8{(const bf16_t*)f8rows.q, Cout, rowtiles, listed ? p->n_rowtiles : 0, f8rows.rowexp};
-      PGemmEpiArgs pe8{(bf16_t*)(ws + dx_out), Cin, nullptr, nullptr, (const float*)(ws + w8ts)};
+      PGemmEpiArgs pe8{(bf16_t*)(ws + dx_out), Cin, nullptr, nullptr, (const float*)(ws + w8ts), 0.f, nt_out ? 1 : 0};
       rc = launch_pgemm_nt_f8(g8, pa8, pe8, st);
     } else {
       GemmShape g{M, Cin, Cout, ws + wc.wt};
       PGemmNtArgs pa{(const bf16_t*)(ws + dz), Cout, rowtiles, listed ? p->n_rowtiles : 0};
-      PGemmEpiArgs pe{(bf16_t*)(ws + dx_out), Cin, nullptr, nullptr, nullptr};
+      PGemmEpiArgs pe{(bf16_t*)(ws + dx_out), Cin, nullptr, nullptr, nullptr, 0.f, nt_out ? 1 : 0};
       rc = launch_pgemm_nt(g, pa, pe, st);
     }
     if (rc) return rc;
@@ -581,7 +581,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       const BnAct axs = a0 ? identity_rows() : actx;
       int rc = pipe_layer(bw.dZk, bw.S, mb.bnskip, H, bw.wskip, H, p->dXs, xs, is_plain(axs), axs, mb.wskip, false, tn_batched && (i > 0 || a0),
                           f8s ? Fp8Rows{(uint8_t*)(ws + p->ds8s), (uint8_t*)(ws + p->dsexps)} : Fp8Rows{nullptr, nullptr},
-                          f8s ? bw.w8t_skip : 0, f8s ? bw.w8ts_skip : 0);
+                          f8s ? bw.w8t_skip : 0, f8s ? bw.w8ts_skip : 0, Fp8Cols{nullptr, nullptr, nullptr, nullptr, 0}, p->nt_skip);
       if (rc) return rc;
     } else
     {

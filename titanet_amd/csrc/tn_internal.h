@@ -181,6 +181,8 @@ struct tn_plan {
   // skip data gradient beside the last two sub-blocks' fused data-gradient launches (backward) — one kernel's ramp-up fills
   // the other's drain.  Fork / join with plan-owned events; works under stream capture (the side stream joins the capture).
   bool overlap = false;
+  bool nt_skip = false;             // wide models: non-temporal stores for the skip conv's output and the skip data gradient
+  bool skip_late = false;           // forward: the skip conv of a mega block is launched behind its sub-blocks (tn_api.hip)
   // attentive pooling without a stored energy tensor (asp_v2_kernel, tn_v2_wide_kernels.h): forward and backward recompute
   // the K = 128 product.  Decided at plan creation (TN_ASP_FUSED=0 keeps the stored-energies kernels; shapes outside the
   // kernel — frames > 320, several workgroups per utterance — always do): forward and backward must agree.

@@ -44,6 +44,9 @@ __device__ __forceinline__ void pg_barrier() {
 __device__ __forceinline__ void pg_store_dword(uint32_t v, unsigned voff, pg_i32x4_t srd, unsigned soff) {
   asm volatile("buffer_store_dword %0, %1, %2, %3 offen" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
+__device__ __forceinline__ void pg_store_dword_nt(uint32_t v, unsigned voff, pg_i32x4_t srd, unsigned soff) {
+  asm volatile("buffer_store_dword %0, %1, %2, %3 offen nt" ::"v"(v), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
 __device__ __forceinline__ void pg_atomic_add(float* p, float v) { asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ pg_i32x4_t pg_make_srd(const void* base, unsigned bytes) {
   const uint64_t b = (uint64_t)base;
@@ -98,6 +101,8 @@ struct PGemmEpiArgs {
   const float* colscale;   // [N] or null: y = acc * colscale[n] + bias[n]
   float pad_rows;          // variable-length batches: that many rows < M of A are all-zero padding (y == bias there, exactly):
                            // their contribution is taken out of `stats` again (sums over the valid rows only)
+  int nt_out;              // the output is stored non-temporal: nobody reads it within the next few launches (the skip conv's
+                           // output, the skip data gradient: round 6, Infinity-Cache management by store policy)
 };
 
 // DBG (tuning only): 1 no MFMA, 2 no DMA after the prologue, 4 linear DMA source (wrong results), 8 no output stores
@@ -360,7 +365,10 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(GemmShape g, PGemmNtAr
             for (int r = 0; r < 16; ++r) {
               const int rr = (r & 3) + 8 * (r >> 2);
               float y0 = fmaf(acc[h][mt][0][r], cv[0], bv[0]), y1 = fmaf(acc[h][mt][1][r], cv[1], bv[1]);
-              if (!(DBG & 8)) pg_store_dword(f2bf_pk(y0, y1), yvoff + (sbase + (unsigned)rr * row_b), ysrd, 0u);   // (the bounds check covers the VGPR offset only)
+              if (!(DBG & 8)) {
+                if (ea.nt_out) pg_store_dword_nt(f2bf_pk(y0, y1), yvoff + (sbase + (unsigned)rr * row_b), ysrd, 0u);
+                else pg_store_dword(f2bf_pk(y0, y1), yvoff + (sbase + (unsigned)rr * row_b), ysrd, 0u);   // (the bounds check covers the VGPR offset only)
+              }
               if (!full_rows) {
                 const bool ok = rblk + rr + 4 * fh < g.M;
                 y0 = ok ? y0 : 0.f; y1 = ok ? y1 : 0.f;
@@ -717,7 +725,7 @@ __global__ __launch_bounds__(512, 2) void rwgemm_k512_v2_kernel(GemmShape g, PGe
       const unsigned voff = ((unsigned)gr * (unsigned)ea.ldy + (unsigned)(col0 + wave * 32 + opc * 8)) * 2u;
       // (s_nop: an inline-asm store gets no hazard slots from hipcc before a write of its data registers — found in the v3
       //  kernel below, where the next row's ds_read landed in them; here the two rows happen to get distinct registers)
-      if (RW_POL & 2) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen nt\n\ts_nop 1" ::"v"(u), "v"(voff), "s"(srdY) : "memory");
+      if ((RW_POL & 2) || ea.nt_out) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen nt\n\ts_nop 1" ::"v"(u), "v"(voff), "s"(srdY) : "memory");
       else if (!(RW_DBG & 2)) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(u), "v"(voff), "s"(srdY) : "memory");
       else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(u), "v"(0x7ffffff0u), "s"(srdY) : "memory");
       if (EPI && ea.stats && gr < g.M) {

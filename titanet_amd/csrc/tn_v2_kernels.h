@@ -638,12 +638,12 @@ __global__ __launch_bounds__(512) void se_combine_fwd_v3_kernel(SeCombineV3Args 
   auto row_off = [&](int u) -> int { return (min(tg + 16 * u, lastrow) * V2_C + c0) * (int)sizeof(bf16_t); };
   uint4 ry[SC3_MAXU];
 #pragma unroll
-  for (int u = 0; u < SC3_MAXU; ++u) ry[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srdY, row_off(u), 0, 0));
+  for (int u = 0; u < SC3_MAXU; ++u) ry[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srdY, row_off(u), 0, (TN_NT_WGRAD_OPERANDS & 64) ? 2 : 0));
   // skip rows: three groups of 4 rows in flight (the first behind the utterance's rows, the second before the mat-vec tail)
   uint4 rs[3][G];
   auto load_s = [&](int g, uint4 (&dst)[G]) {
 #pragma unroll
-    for (int q = 0; q < G; ++q) dst[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srdS, row_off(g * G + q), 0, 0));
+    for (int q = 0; q < G; ++q) dst[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srdS, row_off(g * G + q), 0, (TN_NT_WGRAD_OPERANDS & 64) ? 2 : 0));
   };
   load_s(0, rs[0]);
   if (tid < V2_C) { cst[tid] = cs0; cst[V2_C + tid] = ch0; cst[2 * V2_C + tid] = cs1; cst[3 * V2_C + tid] = ch1; }
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(V2_NT, 2) void sub_fwd_v5_kernel(SubFwdV2Args a) {
     uint4 pf[R / 8];
     auto prefetch_q = [&](int tile, int q) {
       const int gr = tile * OUTR - PADR + rq + 8 * q;
-      pf[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srdX, (tile < a.ntiles) ? (gr * V2_C + c0) * (int)sizeof(bf16_t) : V5_OOB, 0, 0));
+      pf[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srdX, (tile < a.ntiles) ? (gr * V2_C + c0) * (int)sizeof(bf16_t) : V5_OOB, 0, (TN_NT_WGRAD_OPERANDS & 128) ? 2 : 0));
     };
     auto prefetch = [&](int tile) {
 #pragma unroll
