@@ -2,6 +2,9 @@
 // of src/models.py / src/modules.py / src/losses.py, reference src/learn.py:117); the formulas
 // below are the analytic gradients of those forward definitions.
 #pragma once
+#ifndef TN_NT_F8C
+#define TN_NT_F8C 0      // tuning only: fp8 plans store the per-column-scaled e4m3 copy of dS non-temporal (measured: no effect on L/5 fp8)
+#endif
 #include <algorithm>
 
 #include "../../include/titanet_amd.h"
@@ -1416,7 +1419,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(bf16_t* __restrict__ 
             *reinterpret_cast<float4*>(cs8 + 4) = *reinterpret_cast<const float4*>(csc_l + c0 + 4);
 #pragma unroll
             for (int u = 0; u < 8; ++u) cmx[v][u] = fmaxf(cmx[v][u], fabsf(z[v][u]));
-            *reinterpret_cast<uint2*>(fc.q + (size_t)row * C + c0) = tn_e4m3_pack8_cols(z[v], cs8);
+            {
+              // (the column-scaled copy is read by the weight-gradient launch at the end of backward only: non-temporal, TN_NT_F8C)
+              typedef __attribute__((ext_vector_type(2))) unsigned int f8c_u2;
+              const uint2 pk = tn_e4m3_pack8_cols(z[v], cs8);
+              if (TN_NT_F8C) __builtin_nontemporal_store(f8c_u2{pk.x, pk.y}, reinterpret_cast<f8c_u2*>(fc.q + (size_t)row * C + c0));
+              else *reinterpret_cast<uint2*>(fc.q + (size_t)row * C + c0) = pk;
+            }
           }
         }
       }
