@@ -105,3 +105,41 @@ def test_mel_feeds_the_network():
         e = m(x)
     assert e.shape == (4, 192) and torch.isfinite(e).all()
     assert torch.allclose(e.norm(dim=1), torch.ones(4, device=e.device), atol=1e-4)
+
+
+def test_wave_per_frame_kernel_equals_the_generic_kernel(monkeypatch):
+    """n_fft = 512 runs mel512_batch_kernel (one wave per frame, radix-8 passes); TN_MEL_GENERIC=1 at tn_mel_create keeps the
+    generic radix-2 workgroup-per-frame kernel, which every other n_fft uses: same spectrograms on a ragged, time-stretched,
+    masked batch (float32 rounding of two FFT factorizations apart), and the generic kernel still meets the oracle."""
+    from titanet_amd.transforms import MelSpectrogram
+    rng = np.random.default_rng(5)
+    lens = [40000, 16000 + 77, 52000, 700, 31999]
+    rates = [0.95, 1.0, 1.05, 1.0, 1.3]
+    A = max(lens)
+    waves = np.zeros((len(lens), A), dtype=np.float32)
+    for b, n in enumerate(lens):
+        waves[b, :n] = rng.normal(0, 0.05, n)
+    fast = MelSpectrogram(16000, n_fft=512, win_length=400, hop_length=160, n_mels=80, specaugment_probability=0.0)
+    fast._mel()
+    monkeypatch.setenv("TN_MEL_GENERIC", "1")
+    slow = MelSpectrogram(16000, n_fft=512, win_length=400, hop_length=160, n_mels=80, specaugment_probability=0.0)
+    slow._mel()
+    monkeypatch.delenv("TN_MEL_GENERIC")
+    T = max(fast.n_frames(n, r) for n, r in zip(lens, rates))
+    fm = torch.zeros(len(lens), 80, dtype=torch.bool); fm[1, 10:31] = True; fm[4, 70:] = True
+    tm = torch.zeros(len(lens), T, dtype=torch.bool); tm[0, 5:40] = True; tm[2, 100:101] = True
+    w = torch.from_numpy(waves)
+    a = fast.batch(w, lengths=lens, rates=rates, freq_masks=fm, time_masks=tm).cpu().numpy()
+    b = slow.batch(w, lengths=lens, rates=rates, freq_masks=fm, time_masks=tm).cpu().numpy()
+    assert a.shape == b.shape == (len(lens), 80, T)
+    assert np.abs(a - b).max() < 2e-4, np.abs(a - b).max()
+    assert ((a == 0) == (b == 0)).all()
+    # equal lengths, interval masks (tn_mel_forward)
+    mk = torch.tensor([[3, 9, 10, 30]] * 2, dtype=torch.int32)
+    a2 = fast.batch(w[:2, :32000], masks=mk).cpu().numpy()
+    b2 = slow.batch(w[:2, :32000], masks=mk).cpu().numpy()
+    assert np.abs(a2 - b2).max() < 2e-4 and ((a2 == 0) == (b2 == 0)).all()
+    assert (a2[:, 3:9] == 0).all() and (a2[:, :, 10:30] == 0).all()
+    want = MO.mel_spectrogram(waves[0, :lens[0]].astype(np.float64), rate=rates[0])
+    got = slow.batch(w[:1, :lens[0]], rates=[rates[0]]).cpu().numpy()[0]
+    assert rel_err(got, want) < 1e-3
