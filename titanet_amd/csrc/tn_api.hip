@@ -215,6 +215,17 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   // (utterances of >= 512 frames only: the summation tree of the SE mean changes with the number of parts, and the short
   //  fixed-length batches keep embeddings that do not depend on the batch they are computed in, bit for bit)
   if (batch * 2 <= 256 && frames >= 512) p->tail_parts = std::max(1, std::min(std::min(256 / batch, 16), frames / 128));
+  p->se_parts = p->tail_parts;
+  if (p->tail_parts > 1) {
+    // TN_SE_ONE_LAUNCH=1: partial sums and the two mat-vecs in ONE launch (se_squeeze_fc_kernel mode 3) instead of two.
+    // Measured on configs[3] (32 x <= 1969 frames, hidden 512): 10.37 ms either way — the last arrival's mat-vecs are the
+    // same latency chain the second launch was, only the ~2 us launch gap goes away.  Off: the two-launch form is the tested default.
+    const char* e1 = getenv("TN_SE_ONE_LAUNCH");
+    if (e1 && atoi(e1) == 1) {
+      p->se_parts = std::max(p->tail_parts, std::min(std::min(16, 512 / batch), frames / 128));
+      p->se_cnt = b.take(sizeof(int) * (size_t)batch);
+    }
+  }
   p->zero_bytes = ((b.off + 255) & ~(size_t)255) - p->zero_begin;
   b.off = p->zero_begin + p->zero_bytes;
   // ---- region cleared at the start of every backward (so a backward can be repeated from one forward,
@@ -244,7 +255,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
   p->step_state = b.take(64);
   p->lens = b.take(sizeof(int) * (size_t)batch);
   p->rowtiles = b.take(sizeof(int) * ((size_t)(M + 255) / 256 + 1));
-  if (p->tail_parts > 1) p->se_acc = b.take((size_t)batch * p->tail_parts * H * sizeof(float));      // one block at a time
+  if (p->tail_parts > 1) p->se_acc = b.take((size_t)batch * p->se_parts * H * sizeof(float));      // one block at a time
   // ---- compute-precision weights
   auto wc = [&](size_t n, size_t k) {
     WcRef r; r.w = b.take(n * k * e); r.wt = b.take(n * k * e);
@@ -989,11 +1000,17 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
         // activation flags of the last sub-block's output as a template parameter where they are the usual ones
         const int flse = (acur.mode != 0 ? 1 : 0) | (acur.relu ? 2 : 0) | (acur.drop_thr ? 4 : 0);
         auto kse = flse == 7 ? se_squeeze_fc_kernel<AT, 7> : flse == 3 ? se_squeeze_fc_kernel<AT, 3> : se_squeeze_fc_kernel<AT, -1>;
+        if (acc && p->se_cnt)     // partial column sums from se_parts workgroups per utterance; the last one to arrive finishes
+          hipLaunchKernelGGL(kse, dim3(B, p->se_parts), dim3(512), smem, st, (const AT*)cur, acur, T, H, Hr,
+                             params + mb.se_w1, params + mb.se_w2, (float*)(ws + bw.m), (float*)(ws + bw.h), (float*)(ws + bw.g), acc, 3, p->se_parts,
+                             (int*)(ws + p->se_cnt));
+        else {
         if (acc)     // partial column sums from tail_parts workgroups per utterance, then the two mat-vecs per utterance
           hipLaunchKernelGGL(kse, dim3(B, p->tail_parts), dim3(512), smem, st, (const AT*)cur, acur, T, H, Hr,
-                             params + mb.se_w1, params + mb.se_w2, (float*)(ws + bw.m), (float*)(ws + bw.h), (float*)(ws + bw.g), acc, 1, p->tail_parts);
+                             params + mb.se_w1, params + mb.se_w2, (float*)(ws + bw.m), (float*)(ws + bw.h), (float*)(ws + bw.g), acc, 1, p->tail_parts, (int*)nullptr);
         hipLaunchKernelGGL(kse, dim3(B), dim3(512), smem, st, (const AT*)cur, acur, T, H, Hr,
-                           params + mb.se_w1, params + mb.se_w2, (float*)(ws + bw.m), (float*)(ws + bw.h), (float*)(ws + bw.g), acc, acc ? 2 : 0, p->tail_parts);
+                           params + mb.se_w1, params + mb.se_w2, (float*)(ws + bw.m), (float*)(ws + bw.h), (float*)(ws + bw.g), acc, acc ? 2 : 0, p->tail_parts, (int*)nullptr);
+        }
       }
       { int rcj = join_skip(); if (rcj) return rcj; }      // the combine reads S and the skip BatchNorm's statistics
       BnAct acts = make_act(p, mb.bnskip, M, training, 0, 0.f, seed, 0);

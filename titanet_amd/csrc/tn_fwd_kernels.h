@@ -456,7 +456,10 @@ inline int launch_dw_fwd(const AT* X, const BnAct& act, const float* wdw, const 
 // frames would occupy 32 of the 256 CUs), gridDim.y = P workgroups per utterance that store their partial column sums in
 // `acc` ([B][P][C], plain stores: the result does not depend on the order the workgroups run in); a second launch with
 // mode 2 (one workgroup per utterance) adds them in order and turns the sums into mean / h / g.
-//   mode 0: everything in one workgroup;  1: partial sums of frames [p T/P, (p+1) T/P) -> acc[b][p];  2: acc[b][0..parts) -> m, h, g
+//   mode 0: everything in one workgroup;  1: partial sums of frames [p L/P, (p+1) L/P) -> acc[b][p];  2: acc[b][0..parts) -> m, h, g
+//   mode 3 (round 6): 1 and 2 in ONE launch — the workgroup that arrives LAST at the utterance's counter (cnt[b], zero
+//   between launches: the last arrival clears it) adds the partial sums in order and makes m / h / g: the result does not
+//   depend on which workgroup that is.  The frames are split by the utterance's own length (L / P each), not T / P.
 // ------------------------------------------------------------------------------------------
 // FL >= 0: the activation flags as a compile-time constant (1 BatchNorm, 2 ReLU, 4 dropout) — the row loop of the generic form
 // (FL = -1: run-time flags, a padding test with an integer division per row) is VALU-bound at hidden 512 / 1024
@@ -464,8 +467,10 @@ template <typename AT, int FL = -1>
 __global__ __launch_bounds__(512) void se_squeeze_fc_kernel(const AT* __restrict__ Y, BnAct act, int T, int C, int Hr,
                                                             const float* __restrict__ W1, const float* __restrict__ W2,
                                                             float* __restrict__ m_out, float* __restrict__ h_out,
-                                                            float* __restrict__ g_out, float* __restrict__ acc, int mode, int parts) {
+                                                            float* __restrict__ g_out, float* __restrict__ acc, int mode, int parts,
+                                                            int* __restrict__ cnt = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_last;
   float* sc = reinterpret_cast<float*>(smem);
   float* sh = sc + C;
   float* mean = sh + C;
@@ -480,7 +485,7 @@ __global__ __launch_bounds__(512) void se_squeeze_fc_kernel(const AT* __restrict
   const int vc = tid % CV, tg = tid / CV;
   // frames of this workgroup; padding frames (>= len[b]) contribute nothing and are not read
   const int L = act.rm.len ? act.rm.len[b] : T;
-  const int per = (T + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int per = (L + (int)gridDim.y - 1) / (int)gridDim.y;
   const int t_lo = (int)blockIdx.y * per, t_hi = min(L, t_lo + per);
   if (tg < TG && mode != 2) {
     float s[8];
@@ -534,9 +539,30 @@ __global__ __launch_bounds__(512) void se_squeeze_fc_kernel(const AT* __restrict
     }
     return;
   }
+  if (mode == 3) {
+    // The partial sums cross workgroups INSIDE a launch (the XCDs' L2s are not coherent with each other): device-scope
+    // exchanges / loads, performed at the memory side, and a relaxed counter — a release / acquire pair at device scope is an
+    // L2 write-back + invalidate per workgroup (measured: + 90 us per launch behind a GEMM's dirty output lines).  The
+    // RETURNING exchange has been performed when its value is back, i.e. before the barrier that precedes the arrival.
+    for (int c = tid; c < C; c += NT) {
+      float s = 0.f;
+      for (int k = 0; k < TG; ++k) s += part[k * C + c];
+      const float old = __hip_atomic_exchange(acc + ((size_t)b * gridDim.y + blockIdx.y) * C + c, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" : : "v"(old));
+    }
+    __syncthreads();
+    if (tid == 0) {
+      s_last = __hip_atomic_fetch_add(cnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.y - 1;
+      if (s_last) __hip_atomic_store(cnt + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+  }
   for (int c = tid; c < C; c += NT) {
     float s = 0.f;
-    if (mode == 2)
+    if (mode == 3)
+      for (int k = 0; k < parts; ++k) s += __hip_atomic_load(acc + ((size_t)b * parts + k) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (mode == 2)
       for (int k = 0; k < parts; ++k) s += acc[((size_t)b * parts + k) * C + c];
     else
       for (int k = 0; k < TG; ++k) s += part[k * C + c];

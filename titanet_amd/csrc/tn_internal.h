@@ -205,6 +205,8 @@ struct tn_plan {
   // tail_parts workgroups per utterance; their partial sums meet in se_acc / dgate_acc ([block][B][hidden] floats, cleared
   // with the backward zero region; se_acc: [B][parts][hidden] partial sums, reused block after block)
   int tail_parts = 1;
+  int se_parts = 1;             // workgroups per utterance of the one-launch SE squeeze (se_squeeze_fc_kernel mode 3), counters in se_cnt
+  size_t se_cnt = 0;
   size_t se_acc = 0, dgate_acc = 0;
   // variable-length batches on the pipelined GEMMs: the 256-row tiles holding at least one valid frame (int32 list in the
   // workspace, rewritten with every set of lengths), their count and the rows they cover; skip_pad_tiles: the plan's kernels
