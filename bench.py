@@ -318,14 +318,19 @@ def other_configs(dev, only=None):
         y = torch.randint(0, n_classes, (B,), generator=g).to(dev)
         ln = torch.tensor(frames, dtype=torch.int64)
 
+        shape = {}
+
         def step():
-            # the front end writes the prolog conv's packed bf16 operand itself (no float32 [B, 80, T] tensor, no pack pass)
+            # the front end writes the prolog conv's packed bf16 operand itself (no float32 [B, 80, T] tensor, no pack pass); it
+            # pads the frame axis to a multiple of 256 (every utterance starts on a row-tile boundary, MelSpectrogram.batch)
             x = mel.batch(wav, lengths=nsamp, rates=rates, freq_masks=fm, time_masks=tm, into=m)
+            shape["T"] = x.shape[2]
             tr.step(x, y, lengths=ln)
         dt = _timed_steps(step, 6, 8)          # (6 warm-up steps: the front end allocates its 4 pinned staging slots on first use)
         valid = sum(frames)
         nbytes = ELEMS_PER_FRAME["m"] * valid * 10.0
         flops = FLOPS_PER_UTT["m"] * valid / 300.0
+        T = shape["T"]
         return {"workload": f"TitaNet-M/10, {B} waveforms of U(2,20) s -> GPU mel + SpecAugment -> padded [B,80,{T}] + lengths -> masked fwd+bwd+Adam, bf16",
                 "ms_per_step": round(dt * 1e3, 3), "utt_per_s": round(B / dt, 1), "audio_s_per_s": round(sum(nsamp) / sr / dt, 1),
                 "valid_frames": valid, "padded_frames": B * T, "bound": "hbm", "frac": round(nbytes / dt / 1e9 / HBM_PEAK_GBS, 4),

@@ -34,7 +34,7 @@ def ragged_waveforms(B, seed, lo=2.0, hi=20.0):
     return wav, nsamp, rnd
 
 
-def front_end(wav, nsamp, rnd, stretch=True, into=None):
+def front_end(wav, nsamp, rnd, stretch=True, into=None, align_frames=None):
     from titanet_amd.transforms import MelSpectrogram
     B = wav.shape[0]
     mel = MelSpectrogram(SR, n_fft=512, win_length=400, hop_length=HOP, n_mels=80)
@@ -49,7 +49,7 @@ def front_end(wav, nsamp, rnd, stretch=True, into=None):
         t0 = rnd.randrange(0, frames[b] - 4); t1 = min(frames[b], t0 + rnd.randrange(1, max(2, int(0.15 * frames[b]))))
         fm[b, f0:f1] = True; tm[b, t0:t1] = True
         fms.append((f0, f1)); tms.append((t0, t1))
-    x = mel.batch(wav.cuda(), lengths=nsamp, rates=rates, freq_masks=fm, time_masks=tm, into=into)
+    x = mel.batch(wav.cuda(), lengths=nsamp, rates=rates, freq_masks=fm, time_masks=tm, into=into, align_frames=align_frames)
     return x, frames, rates, fms, tms
 
 
@@ -131,7 +131,8 @@ def test_front_end_fused_into_the_prolog_operand():
     res = []
     for fused in (False, True):
         wav, nsamp, rnd = ragged_waveforms(B, seed=4, lo=2.0, hi=8.0)
-        x, frames, *_ = front_end(wav, nsamp, rnd, into=m if fused else None)
+        # (same frame axis on both paths: the dropout masks are a hash of the row index b * T + t)
+        x, frames, *_ = front_end(wav, nsamp, rnd, into=m if fused else None, align_frames=1)
         m._seed_base, m._step = 11, 0
         m.zero_grad()
         if fused:
@@ -147,8 +148,19 @@ def test_front_end_fused_into_the_prolog_operand():
     print(f"fused vs tensor path: emb {e:.2e}, loss {res[1][1]:.5f} / {res[0][1]:.5f}, gradient cosine {cos:.6f}")
     # identical bf16 operand bits; what differs is the summation order of the atomics-accumulated statistics
     assert e < 2e-2 and abs(res[1][1] - res[0][1]) < 2e-2 and cos > 0.995
-    # eval, equal lengths, the f32 twin of the packed operand
+    # by default the packed path pads the frame axis to a multiple of 256 (every utterance starts on a row-tile boundary):
+    # the padding is invisible behind the lengths mask (eval: no dropout hash of the row index)
     m.eval()
+    with torch.no_grad():
+        wav, nsamp, rnd = ragged_waveforms(B, seed=4, lo=2.0, hi=8.0)
+        xa, frames, *_ = front_end(wav, nsamp, rnd, into=m)
+        assert xa.shape == (B, 80, -(-max(frames) // 256) * 256) and xa.shape[2] > max(frames)
+        ea = m(xa).cpu().numpy()
+        wav, nsamp, rnd = ragged_waveforms(B, seed=4, lo=2.0, hi=8.0)
+        xb, *_ = front_end(wav, nsamp, rnd, into=m, align_frames=1)
+        eb = m(xb).cpu().numpy()
+    assert rel_err(ea, eb) < 2e-3, rel_err(ea, eb)
+    # eval, equal lengths, the f32 twin of the packed operand
     from titanet_amd.transforms import MelSpectrogram
     mel = MelSpectrogram(SR, n_fft=512, win_length=400, hop_length=HOP, n_mels=80)
     w = torch.randn(4, 32000, generator=torch.Generator().manual_seed(2)) * 0.05

@@ -428,6 +428,7 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
       // wide models: the skip conv's output and the skip data gradient (pipelined GEMMs) stored non-temporal; TN_NT_SKIP=0 turns it off
       const char* en = getenv("TN_NT_SKIP");
       p->nt_skip = !(en && atoi(en) == 0);
+      { const char* er = getenv("TN_RW_NT"); p->rw_nt = er ? atoi(er) : 0; }
     }
     if (p->overlap) {
       if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) { p->side = nullptr; p->overlap = false; }
@@ -945,7 +946,7 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
             if (rc == -1000) rc = launch_gemm_fp8<EpiStore>(g8, q8, e8, st);
           } else {
             ProdPlain::Args pq{ws + bw.Q[j], H, identity_act()};
-            rc = gemm_plain_pipe<AT>(p, g, ws + bw.Q[j], H, identity_act(), ea, st, q_clean);
+            rc = gemm_plain_pipe<AT>(p, g, ws + bw.Q[j], H, identity_act(), ea, st, q_clean, (p->rw_nt & 1) != 0);
             if (rc == -1000) rc = gemm_store<AT, ProdPlain>(g, pq, ea, 0, st);
           }
         } else {
@@ -1126,10 +1127,16 @@ int forward_impl(tn_plan* p, const float* spec, const int64_t* speakers, int tra
     }
     if (rc) return rc;
     if (pooled_done) {
-    } else if (p->tail_parts > 1)
-      hipLaunchKernelGGL((asp_pool_fwd_kernel<AT, 16, 16>), dim3(B, (D + 127) / 128), dim3(256), 0, st, (const AT*)(ws + p->E), acte,
+    } else if (p->tail_parts > 1) {
+      // the frames of an utterance over tail_parts workgroups, partial records in the (idle) weight-gradient slabs
+      const int P = p->slab_bytes >= (size_t)B * p->tail_parts * 4 * D * sizeof(float) ? p->tail_parts : 1;
+      hipLaunchKernelGGL((asp_pool_fwd_kernel<AT, 16, 16>), dim3(B, (D + 127) / 128, P), dim3(256), 0, st, (const AT*)(ws + p->E), acte,
                          (const AT*)(ws + p->EN), T, D, 1e-6f, (float*)(ws + p->pooled), (float*)(ws + p->smax),
-                         (float*)(ws + p->sinv), (float*)(ws + p->qv), statp(m->pool_bn));
+                         (float*)(ws + p->sinv), (float*)(ws + p->qv), statp(m->pool_bn), (float*)(ws + p->slabs));
+      if (P > 1)
+        hipLaunchKernelGGL(asp_pool_merge_kernel, dim3(B, (D + 255) / 256), dim3(256), 0, st, (const float*)(ws + p->slabs), P, D, 1e-6f,
+                           (float*)(ws + p->pooled), (float*)(ws + p->smax), (float*)(ws + p->sinv), (float*)(ws + p->qv), statp(m->pool_bn));
+    }
     else
       hipLaunchKernelGGL(asp_pool_fwd_kernel<AT>, dim3(B, (D + 511) / 512), dim3(256), 0, st, (const AT*)(ws + p->E), acte,
                          (const AT*)(ws + p->EN), T, D, 1e-6f, (float*)(ws + p->pooled), (float*)(ws + p->smax),

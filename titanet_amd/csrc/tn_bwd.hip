@@ -387,7 +387,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       if (rc) return rc;
     } else
     if (p->tail_parts > 1)
-      hipLaunchKernelGGL((asp_bwd_de_kernel<AT, 16, 16>), dim3(B, (D + 127) / 128), dim3(256), 0, st, (const AT*)(ws + p->E), acte,
+      hipLaunchKernelGGL((asp_bwd_de_kernel<AT, 16, 16>), dim3(B, (D + 127) / 128, p->tail_parts), dim3(256), 0, st, (const AT*)(ws + p->E), acte,
                          (const AT*)(ws + p->EN), T, D, 1e-6f, (const float*)(ws + p->pooled), (const float*)(ws + p->qv),
                          (const float*)(ws + p->smax), (const float*)(ws + p->sinv), (const float*)(ws + p->dpooled),
                          (AT*)(ws + p->dE), (AT*)(ws + p->dEbn), grads + m->asp_bout);
@@ -674,7 +674,7 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         const bool f8 = p->fp8_bwd && !bw.w8t.empty();
         int rc = pipe_layer(bw.dY[j], bw.Y[j], sb.bn, H, bw.wpw[j], H, p->dD, ws + bw.Q[j], true, identity_act(), sb.wpw,
                             z3, tn_batched, f8 ? Fp8Rows{(uint8_t*)(ws + p->ds8), (uint8_t*)(ws + p->dsexp)} : Fp8Rows{nullptr, nullptr},
-                            f8 ? bw.w8t[j] : 0, f8 ? bw.w8ts[j] : 0, f8 ? fcols_of(bw, j) : Fp8Cols{nullptr, nullptr, nullptr, nullptr, 0});
+                            f8 ? bw.w8t[j] : 0, f8 ? bw.w8ts[j] : 0, f8 ? fcols_of(bw, j) : Fp8Cols{nullptr, nullptr, nullptr, nullptr, 0}, (p->rw_nt & 2) != 0);
         if (rc) return rc;
       } else {
         GemmShape g{M, H, H, wt(bw.wpw[j])};

@@ -893,29 +893,44 @@ __global__ __launch_bounds__(256) void asp_bwd_de_kernel(const AT* __restrict__ 
       mx[i] = smax[o];
       iv[i] = sinv[o];
     }
-    const int L = actE.rm.len ? actE.rm.len[b] : T;     // softmax over the valid frames only
-    for (int t = L + tg; t < T; t += TG) {                 // padded frames: no gradient
+    // gridDim.z = P workgroups share the utterance's frames (small batches of long utterances): element-wise work, the column
+    // sums meet in the atomics below
+    const int Lb = actE.rm.len ? actE.rm.len[b] : T;     // softmax over the valid frames only
+    const int per = (Lb + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int t_lo = (int)blockIdx.z * per, L = min(Lb, t_lo + per);
+    for (int t = Lb + tg + (int)blockIdx.z * TG; t < T; t += TG * (int)gridDim.z) {                 // padded frames: no gradient
       const size_t o = ((size_t)b * T + t) * D + c0;
       float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       store8(dEN + o, z);
       store8(DXD + o, z);
     }
-    for (int t = tg; t < L; t += TG) {
-      const uint32_t row = (uint32_t)b * T + t;
-      const size_t o = (size_t)row * D + c0;
-      float x[8], e[8], de[8], dx[8];
-      load8(E + o, x);
-      load8(EN + o, e);
-      act8(x, scs + vc * 8, shs + vc * 8, actE, row, D, c0);
+    constexpr int U = 4;       // rows in flight per thread (asp_pool_fwd_kernel: one row per trip was a round trip per row)
+    for (int t0 = t_lo + tg; t0 < L; t0 += TG * U) {
+      float x[U][8], e[U][8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float al = __expf(e[i] - mx[i]) * iv[i];
-        de[i] = al * (dmu[i] * x[i] + dq[i] * x[i] * x[i] - cst[i]);
-        dx[i] = al * (dmu[i] + 2.f * x[i] * dq[i]);
-        sb[i] += de[i];
+      for (int u = 0; u < U; ++u) {
+        const size_t o = ((size_t)b * T + min(t0 + u * TG, L - 1)) * D + c0;
+        load8(E + o, x[u]);
+        load8(EN + o, e[u]);
       }
-      store8(dEN + o, de);
-      store8(DXD + o, dx);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (t0 + u * TG < L) {
+          const uint32_t row = (uint32_t)b * T + t0 + u * TG;
+          const size_t o = (size_t)row * D + c0;
+          float de[8], dx[8];
+          act8(x[u], scs + vc * 8, shs + vc * 8, actE, row, D, c0);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float al = __expf(e[u][i] - mx[i]) * iv[i];
+            de[i] = al * (dmu[i] * x[u][i] + dq[i] * x[u][i] * x[u][i] - cst[i]);
+            dx[i] = al * (dmu[i] + 2.f * x[u][i] * dq[i]);
+            sb[i] += de[i];
+          }
+          store8(dEN + o, de);
+          store8(DXD + o, dx);
+        }
+      }
     }
   }
 #pragma unroll

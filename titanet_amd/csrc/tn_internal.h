@@ -205,6 +205,7 @@ struct tn_plan {
   // tail_parts workgroups per utterance; their partial sums meet in se_acc / dgate_acc ([block][B][hidden] floats, cleared
   // with the backward zero region; se_acc: [B][parts][hidden] partial sums, reused block after block)
   int tail_parts = 1;
+  int rw_nt = 0;                // tuning (TN_RW_NT): 1 = non-temporal stores of the wide models' forward pointwise outputs, 2 = of their data gradients
   int se_parts = 1;             // workgroups per utterance of the one-launch SE squeeze (se_squeeze_fc_kernel mode 3), counters in se_cnt
   size_t se_cnt = 0;
   size_t se_acc = 0, dgate_acc = 0;

@@ -113,7 +113,7 @@ class MelSpectrogram:
         start = int(min_value.long())
         return start, start + int(value.long())
 
-    def batch(self, waveforms, masks=None, lengths=None, rates=None, freq_masks=None, time_masks=None, into=None):
+    def batch(self, waveforms, masks=None, lengths=None, rates=None, freq_masks=None, time_masks=None, into=None, align_frames=None):
         """[B, A] float waveforms -> [B, n_mels, frames] on the GPU (the collate_fn layout, zero beyond an utterance's end).
 
         masks: optional int32 [B, 4] = (f_start, f_end, t_start, t_end), one interval per axis (``tn_mel_forward``).
@@ -121,7 +121,12 @@ class MelSpectrogram:
         time-stretch rates; freq_masks / time_masks: bool [B, n_mels] / [B, frames] unions of mask intervals.
         into: a bf16 / fp8 ``TitaNet`` on the same device — the spectrogram is then written STRAIGHT into that model's prolog
         operand (bf16 rows x n_mels; no float32 tensor, no packing pass) and a ``PackedSpectrograms`` handle is returned;
-        ``model(handle, speakers)`` runs the network on it, ragged batches with their padding mask (BASELINE configs[3])."""
+        ``model(handle, speakers)`` runs the network on it, ragged batches with their padding mask (BASELINE configs[3]).
+        align_frames: the frame axis is padded to a multiple of this (default: 256 for a ragged batch written ``into`` a model,
+        1 otherwise).  The kernels of a variable-length batch skip 256-row tiles without valid frames; with every utterance
+        starting on a tile boundary only the tile at its END is partly padding (row b * T is otherwise somewhere inside a tile
+        shared with utterance b - 1), and batches whose longest utterance falls in the same 256-frame bucket share one plan.
+        The result does not depend on the padding (lengths mask)."""
         if waveforms.dim() != 2:
             raise ValueError("expected waveforms of shape [B, A]")
         if not torch.cuda.is_available():
@@ -153,6 +158,12 @@ class MelSpectrogram:
         T = max(frames)
         if time_masks is not None:
             T = max(T, time_masks.shape[1])
+        if align_frames is None:
+            align_frames = 256 if (into is not None and lengths is not None) else 1
+        if align_frames > 1:
+            T = -(-T // align_frames) * align_frames
+            if time_masks is not None and time_masks.shape[1] < T:
+                time_masks = torch.nn.functional.pad(time_masks.detach(), (0, T - time_masks.shape[1]))
         out = None if into is not None else torch.empty(B, self.n_mels, T, dtype=torch.float32, device=self.device)
         parts = [(ln, torch.int64, (B,)), (rt, torch.float64, (B,))]
         if freq_masks is not None:
