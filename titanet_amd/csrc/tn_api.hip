@@ -389,6 +389,16 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
     }
     p->dw_table = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * 32);
   }
+  if (p->wide_wgrad && p->wide_dw_bwd && (c.kernel == 7 || c.kernel == 11) && H % 256 == 0 && c.dropout > 0.f) {
+    // wide models: the depthwise tap / bias gradients as stored partial sums + one reduction per gradient bucket
+    // (TN_DW_PART=0: atomics on the gradient buffer, round 5)
+    const char* ep = getenv("TN_DW_PART");
+    if (!(ep && atoi(ep) == 0)) {
+      p->dw_part_stride = (size_t)256 * (c.kernel + 1) * 256 * sizeof(float);
+      p->dw_part = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * p->dw_part_stride);
+      p->dw_table = b.take((size_t)c.n_mega_blocks * c.n_sub_blocks * 32);
+    }
+  }
   if (precision == TN_PREC_BF16) p->se_gu = b.take((size_t)batch * 2 * H * sizeof(float));      // fused mega-block tail backward
   if (p->wide_wgrad) p->a0 = b.take(M * H * e);      // the activated prolog output as a stored operand (first block's skip conv)
   if (p->wide_wgrad) p->tn_table = b.take((size_t)c.n_mega_blocks * (c.n_sub_blocks + 1) * 64);   // >= sizeof(PGemmTnDesc) each
@@ -428,7 +438,10 @@ extern "C" int tn_plan_create(const tn_model* m, int32_t batch, int32_t frames, 
       // wide models: the skip conv's output and the skip data gradient (pipelined GEMMs) stored non-temporal; TN_NT_SKIP=0 turns it off
       const char* en = getenv("TN_NT_SKIP");
       p->nt_skip = !(en && atoi(en) == 0);
-      { const char* er = getenv("TN_RW_NT"); p->rw_nt = er ? atoi(er) : 0; }
+      // the wide models' forward pointwise outputs (read by the next depthwise launch, then not before the backward pass):
+      // same-box A/B (tools/env_ab.sh, TN_RW_NT=0 / 1): L bf16 20.02 -> 19.84 ms, L fp8 16.69 -> 16.64, M 14.37 -> 14.34, configs[3]
+      // 10.09 -> 10.00; bit 2 (their data gradients) is worse on M (14.25 -> 14.51)
+      { const char* er = getenv("TN_RW_NT"); p->rw_nt = er ? atoi(er) : 1; }
     }
     if (p->overlap) {
       if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) { p->side = nullptr; p->overlap = false; }

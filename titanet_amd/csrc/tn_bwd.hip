@@ -173,6 +173,8 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
   auto tn_entries = [&](int blk) { return nsub + ((blk > 0 || p->a0) ? 1 : 0); };
   auto tn_offset = [&](int blk) { int o = 0; for (int k = c.n_mega_blocks - 1; k > blk; --k) o += tn_entries(k); return o; };
   const bool v2_bwd = sizeof(AT) == 2 && use_v2;
+  // wide models: tap / bias gradients of the depthwise convs from stored partial sums (dw_part_reduce_kernel, per bucket)
+  const bool dw_part = sizeof(AT) == 2 && !use_v2 && p->dw_part != 0 && training && p->wide_dw_bwd && H % V2_C == 0;
   const bool ov = p->overlap && v2_bwd && p->side != nullptr;      // independent launches on the plan's side stream (tn_internal.h)
   // round 4: the mega-block tail backward in ONE pass (combine_bwd1_v3 finishes the SE backward per utterance; the last
   // sub-block's fused data-gradient kernel rebuilds its incoming gradient on load and stores the BatchNorm-backward'd dS for
@@ -213,6 +215,10 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
       }
       if (rc) { rc_fin = rc; return; }
     }
+    if (dw_part && has_blocks)
+      hipLaunchKernelGGL(dw_part_reduce_kernel, dim3((bk.blk_hi - bk.blk_lo + 1) * nsub, H / V2_C, c.kernel + 1), dim3(256), 0, st,
+                         (const DwGradOut*)(ws + p->dw_table) + (size_t)bk.blk_lo * nsub, c.kernel, H / V2_C,
+                         dw_bwd_slab_per(M, H, (p->masked && p->skip_pad_tiles) ? p->n_rowtiles : 0, 256));
     if (v2_bwd && has_blocks)
       hipLaunchKernelGGL(dw_grad_finalize_kernel, dim3((bk.blk_hi - bk.blk_lo + 1) * nsub), dim3(256), 0, st,
                          (const DwGradOut*)(ws + p->dw_table) + (size_t)bk.blk_lo * nsub, c.kernel);
@@ -713,9 +719,11 @@ int backward_impl(tn_plan* p, float gs, const float* gs_dev, const float* g_emb,
         sa.OUT = (bf16_t*)da.OUT; sa.wdw = da.wdw; sa.g_wdw = da.g_wdw; sa.g_bdw = da.g_bdw; sa.bsumsX = da.bsumsX;
         sa.M = M; sa.T = T; sa.C = H;
         if (p->masked && p->skip_pad_tiles && p->n_rowtiles > 0) { sa.rowtiles = (const int*)(ws + p->rowtiles); sa.n_rowtiles = p->n_rowtiles; }
+        if (dw_part) sa.gpart = (float*)(ws + p->dw_part + (size_t)(i * nsub + j) * p->dw_part_stride);
         ProfScope ps(p, TN_PROF_BWD_DW, st);
         rc = c.kernel == 7 ? launch_dw_bwd_slab<7>(sa, 256, st) : launch_dw_bwd_slab<11>(sa, 256, st);
         if (rc > 0) return rc;
+        if (rc == -1000 && dw_part) return TN_E_STATE;      // (the bucket's reduction would overwrite the generic kernel's sums)
       }
       if (rc == -1000) {
         ProfScope ps(p, TN_PROF_BWD_DW, st);
@@ -970,6 +978,22 @@ int plan_upload_bwd_tables(tn_plan* p, hipStream_t st) {
     if (sizeof(DwGradOut) > 32) return TN_E_STATE;
     TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->dw_table, dg.data(), dg.size() * sizeof(DwGradOut), hipMemcpyHostToDevice, st));
     TN_CHECK_HIP(hipStreamSynchronize(st));      // wd, wd2, wo, dg are pageable sources of the copies above
+  }
+  if (p->dw_part && !p->use_v2) {
+    // wide models: where dw_part_reduce_kernel finds a layer's partial records and puts its tap / bias gradients
+    const tn_config& c = m->cfg;
+    std::vector<DwGradOut> dg;
+    for (int i = 0; i < c.n_mega_blocks; ++i)
+      for (int j = 0; j < c.n_sub_blocks; ++j) {
+        DwGradOut o;
+        o.gacc = (const float*)(p->ws + p->dw_part + (size_t)(i * c.n_sub_blocks + j) * p->dw_part_stride);
+        o.g_wdw = p->grads + m->blocks[i].sub[j].wdw;
+        o.g_bdw = p->grads + m->blocks[i].sub[j].bdw;
+        dg.push_back(o);
+      }
+    if (sizeof(DwGradOut) > 32) return TN_E_STATE;
+    TN_CHECK_HIP(hipMemcpyAsync(p->ws + p->dw_table, dg.data(), dg.size() * sizeof(DwGradOut), hipMemcpyHostToDevice, st));
+    TN_CHECK_HIP(hipStreamSynchronize(st));
   }
   TN_CHECK_HIP(hipStreamSynchronize(st));
   return 0;

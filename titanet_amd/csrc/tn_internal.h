@@ -205,6 +205,8 @@ struct tn_plan {
   // tail_parts workgroups per utterance; their partial sums meet in se_acc / dgate_acc ([block][B][hidden] floats, cleared
   // with the backward zero region; se_acc: [B][parts][hidden] partial sums, reused block after block)
   int tail_parts = 1;
+  size_t dw_part = 0;           // wide models: partial tap-gradient records of dw_bwd_slab_kernel [layer][256 workgroups][K + 1][256] (dw_part_reduce_kernel)
+  size_t dw_part_stride = 0;    // bytes per layer
   int rw_nt = 0;                // tuning (TN_RW_NT): 1 = non-temporal stores of the wide models' forward pointwise outputs, 2 = of their data gradients
   int se_parts = 1;             // workgroups per utterance of the one-launch SE squeeze (se_squeeze_fc_kernel mode 3), counters in se_cnt
   size_t se_cnt = 0;

@@ -1148,6 +1148,10 @@ struct DwBwdSlabArgs {
   float* g_wdw;        // [C][KD] (atomic accumulate, pre-zeroed)
   float* g_bdw;        // [C]
   float* bsumsX;       // [TN_NREP][2][C] or null
+  // round 6: the tap-weight / bias gradient sums of a workgroup are STORED here ([gridDim.x][KD + 1][256], plain coalesced
+  // stores) and added up by dw_part_reduce_kernel when the gradient bucket is finalised, instead of 2 K atomics per workgroup
+  // on g_wdw (stride-K addresses, 256 workgroups per address): 14 of 48 us per TitaNet-M launch were those atomics.  null: atomics
+  float* gpart;
   int M, T, C, ntiles;
   const int* rowtiles; int n_rowtiles;      // as DwFwdSlabArgs: the 256-row tiles with valid frames (variable-length batches) or null
 };
@@ -1383,6 +1387,7 @@ __global__ __launch_bounds__(512, 2) void dw_bwd_slab_kernel(DwBwdSlabArgs a) {
 #pragma unroll
     for (int w = 0; w < 8 / WPS; ++w) v += red[(size_t)w * (KD + 3) * V2_C + i];
     const int k = i / V2_C, c = cb + i % V2_C;
+    if (a.gpart && k <= KD) { a.gpart[(size_t)blockIdx.x * (KD + 1) * V2_C + i] = v; continue; }
     if (k < KD) atomic_add_f32(&a.g_wdw[(size_t)c * KD + k], v);
     else if (k == KD) atomic_add_f32(&a.g_bdw[c], v);
     else if (a.bsumsX && HAS_MASK) atomic_add_f32(&a.bsumsX[(size_t)(rep * 2 + (k - KD - 1)) * a.C + c], v);
@@ -1399,6 +1404,33 @@ inline int launch_dw_bwd_slab_t(DwBwdSlabArgs a, int grid, hipStream_t st) {
   return (int)hipGetLastError();
 }
 // -1000: no specialisation for this (taps, flags) combination (caller runs the generic dw_bwd_kernel)
+// workgroups per 256-channel slab of a dw_bwd_slab launch (the launcher's grid / nslab; dw_part_reduce_kernel's partial count)
+inline int dw_bwd_slab_per(int M, int C, int n_rowtiles, int max_wgs) {
+  const int ntiles = n_rowtiles > 0 ? n_rowtiles * 4 : (M + 63) / 64;
+  int per = max_wgs / (C / V2_C);
+  if (per < 1) per = 1;
+  return per > ntiles ? ntiles : per;
+}
+// gradient sums of the depthwise taps / bias from the partial records of dw_bwd_slab_kernel (DwBwdSlabArgs::gpart):
+// grid (layers, C / 256, KD + 1); workgroup blockIdx.x of the slab kernel worked on slab blockIdx.x % nslab.  Fixed order:
+// the result does not depend on the order the workgroups ran in.
+__global__ __launch_bounds__(256) void dw_part_reduce_kernel(const DwGradOut* __restrict__ outs, int KD, int nslab, int per) {
+  const DwGradOut o = outs[blockIdx.x];
+  const int slab = blockIdx.y, k = blockIdx.z, c = threadIdx.x;
+  const float* src = o.gacc + ((size_t)slab * (KD + 1) + k) * V2_C + c;
+  const size_t step = (size_t)nslab * (KD + 1) * V2_C;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int w = 0;
+  for (; w + 8 <= per; w += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] += src[(size_t)(w + u) * step];
+  }
+  for (; w < per; ++w) v[0] += src[(size_t)w * step];
+  const float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  const int cg = slab * V2_C + c;
+  if (k < KD) o.g_wdw[(size_t)cg * KD + k] = s;
+  else o.g_bdw[cg] = s;
+}
 template <int KD>
 inline int launch_dw_bwd_slab(DwBwdSlabArgs a, int max_wgs, hipStream_t st) {
   if (a.C % V2_C != 0) return -1000;
