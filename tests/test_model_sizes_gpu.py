@@ -266,3 +266,46 @@ def test_narrow_configs_cast_every_bf16_weight(hidden, enc_out, attn):
     print(hidden, enc_out, attn, "eval emb rel", e, "train loss", float(lv.detach()))
     assert np.isfinite(ev).all() and torch.isfinite(g).all() and np.isfinite(float(lv.detach()))
     assert e < 1.5e-3, e      # (7.4e-4 here; 2.5e-3 with the unwritten pooling weight copy of the round-5 library)
+
+
+@pytest.mark.parametrize("size", ["m", "l"])
+def test_wide_depthwise_gradients_from_partial_sums(size, monkeypatch):
+    """Round 6: dw_bwd_slab_kernel stores its per-workgroup sums of the depthwise tap / bias gradients and dw_part_reduce_kernel
+    adds them up per gradient bucket (TN_DW_PART, default on) instead of atomics on the gradient buffer: same gradients as
+    the atomics path on every parameter (what differs is float summation order), ragged batch included."""
+    from titanet_amd import LOSSES, TitaNet
+
+    def run(lengths):
+        torch.manual_seed(5)
+        m = TitaNet.get_titanet(n_mega_blocks=2, model_size=size, loss_function=LOSSES["ce"](192, 20, device="cuda"), dropout=0.1,
+                                device="cuda", precision="bf16").train()
+        g = torch.Generator().manual_seed(6)
+        x = (torch.randn(6, 80, 300, generator=g) * 0.11 - 0.1).cuda()
+        y = torch.randint(0, 20, (6,), generator=g).cuda()
+        m._seed_base, m._step = 3, 0
+        _, _, lv = m(x, speakers=y, lengths=lengths)
+        lv.backward()
+        torch.cuda.synchronize()
+        return float(lv), {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
+
+    for lengths in (None, torch.tensor([300, 120, 257, 64, 300, 200])):
+        monkeypatch.delenv("TN_DW_PART", raising=False)
+        la, ga = run(lengths)
+        monkeypatch.setenv("TN_DW_PART", "0")
+        lb, gb = run(lengths)
+        monkeypatch.delenv("TN_DW_PART")
+        assert abs(la - lb) < 2e-2
+        n_dw = 0
+        for k in ga:
+            if ".conv.0." in k:
+                n_dw += 1
+            if k.endswith(".bias") and k.replace(".bias", ".weight") in ga:
+                # a bias in front of a BatchNorm has a zero gradient in exact arithmetic: both paths hold rounding noise there,
+                # compared on the scale of the layer's weight gradient
+                scale = np.abs(ga[k.replace(".bias", ".weight")]).max()
+                assert np.abs(ga[k] - gb[k]).max() < 2e-2 * max(scale, 1e-6), (k, np.abs(ga[k] - gb[k]).max(), scale)
+                continue
+            e = rel_err(ga[k], gb[k])
+            assert e < 2e-2, (k, e)
+        assert n_dw >= 8
+        print(size, "ragged" if lengths is not None else "fixed", "parameters compared", len(ga), "depthwise", n_dw)
