@@ -31,6 +31,21 @@ int main(int argc, char** argv) {
   a.act.drop_thr = 6554; a.act.inv_keep = 1.f / 0.9f; a.act.drop_key = 12345;
   a.wdw = wdw; a.bdw = bdw; a.W = W; a.bias = bias; a.stats = ostats; a.M = M; a.T = T; a.Wswz = swz;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  if (argc > 1 && !strcmp(argv[1], "sweep")) {
+    // fixed cost per launch: the shipped form (32-row tiles, depthwise output kept) over the row count, down to one tile per launch
+    for (int m : {32, 2400, 9600, 19200, 38400, 76800}) {
+      a.M = m;
+      auto go = [&](int it) { const int s = it % NSET; a.X = X[s]; a.Y = Y[s]; a.Q = Q[s]; return launch_sub_fwd_v5<3, true, 32>(a, 256, 0); };
+      for (int it = 0; it < 4; ++it) go(it);
+      CK(hipDeviceSynchronize());
+      hipEventRecord(e0, 0);
+      for (int it = 0; it < 40; ++it) go(it);
+      hipEventRecord(e1, 0); CK(hipEventSynchronize(e1));
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      printf("sub_fwd_v5<3,true,7,32> M = %6d rows: %.2f us per launch\n", m, ms * 1e3f / 40);
+    }
+    return 0;
+  }
   for (int rep = 0; rep < 2; ++rep)
     for (int variant = 0; variant < 4; ++variant) {
       const bool r32 = variant & 1, keepq = !(variant & 2);
