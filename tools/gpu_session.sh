@@ -11,6 +11,11 @@
 #         profiles                       tools/collect_profiles.sh <tag> (kernel stats + PMC traffic -> gpurun_out/)
 #         sq                             tools/collect_sq_counters.sh <tag>
 #         py:SCRIPT[:args]               python tools/SCRIPT args
+#         legab:LEG:ENV:ROUNDS:V1,V2,..  same-box A/B of ONE other_configs leg under ENV=V1 / V2 / .. (tools/env_ab.sh)
+#         legprof:LEG                    kernel-time table of one other_configs leg (tools/prof_leg.sh)
+#         gaps:LEG                       idle time between the kernels of one leg (tools/gap_leg.sh)
+#         intercept                      fixed cost per launch of the headline kernels, batch 128 vs 256 (tools/intercept.sh)
+#         pgemmpmc[:M:N:K]               SQ counters of pgemm_nt and its compiled-out variants (tools/pgemm_counters.sh)
 tag=$1; shift
 mkdir -p gpurun_out
 for task in "$@"; do
@@ -28,6 +33,11 @@ for task in "$@"; do
     profiles) (bash tools/collect_profiles.sh $tag 2>&1 | tail -30) > $out ;;
     sq)      (bash tools/collect_sq_counters.sh $tag 2>&1 | tail -30) > $out ;;
     py)      (timeout 1800 python tools/$a1 $a2 $a3 $a4 2>&1 | grep -v amdgpu.ids | tail -100) > gpurun_out/${tag}_${a1%.py}.txt; out=gpurun_out/${tag}_${a1%.py}.txt ;;
+    legab)   (timeout 2400 bash tools/env_ab.sh $a1 $a2 ${a3:-2} $(echo "$a4" | tr ',' ' ') 2>&1) > $out ;;
+    legprof) (bash tools/prof_leg.sh ${tag}_$a1 $a1 2>&1 | cut -c1-200) > $out ;;
+    gaps)    (bash tools/gap_leg.sh ${tag}_gap $a1 2>&1 | cut -c1-200) > $out ;;
+    intercept) (bash tools/intercept.sh ${tag}_ic 2>&1 | cut -c1-160) > $out ;;
+    pgemmpmc) (bash tools/pgemm_counters.sh ${tag}_pgemm $a1 $a2 $a3 2>&1 | cut -c1-330) > $out ;;
     *)       echo "unknown task $task" ;;
   esac
   tail -40 $out | cut -c1-400
