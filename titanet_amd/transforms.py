@@ -161,9 +161,7 @@ class MelSpectrogram:
         if align_frames is None:
             align_frames = 256 if (into is not None and lengths is not None) else 1
         if align_frames > 1:
-            T = -(-T // align_frames) * align_frames
-            if time_masks is not None and time_masks.shape[1] < T:
-                time_masks = torch.nn.functional.pad(time_masks.detach(), (0, T - time_masks.shape[1]))
+            T = -(-T // align_frames) * align_frames      # (_upload zero-pads a narrower time mask inside its pinned slot)
         out = None if into is not None else torch.empty(B, self.n_mels, T, dtype=torch.float32, device=self.device)
         parts = [(ln, torch.int64, (B,)), (rt, torch.float64, (B,))]
         if freq_masks is not None:
